@@ -1,0 +1,191 @@
+/*
+ * protoasnet_amd.h -- C-ABI of the MI355X (gfx950) ProtoASNet hot path.
+ *
+ * The reference (hooman007/ProtoASNet) has no FFI / operator registry: its hot path is a
+ * stack of torch.nn calls inside three nn.Modules.  This header is
+ * the boundary a replacement exports *under* that nn.Module surface: one entry point per
+ * fused stage, each citing the reference call site(s) it replaces.  The Python host side
+ * (the protoasnet_amd Python package) binds these with ctypes and keeps the reference's module surface
+ * (forward / push_forward / compute_occurence_map / state_dict keys) on top.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - Every pointer is DEVICE memory owned by the caller (torch's caching allocator).  The
+ *     library never allocates, frees or retains device memory.  Workspaces are passed in.
+ *   - Work is enqueued asynchronously on the caller's HIP stream (`stream`, a hipStream_t);
+ *     no internal streams, no host synchronisation, safe to capture into a hipGraph.
+ *   - Return 0 on success; non-zero = error, message via pasn_last_error() (thread-local).
+ *   - dtype: PASN_F32 = 0, PASN_BF16 = 1.  Arithmetic always accumulates in fp32.
+ *   - Activations are CHANNELS-LAST: [N][T][H][W][Cp] (T = 1 for images) with the channel
+ *     stride Cp a multiple of 8 and channels >= C stored as zeros.  A logical NC(T)HW view
+ *     of such a buffer is what the nn.Module surface hands back to reference callers.
+ */
+#ifndef PROTOASNET_AMD_H
+#define PROTOASNET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PASN_VERSION 100 /* round 1 */
+
+enum { PASN_F32 = 0, PASN_BF16 = 1 };
+enum { PASN_ACT_NONE = 0, PASN_ACT_RELU = 1, PASN_ACT_SIGMOID = 2, PASN_ACT_SWISH = 3, PASN_ACT_ABS = 4 };
+enum { PASN_OK = 0, PASN_ERR_ARG = 1, PASN_ERR_LAUNCH = 2, PASN_ERR_UNSUPPORTED = 3 };
+
+int pasn_version(void);
+const char* pasn_last_error(void);
+
+/* Geometry of one convolution / pooling window over channels-last activations. */
+typedef struct pasn_conv_desc {
+    int32_t N, Ti, Hi, Wi;    /* input extent                                              */
+    int32_t Cin, Cin_p;       /* input channels, input channel stride (elements)           */
+    int32_t To, Ho, Wo;       /* output extent                                             */
+    int32_t Cout, Cout_p;     /* output channels, output channel stride (elements)         */
+    int32_t kt, kh, kw;       /* window                                                    */
+    int32_t st, sh, sw;       /* stride                                                    */
+    int32_t pt, ph, pw;       /* zero padding (max-pool: -inf padding)                     */
+    int32_t act;              /* PASN_ACT_* applied after scale/bias (+ residual)          */
+    int32_t in_swish;         /* conv3d: apply x*sigmoid(x) to the INPUT while loading it  */
+    int32_t w_kc;             /* conv3d: per-tap K extent of the packed weight (elements)  */
+    int32_t w_rows;           /* conv3d: rows of the packed weight / scale / bias arrays   */
+} pasn_conv_desc;
+
+/*
+ * First layer: planar (N,3,T,H,W) clip -> channels-last activation, window (1,kh,kw), fused
+ * per-channel scale/bias (folded eval-mode BatchNorm) and activation.
+ * Replaces: resnet_features.py:203-205 (conv1+bn1+relu), torchvision R2Plus1dStem conv 0-2
+ * (call site resnet_features.py:316-320), X3D stem conv_xy.
+ *   x      : in_dtype  [N][3][Ti][Hi][Wi]
+ *   w      : fp32 [3*kh*kw][Cout_p]  (tap-major, channel-minor; rows ordered ci, r, s)
+ *   scale, bias : fp32 [Cout_p]
+ *   y      : out_dtype [N][To][Ho][Wo][Cout_p]
+ */
+int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                        const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream);
+
+/*
+ * Dense convolution as an implicit GEMM on the matrix cores (MFMA), channels-last, groups=1, any
+ * window/stride/padding, fused epilogue  y = act(acc*scale + bias [+ residual]).
+ * Optional fused input transform (X3D project conv): x' = swish(x * gate[n][ci]).
+ * Replaces: every nn.Conv2d/Conv3d + BatchNorm (+ReLU, + residual add) of the trunks
+ * (resnet_features.py:49-66,202-213; torchvision Conv2Plus1D/BasicBlock at :316-320), the 1x1(x1)
+ * add-on convs of PPNet (ProtoPNet.py:117-130) and the X3D expand / project / shortcut convs.
+ *   x     : dtype [N][Ti][Hi][Wi][Cin_p]
+ *   w     : dtype [w_rows][kt*kh*kw][w_kc], zero padded (w_rows multiple of 128, w_kc multiple of
+ *           16 (bf16) / 8 (fp32) and >= Cin_p)
+ *   scale, bias : fp32 [w_rows]
+ *   residual : dtype [N][To][Ho][Wo][Cout_p] or NULL
+ *   gate  : fp32 [N][Cin_p] or NULL
+ *   y     : dtype [N][To][Ho][Wo][Cout_p]
+ */
+int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
+                    const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream);
+
+/*
+ * Depthwise convolution (groups = C), channels-last, fused scale/bias/activation; optionally also
+ * emits per-block partial channel sums of the (pre-activation) output for the squeeze-excite pool.
+ * Replaces: X3D stem conv_t + BN + ReLU and X3D conv_b + BN (+Swish); HBM-bound stencil.
+ *   w     : fp32 [kt*kh*kw][Cp]
+ *   pool_partial : fp32 [N][pool_blocks][Cp] or NULL; pool_blocks = pasn_dwconv3d_pool_blocks(d)
+ */
+int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d);
+int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                      float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream);
+
+/*
+ * Squeeze-excite gate: mean over positions (from the partial sums above, fixed summation order),
+ * fc1 + ReLU, fc2 + sigmoid.   gate : fp32 [N][Cp].
+ *   w1 : fp32 [Cse][C], b1 : fp32 [Cse], w2 : fp32 [C][Cse], b2 : fp32 [C]
+ */
+int pasn_se_gate_fwd(const float* pool_partial, int pool_blocks, int positions, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* gate, int N, int C, int Cp, int Cse, void* stream);
+
+/* Max pooling, channels-last.  Replaces nn.MaxPool2d(3,2,1) at resnet_features.py:206. */
+int pasn_maxpool3d_fwd(const void* x, void* y, const pasn_conv_desc* d, int dtype, void* stream);
+
+/*
+ * Head A -- PPNet prototype layer.  Replaces PPNet._l2_convolution (ProtoPNet.py:189-207: the ones-conv
+ * for ||x||^2, the prototype conv for x.p, relu), the global min pooling + distance_2_similarity + last_layer
+ * of PPNet.forward (ProtoPNet.py:236-241), and the distance map of push_forward (ProtoPNet.py:245-249).
+ *   z        : dtype [N][S][Dp]      add-on output (after Sigmoid), channels-last
+ *   protos   : fp32 [P][D]
+ *   fc_w     : fp32 [K][P]           last_layer.weight
+ *   dist     : fp32 [N][P][S] or NULL  (full map, planar like the reference's (N,P,H,W))
+ *   min_dist : fp32 [N][P]
+ *   argmin   : int32 [N][P] or NULL  first s attaining the minimum
+ *   logits   : fp32 [N][K]
+ *   activation: 0 = log((d+1)/(d+eps)), 1 = linear (-d)
+ */
+int pasn_l2_head_fwd(const void* z, const float* protos, const float* fc_w, float* dist, float* min_dist,
+                     int32_t* argmin, float* logits, int N, int S, int D, int Dp, int P, int K, int dtype,
+                     int activation, float eps, void* stream);
+
+/*
+ * Head B -- XProtoNet / Video_XProtoNet ("ProtoASNet") prototype layer: add-on convs, occurrence module + abs,
+ * occurrence-weighted pooling WITHOUT materialising the (N,P,D,S) broadcast product of Video_XProtoNet.py:87 /
+ * XProtoNet.py:56, cosine similarity (torch semantics: each vector divided by max(norm, 1e-8) first), (s+1)/2,
+ * last layer.  Replaces everything after the trunk in Video_XProtoNet.forward / push_forward
+ * (Video_XProtoNet.py:82-130), XProtoNet.forward / push_forward (XProtoNet.py:51-106) and, with mode = 1,
+ * the head part of compute_occurence_map (Video_XProtoNet.py:100-109, XProtoNet.py:69-85).
+ *   x      : dtype [N][S][Cbp]  trunk features, channels-last
+ *   a1,a2  : add_on_layers.{0,2}.weight;  o1,o2,o3 : occurrence_module.{0,2,4}.weight -- each packed like a
+ *            pasn_conv3d_fwd weight with one tap: dtype [round_up(Cout_p,128)][round_up(Cin_p, 16|8)], zero padded
+ *   a1b,a2b,o1b,o2b : fp32 biases [round_up(Cout_p,128)], zero padded (o3 has no bias)
+ *   protos : fp32 [P][D];  fc_w : fp32 [K][P]
+ *   occ    : fp32 [N][P][S]   planar, i.e. the reference's (N,P,1,[T,]H,W)
+ *   feat   : fp32 [N][P][D]   features_extracted;   sim : fp32 [N][P];   logits : fp32 [N][K]
+ *   ws     : workspace of pasn_xproto_head_workspace_bytes() bytes, 256-byte aligned
+ *   mode   : 0 = full forward, 1 = occurrence map only (feat / sim / logits may be NULL)
+ */
+typedef struct pasn_xproto_desc {
+    int32_t N, S;
+    int32_t Cb, Cbp;   /* trunk channels and channel stride        */
+    int32_t D, Dp;     /* prototype depth, round_up(D, 8)          */
+    int32_t Hd, Hp;    /* D / 2 (hidden width of the occurrence module), round_up(Hd, 8) */
+    int32_t P, Pp;     /* prototypes, round_up(P, 8)               */
+    int32_t K;         /* classes                                   */
+    int32_t mode;
+} pasn_xproto_desc;
+
+int pasn_xproto_head_splits(const pasn_xproto_desc* d);
+size_t pasn_xproto_head_workspace_bytes(const pasn_xproto_desc* d, int dtype);
+int pasn_xproto_head_fwd(const void* x, const void* a1, const float* a1b, const void* a2, const float* a2b,
+                         const void* o1, const float* o1b, const void* o2, const float* o2b, const void* o3,
+                         const float* protos, const float* fc_w, float* occ, float* feat, float* sim, float* logits,
+                         void* ws, const pasn_xproto_desc* d, int dtype, void* stream);
+
+/*
+ * Push sweep, XProtoNet / Video rule (push_abs_revision.py:288-307): per prototype j, over the clips of
+ * this batch whose label matches class(j) (or all clips when class_mask[j] == 0): batch min of
+ * proto_dist[:, j], first index; accepted when min <= best (a later batch wins ties).  State stays on the device.
+ *   proto_dist : fp32 [B][P]   (1 - similarity)
+ *   feat       : fp32 [B][P][D]
+ *   labels     : int64 [B]
+ *   proto_class: int32 [P]     argmax of prototype_class_identity
+ *   class_mask : int32 [P]     1 = class specific
+ *   best_dist  : fp32 [P]  (init +inf);  best_index : int64 [P] (init -1; global clip index = index_base + b)
+ *   best_feat  : fp32 [P][D]
+ */
+int pasn_push_xproto_update(const float* proto_dist, const float* feat, const int64_t* labels, const int32_t* proto_class,
+                            const int32_t* class_mask, float* best_dist, int64_t* best_index, float* best_feat, int B, int P,
+                            int D, int64_t index_base, void* stream);
+
+/*
+ * Push sweep, PPNet rule (push_ProtoPNet.py:198-235): per prototype j, argmin over the flattened (n_c,h,w) of the
+ * distance map restricted to images of class(j) (all images when class_specific == 0); accepted on strict '<'
+ * (the first batch wins ties); the winning 1x1 patch of the add-on output is copied.
+ *   dist : fp32 [B][P][S];  z : dtype [B][S][Dp] channels-last add-on output
+ *   best_dist fp32 [P] (+inf), best_index int64 [P][2] = (global image index, s) (-1), best_patch fp32 [P][D]
+ */
+int pasn_push_ppnet_update(const float* dist, const void* z, const int64_t* labels, const int32_t* proto_class,
+                           int class_specific, float* best_dist, int64_t* best_index, float* best_patch, int B, int P, int S,
+                           int D, int Dp, int dtype, int64_t index_base, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROTOASNET_AMD_H */

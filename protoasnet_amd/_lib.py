@@ -1,0 +1,95 @@
+"""ctypes binding of ``libprotoasnet_amd.so`` (C-ABI in ``include/protoasnet_amd.h``).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails,
+the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "swish": 3, "abs": 4}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libprotoasnet_amd.so")
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "N", "Ti", "Hi", "Wi", "Cin", "Cin_p", "To", "Ho", "Wo", "Cout", "Cout_p",
+        "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "in_swish", "w_kc", "w_rows",
+    )]
+
+
+class XProtoDesc(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("N", "S", "Cb", "Cbp", "D", "Dp", "Hd", "Hp", "P", "Pp", "K", "mode")]
+
+
+# name -> (restype, argtypes); every symbol the header declares
+SIGNATURES = {
+    "pasn_version": (c_int, []),
+    "pasn_last_error": (c_char_p, []),
+    "pasn_first_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
+    "pasn_conv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_dwconv3d_pool_blocks": (c_int, [POINTER(ConvDesc)]),
+    "pasn_dwconv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_se_gate_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pasn_maxpool3d_fwd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_l2_head_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "pasn_xproto_head_splits": (c_int, [POINTER(XProtoDesc)]),
+    "pasn_xproto_head_workspace_bytes": (c_size_t, [POINTER(XProtoDesc), c_int]),
+    "pasn_xproto_head_fwd": (c_int, [c_void_p] * 17 + [POINTER(XProtoDesc), c_int, c_void_p]),
+    "pasn_push_xproto_update": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int64, c_void_p]),
+    "pasn_push_ppnet_update": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises if it has not been built (``python __graft_entry__.py`` builds it)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().pasn_last_error().decode("utf-8", "replace")
+        if rc == 1:
+            raise ValueError(f"protoasnet_amd: {msg}")
+        raise RuntimeError(f"protoasnet_amd (status {rc}): {msg}")
+
+
+def dtype_code(dtype) -> int:
+    import torch
+
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"protoasnet_amd kernels compute in float32 or bfloat16, not {dtype}")
+
+
+def ptr(t) -> int:
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,530 @@
+// Trunk kernels for gfx950: first-layer conv (planar clip -> channels-last), dense conv as implicit GEMM on
+// MFMA, depthwise stencil with fused squeeze-excite partial sums, squeeze-excite gate, max pooling.
+//
+// Layout: activations are channels-last [N][T][H][W][Cp], Cp % 8 == 0, channels >= C are zero.  A wave's
+// 64 lanes read 16-byte channel chunks of consecutive positions, so every global access is a whole
+// number of 16-byte pieces of contiguous rows (Cp*elem bytes per position, positions contiguous).
+#include "common.h"
+
+namespace pasn {
+
+// =================================================================================================
+// first conv: planar (N,3,T,H,W) -> channels-last, window (1,kh,kw).  One thread = one output position x
+// all COP output channels; the 3*kh*kw x COP weight matrix sits in LDS and is read as broadcasts.
+// =================================================================================================
+template <typename TIN, typename TOUT, int COP>
+__global__ __launch_bounds__(256) void first_conv_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ scale, const float* __restrict__ bias,
+                                                         TOUT* __restrict__ y, pasn_conv_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [3*kh*kw][COP]
+    const int taps = 3 * d.kh * d.kw;
+    for (int i = threadIdx.x; i < taps * COP; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+
+    const long M = (long)d.N * d.To * d.Ho * d.Wo;
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int wo = (int)(m % d.Wo);
+    long r = m / d.Wo;
+    const int ho = (int)(r % d.Ho);
+    r /= d.Ho;
+    const int t = (int)(r % d.To);
+    const int n = (int)(r / d.To);
+
+    float acc[COP];
+#pragma unroll
+    for (int c = 0; c < COP; ++c) acc[c] = 0.0f;
+
+    const long plane = (long)d.Hi * d.Wi;
+    for (int ci = 0; ci < 3; ++ci) {
+        const TIN* xp = x + (((long)n * 3 + ci) * d.Ti + t) * plane;
+        for (int kr = 0; kr < d.kh; ++kr) {
+            const int hi = ho * d.sh - d.ph + kr;
+            if (hi < 0 || hi >= d.Hi) continue;
+            for (int ks = 0; ks < d.kw; ++ks) {
+                const int wi = wo * d.sw - d.pw + ks;
+                if (wi < 0 || wi >= d.Wi) continue;
+                const float xv = (float)xp[(long)hi * d.Wi + wi];
+                const float* wr = wl + ((ci * d.kh + kr) * d.kw + ks) * COP;
+#pragma unroll
+                for (int c = 0; c < COP; c += 4) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+                    acc[c + 0] = fmaf(xv, wv[0], acc[c + 0]);
+                    acc[c + 1] = fmaf(xv, wv[1], acc[c + 1]);
+                    acc[c + 2] = fmaf(xv, wv[2], acc[c + 2]);
+                    acc[c + 3] = fmaf(xv, wv[3], acc[c + 3]);
+                }
+            }
+        }
+    }
+    TOUT* yp = y + m * COP;
+#pragma unroll
+    for (int c = 0; c < COP; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float s = acc[c + j] * scale[c + j] + bias[c + j];
+            v[j] = (c + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
+        }
+        store8(yp + c, v);
+    }
+}
+
+template <typename TIN, typename TOUT>
+static int launch_first_conv(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                             const pasn_conv_desc& d, hipStream_t s) {
+    const long M = (long)d.N * d.To * d.Ho * d.Wo;
+    const dim3 grid(ceil_div(M, 256)), block(256);
+    const size_t lds = (size_t)3 * d.kh * d.kw * d.Cout_p * sizeof(float);
+#define PASN_FC(COP)                                                                                          \
+    case COP:                                                                                                  \
+        hipLaunchKernelGGL((first_conv_kernel<TIN, TOUT, COP>), grid, block, lds, s, (const TIN*)x, w, scale, \
+                           bias, (TOUT*)y, d);                                                                 \
+        break;
+    switch (d.Cout_p) {
+        PASN_FC(8)
+        PASN_FC(16)
+        PASN_FC(24)
+        PASN_FC(32)
+        PASN_FC(48)
+        PASN_FC(64)
+        default:
+            set_error("pasn_first_conv_fwd: Cout_p must be one of 8,16,24,32,48,64");
+            return PASN_ERR_UNSUPPORTED;
+    }
+#undef PASN_FC
+    return check_launch("first_conv_kernel");
+}
+
+// =================================================================================================
+// dense conv as implicit GEMM on MFMA.
+//   D[co][pos] = sum_{tap, ci} W[co][tap][ci] * X[inpos(pos, tap)][ci]
+// A operand = packed weights (row = output channel), B operand = activations (column = output position),
+// both fetched straight from global/L2 in fragment shape: lane (r, h) reads the 16 bytes that hold k values
+// k0 + h*CH .. of row/column r.  One wave owns MT x 32 positions and NT x 32 output channels; a block is 4
+// waves = 4*MT*32 consecutive positions; blockIdx.y walks output-channel chunks of NT*32.
+// Epilogue: the accumulator keeps the position on the lane and 4 consecutive output channels per register
+// quad, so each quad becomes one 8-byte (bf16) / 16-byte (fp32) channels-last store.
+// =================================================================================================
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::frag gate_swish(typename Traits<T>::frag f, const float* gate, bool swish) {
+    constexpr int CH = Traits<T>::CH;
+    typename Traits<T>::frag o;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        float v = (float)f[j];
+        if (gate) v *= gate[j];
+        if (swish) v = v * sigmoidf_(v);
+        o[j] = (T)v;
+    }
+    return o;
+}
+
+template <typename T, int NT, int MT>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                          const float* __restrict__ scale, const float* __restrict__ bias,
+                                                          const T* __restrict__ res, const float* __restrict__ gate,
+                                                          T* __restrict__ y, pasn_conv_desc d) {
+    using frag = typename Traits<T>::frag;
+    constexpr int CH = Traits<T>::CH;
+    constexpr int KSTEP = Traits<T>::KSTEP;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const long M = (long)d.N * d.To * d.Ho * d.Wo;
+    const long mbase = ((long)blockIdx.x * 4 + wave) * (32 * MT);
+    if (mbase >= M) return;  // wave-uniform
+    const int co_base = blockIdx.y * (32 * NT);
+    const int taps = d.kt * d.kh * d.kw;
+    const int ksteps = d.w_kc / KSTEP;
+    const long wrow_stride = (long)taps * d.w_kc;
+
+    long m[MT];
+    int pn[MT], pt[MT], ph[MT], pw[MT];
+    bool mv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        m[mt] = mbase + mt * 32 + c;
+        mv[mt] = m[mt] < M;
+        const long mm = mv[mt] ? m[mt] : 0;
+        pw[mt] = (int)(mm % d.Wo);
+        long r = mm / d.Wo;
+        ph[mt] = (int)(r % d.Ho);
+        r /= d.Ho;
+        pt[mt] = (int)(r % d.To);
+        pn[mt] = (int)(r / d.To);
+    }
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.0f;
+
+    const T* wp[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wp[nt] = w + (long)(co_base + nt * 32 + c) * wrow_stride + h * CH;
+
+    const bool xform = (gate != nullptr) || (d.in_swish != 0);
+    int tap = 0;
+    for (int a = 0; a < d.kt; ++a) {
+        for (int b = 0; b < d.kh; ++b) {
+            for (int e = 0; e < d.kw; ++e, ++tap) {
+                const T* xp[MT];
+                const float* gp[MT];
+                bool v[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int ti = pt[mt] * d.st - d.pt + a;
+                    const int hi = ph[mt] * d.sh - d.ph + b;
+                    const int wi = pw[mt] * d.sw - d.pw + e;
+                    v[mt] = mv[mt] && ti >= 0 && ti < d.Ti && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
+                    const long off = (((long)pn[mt] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi;
+                    xp[mt] = x + (v[mt] ? off : 0) * d.Cin_p + h * CH;
+                    gp[mt] = gate ? gate + (long)pn[mt] * d.Cin_p + h * CH : nullptr;
+                }
+                const long wtap = (long)tap * d.w_kc;
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const int k0 = ks * KSTEP;
+                    const bool cv = (k0 + h * CH) < d.Cin_p;  // second lane half may hang over the channel pad
+                    frag bf[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (v[mt] && cv) {
+                            bf[mt] = load_frag<T>(xp[mt] + k0);
+                            if (xform) bf[mt] = gate_swish<T>(bf[mt], gp[mt] ? gp[mt] + k0 : nullptr, d.in_swish != 0);
+                        } else {
+                            bf[mt] = zero_frag<T>();
+                        }
+                    }
+                    frag af[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) af[nt] = load_frag<T>(wp[nt] + wtap + k0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], af[nt], bf[mt]);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (!mv[mt]) continue;
+        T* yp = y + m[mt] * d.Cout_p;
+        const T* rp = res ? res + m[mt] * d.Cout_p : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co_base + nt * 32 + 8 * g + 4 * h;
+                if (co >= d.Cout_p) continue;
+                float o[4];
+                float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (rp) load4(rp + co, rv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float s = acc[nt][mt][4 * g + j] * (scale ? scale[co + j] : 1.0f) + (bias ? bias[co + j] : 0.0f) + rv[j];
+                    o[j] = (co + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
+                }
+                store4(yp + co, o);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_conv3d(const void* x, const void* w, const float* scale, const float* bias, const void* res,
+                         const float* gate, void* y, const pasn_conv_desc& d, hipStream_t s) {
+    const long M = (long)d.N * d.To * d.Ho * d.Wo;
+    const int tiles = ceil_div(d.Cout_p, 32);
+    // NT: output-channel tiles per wave (weights are padded to 128 rows so any NT <= 4 stays in bounds)
+    int NT = tiles >= 4 ? 4 : tiles;
+    if (tiles > 4 && tiles % 4 != 0 && tiles % 3 == 0) NT = 3;
+    // big position counts: reuse each weight fragment twice -- but only while the accumulators leave room for
+    // >= 3 waves per SIMD (NT*MT*16 accumulator registers; NT=4,MT=2 drops to one wave and cannot hide HBM latency)
+    const int MT = (M >= 256L * 1024 && NT <= 2) ? 2 : 1;
+    const dim3 grid(ceil_div(M, 4 * 32 * MT), ceil_div(tiles, NT)), block(256);
+    PASN_REQUIRE((long)grid.y * NT * 32 <= d.w_rows, "packed weight has too few rows for the chosen tiling");
+#define PASN_CV(NT_, MT_)                                                                                     \
+    hipLaunchKernelGGL((conv3d_mfma_kernel<T, NT_, MT_>), grid, block, 0, s, (const T*)x, (const T*)w, scale, \
+                       bias, (const T*)res, gate, (T*)y, d)
+    if (MT == 2) {
+        if (NT == 1) PASN_CV(1, 2); else PASN_CV(2, 2);
+    } else {
+        switch (NT) {
+            case 1: PASN_CV(1, 1); break;
+            case 2: PASN_CV(2, 1); break;
+            case 3: PASN_CV(3, 1); break;
+            default: PASN_CV(4, 1); break;
+        }
+    }
+#undef PASN_CV
+    return check_launch("conv3d_mfma_kernel");
+}
+
+// =================================================================================================
+// depthwise stencil, channels-last.  Thread (cx, py): channel group cx (8 channels = one 16/32-byte
+// chunk), position slot py; a block walks DW_POS consecutive positions of ONE clip.  Optional fused
+// squeeze-excite partial sums (per block, fixed order => deterministic).
+// =================================================================================================
+constexpr int DW_POS = 128;  // positions per block
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3d_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ scale, const float* __restrict__ bias,
+                                                       T* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [taps][Cp] weights, then [PY][Cp] pool scratch
+    const int taps = d.kt * d.kh * d.kw;
+    const int Cp = d.Cout_p;
+    float* wl = lds;
+    float* red = lds + taps * Cp;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int nthreads = blockDim.x * blockDim.y;
+    for (int i = tid; i < taps * Cp; i += nthreads) wl[i] = w[i];
+    __syncthreads();
+
+    const int cg = threadIdx.x;
+    const bool cvalid = cg * 8 < Cp;
+    const int n = blockIdx.y;
+    const int S = d.To * d.Ho * d.Wo;
+    const int p0 = blockIdx.x * DW_POS;
+    float sc[8], bs[8], psum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = cvalid ? scale[cg * 8 + j] : 0.0f;
+        bs[j] = cvalid ? bias[cg * 8 + j] : 0.0f;
+        psum[j] = 0.0f;
+    }
+    if (cvalid) {
+        for (int p = p0 + threadIdx.y; p < p0 + DW_POS && p < S; p += blockDim.y) {
+            const int wo = p % d.Wo;
+            int r = p / d.Wo;
+            const int ho = r % d.Ho;
+            const int to = r / d.Ho;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+            int tap = 0;
+            for (int a = 0; a < d.kt; ++a) {
+                const int ti = to * d.st - d.pt + a;
+                for (int b = 0; b < d.kh; ++b) {
+                    const int hi = ho * d.sh - d.ph + b;
+                    for (int e = 0; e < d.kw; ++e, ++tap) {
+                        const int wi = wo * d.sw - d.pw + e;
+                        if (ti < 0 || ti >= d.Ti || hi < 0 || hi >= d.Hi || wi < 0 || wi >= d.Wi) continue;
+                        const long off = ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.Cin_p + cg * 8;
+                        float xv[8], wv[8];
+                        load8(x + off, xv);
+                        load8(wl + tap * Cp + cg * 8, wv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+                    }
+                }
+            }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float s = acc[j] * sc[j] + bs[j];
+                psum[j] += s;
+                o[j] = (cg * 8 + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
+            }
+            store8(y + ((long)n * S + p) * Cp + cg * 8, o);
+        }
+    }
+    if (pool) {  // block-uniform
+        if (cvalid) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[threadIdx.y * Cp + cg * 8 + j] = psum[j];
+        }
+        __syncthreads();
+        for (int ch = tid; ch < Cp; ch += nthreads) {
+            float s = 0.0f;
+            for (int q = 0; q < (int)blockDim.y; ++q) s += red[q * Cp + ch];
+            pool[((long)n * gridDim.x + blockIdx.x) * Cp + ch] = s;
+        }
+    }
+}
+
+static void dw_block_shape(int Cp, int& bx, int& by) {
+    const int cgs = Cp / 8;
+    bx = 1;
+    while (bx < cgs) bx <<= 1;
+    if (bx > 256) bx = 256;
+    by = 256 / bx;
+}
+
+template <typename T>
+static int launch_dwconv3d(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
+                           const pasn_conv_desc& d, hipStream_t s) {
+    int bx, by;
+    dw_block_shape(d.Cout_p, bx, by);
+    PASN_REQUIRE(d.Cout_p / 8 <= 256, "depthwise conv supports at most 2048 channels");
+    const int S = d.To * d.Ho * d.Wo;
+    const dim3 grid(ceil_div(S, DW_POS), d.N), block(bx, by);
+    const int taps = d.kt * d.kh * d.kw;
+    const size_t lds = (size_t)(taps + by) * d.Cout_p * sizeof(float);
+    PASN_REQUIRE(lds <= 64 * 1024, "depthwise conv window x channels too large for the LDS weight tile");
+    hipLaunchKernelGGL((dwconv3d_kernel<T>), grid, block, lds, s, (const T*)x, w, scale, bias, (T*)y, pool, d);
+    return check_launch("dwconv3d_kernel");
+}
+
+// =================================================================================================
+// squeeze-excite gate: one block per clip.
+// =================================================================================================
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool, int pool_blocks, float inv_positions,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ gate, int C, int Cp, int Cse) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [Cp] mean, [Cse] hidden
+    float* mean = sm;
+    float* hid = sm + Cp;
+    const int n = blockIdx.x;
+    for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+        float s = 0.0f;
+        const float* pp = pool + (long)n * pool_blocks * Cp + ch;
+        for (int q = 0; q < pool_blocks; ++q) s += pp[(long)q * Cp];
+        mean[ch] = s * inv_positions;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Cse; j += blockDim.x) {
+        float s = b1[j];
+        for (int ch = 0; ch < C; ++ch) s = fmaf(w1[(long)j * C + ch], mean[ch], s);
+        hid[j] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+        float g = 0.0f;
+        if (ch < C) {
+            float s = b2[ch];
+            for (int j = 0; j < Cse; ++j) s = fmaf(w2[(long)ch * Cse + j], hid[j], s);
+            g = sigmoidf_(s);
+        }
+        gate[(long)n * Cp + ch] = g;
+    }
+}
+
+// =================================================================================================
+// max pooling, channels-last, 8-channel groups.
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3d_kernel(const T* __restrict__ x, T* __restrict__ y, pasn_conv_desc d) {
+    const int cgs = d.Cout_p / 8;
+    const long total = (long)d.N * d.To * d.Ho * d.Wo * cgs;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % cgs);
+    long m = idx / cgs;
+    const int wo = (int)(m % d.Wo);
+    long r = m / d.Wo;
+    const int ho = (int)(r % d.Ho);
+    r /= d.Ho;
+    const int to = (int)(r % d.To);
+    const int n = (int)(r / d.To);
+    float best[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = -INFINITY;
+    for (int a = 0; a < d.kt; ++a) {
+        const int ti = to * d.st - d.pt + a;
+        if (ti < 0 || ti >= d.Ti) continue;
+        for (int b = 0; b < d.kh; ++b) {
+            const int hi = ho * d.sh - d.ph + b;
+            if (hi < 0 || hi >= d.Hi) continue;
+            for (int e = 0; e < d.kw; ++e) {
+                const int wi = wo * d.sw - d.pw + e;
+                if (wi < 0 || wi >= d.Wi) continue;
+                float v[8];
+                load8(x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.Cin_p + cg * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], v[j]);
+            }
+        }
+    }
+    store8(y + m * d.Cout_p + cg * 8, best);
+}
+
+}  // namespace pasn
+
+using namespace pasn;
+
+static bool conv_desc_ok(const pasn_conv_desc* d) {
+    return d && d->N > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0 && d->To > 0 && d->Ho > 0 && d->Wo > 0 && d->Cin > 0 &&
+           d->Cout > 0 && d->Cin_p >= d->Cin && d->Cout_p >= d->Cout && d->Cin_p % 8 == 0 && d->Cout_p % 8 == 0 && d->kt > 0 &&
+           d->kh > 0 && d->kw > 0 && d->st > 0 && d->sh > 0 && d->sw > 0;
+}
+
+extern "C" int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                                   const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream) {
+    PASN_REQUIRE(x && w && scale && bias && y && d, "null pointer");
+    PASN_REQUIRE(d->N > 0 && d->Cin == 3 && d->kt == 1 && d->st == 1 && d->pt == 0 && d->To == d->Ti, "first conv is (1,kh,kw) over 3 planar channels");
+    PASN_REQUIRE(d->Cout_p % 8 == 0 && d->Cout_p >= d->Cout, "Cout_p must be a multiple of 8");
+    PASN_REQUIRE((size_t)3 * d->kh * d->kw * d->Cout_p * 4 <= 64 * 1024, "first conv weights exceed the LDS tile");
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == PASN_F32 && out_dtype == PASN_F32) return launch_first_conv<float, float>(x, w, scale, bias, y, *d, s);
+    if (in_dtype == PASN_F32 && out_dtype == PASN_BF16) return launch_first_conv<float, __bf16>(x, w, scale, bias, y, *d, s);
+    if (in_dtype == PASN_BF16 && out_dtype == PASN_BF16) return launch_first_conv<__bf16, __bf16>(x, w, scale, bias, y, *d, s);
+    if (in_dtype == PASN_BF16 && out_dtype == PASN_F32) return launch_first_conv<__bf16, float>(x, w, scale, bias, y, *d, s);
+    set_error("pasn_first_conv_fwd: unknown dtype");
+    return PASN_ERR_ARG;
+}
+
+extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
+                               const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && w && y, "null pointer");  // scale may be NULL (= 1), bias may be NULL (= 0)
+    PASN_REQUIRE(conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
+    const int kstep = dtype == PASN_BF16 ? 16 : 8;
+    PASN_REQUIRE(d->w_kc >= d->Cin_p && d->w_kc % kstep == 0, "w_kc must cover Cin_p and be a multiple of the MFMA k-step");
+    PASN_REQUIRE(d->w_rows % 128 == 0 && d->w_rows >= d->Cout_p, "w_rows must be a multiple of 128 covering Cout_p");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_F32) return launch_conv3d<float>(x, w, scale, bias, residual, gate, y, *d, s);
+    if (dtype == PASN_BF16) return launch_conv3d<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
+    set_error("pasn_conv3d_fwd: unknown dtype");
+    return PASN_ERR_ARG;
+}
+
+extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d) {
+    if (!d) return 0;
+    return ceil_div((long)d->To * d->Ho * d->Wo, DW_POS);
+}
+
+extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                                 float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && w && scale && bias && y, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
+    PASN_REQUIRE(d->Cin == d->Cout && d->Cin_p == d->Cout_p, "depthwise conv keeps the channel count");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_F32) return launch_dwconv3d<float>(x, w, scale, bias, y, pool_partial, *d, s);
+    if (dtype == PASN_BF16) return launch_dwconv3d<__bf16>(x, w, scale, bias, y, pool_partial, *d, s);
+    set_error("pasn_dwconv3d_fwd: unknown dtype");
+    return PASN_ERR_ARG;
+}
+
+extern "C" int pasn_se_gate_fwd(const float* pool_partial, int pool_blocks, int positions, const float* w1, const float* b1,
+                                const float* w2, const float* b2, float* gate, int N, int C, int Cp, int Cse, void* stream) {
+    PASN_REQUIRE(pool_partial && w1 && b1 && w2 && b2 && gate, "null pointer");
+    PASN_REQUIRE(N > 0 && C > 0 && Cp >= C && Cse > 0 && pool_blocks > 0 && positions > 0, "bad sizes");
+    const size_t lds = (size_t)(Cp + Cse) * sizeof(float);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, pool_partial, pool_blocks,
+                       1.0f / (float)positions, w1, b1, w2, b2, gate, C, Cp, Cse);
+    return check_launch("se_gate_kernel");
+}
+
+extern "C" int pasn_maxpool3d_fwd(const void* x, void* y, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && y, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(d) && d->Cin_p == d->Cout_p, "bad geometry");
+    const long total = (long)d->N * d->To * d->Ho * d->Wo * (d->Cout_p / 8);
+    const dim3 grid(ceil_div(total, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_F32)
+        hipLaunchKernelGGL((maxpool3d_kernel<float>), grid, block, 0, s, (const float*)x, (float*)y, *d);
+    else if (dtype == PASN_BF16)
+        hipLaunchKernelGGL((maxpool3d_kernel<__bf16>), grid, block, 0, s, (const __bf16*)x, (__bf16*)y, *d);
+    else {
+        set_error("pasn_maxpool3d_fwd: unknown dtype");
+        return PASN_ERR_ARG;
+    }
+    return check_launch("maxpool3d_kernel");
+}

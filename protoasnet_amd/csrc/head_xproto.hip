@@ -1,0 +1,236 @@
+// Head B (XProtoNet / Video_XProtoNet, "ProtoASNet"): add-on + occurrence module + occurrence-weighted
+// pooling + cosine similarity + last layer.
+//
+// Round-1 structure ("Head B"): the five 1x1(x1) convs run on the MFMA implicit-GEMM kernel
+// (conv.hip) over channels-last [N*S][C] rows; the pooling  F[n][p][d] = sum_s occ[n][s][p] * f[n][s][d]
+// (the reference materialises the (N,P,D,S) product, Video_XProtoNet.py:87) is a split-S reduction into
+// fixed-order slabs so results are bitwise reproducible; a finishing kernel sums the slabs and does
+// cosine / (s+1)/2 / last layer.  Nothing of size N*P*D*S is ever formed.
+#include "common.h"
+
+namespace pasn {
+
+constexpr int POOL_ST = 32;  // positions staged per step
+
+// grid (dchunks*pchunks, G, N), 256 threads: thread = one feature column d, PC prototype accumulators.
+template <typename T, int PC>
+__global__ __launch_bounds__(256) void xproto_pool_kernel(const T* __restrict__ occ_cl, const T* __restrict__ f,
+                                                          float* __restrict__ occ_planar, float* __restrict__ ws, int S,
+                                                          int P, int Pp, int D, int Dp, int G, int dchunks, int do_pool) {
+    __shared__ __attribute__((aligned(16))) float tile[POOL_ST * PC];
+    const int dchunk = blockIdx.x % dchunks, pchunk = blockIdx.x / dchunks;
+    const int g = blockIdx.y, n = blockIdx.z;
+    const int SG = (S + G - 1) / G;
+    const int sbeg = g * SG;
+    const int send = min(S, sbeg + SG);
+    const int d = dchunk * 256 + threadIdx.x;
+    const bool dvalid = do_pool && d < D;
+    const int pbase = pchunk * PC;
+    float acc[PC];
+#pragma unroll
+    for (int i = 0; i < PC; ++i) acc[i] = 0.0f;
+
+    for (int s0 = sbeg; s0 < send; s0 += POOL_ST) {
+        for (int i = threadIdx.x; i < POOL_ST * PC; i += 256) {
+            const int sl = i / PC, pl = i % PC;
+            const int s = s0 + sl, p = pbase + pl;
+            tile[i] = (s < send && p < P) ? (float)occ_cl[((long)n * S + s) * Pp + p] : 0.0f;
+        }
+        __syncthreads();
+        if (occ_planar && dchunk == 0) {
+            for (int i = threadIdx.x; i < POOL_ST * PC; i += 256) {
+                const int pl = i / POOL_ST, sl = i % POOL_ST;
+                const int s = s0 + sl, p = pbase + pl;
+                if (s < send && p < P) occ_planar[((long)n * P + p) * S + s] = tile[sl * PC + pl];
+            }
+        }
+        if (dvalid) {
+            const int cnt = min(POOL_ST, send - s0);
+            for (int sl = 0; sl < cnt; ++sl) {
+                const float fv = (float)f[((long)n * S + s0 + sl) * Dp + d];
+#pragma unroll
+                for (int i = 0; i < PC; i += 4) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(tile + sl * PC + i);
+                    acc[i + 0] = fmaf(o[0], fv, acc[i + 0]);
+                    acc[i + 1] = fmaf(o[1], fv, acc[i + 1]);
+                    acc[i + 2] = fmaf(o[2], fv, acc[i + 2]);
+                    acc[i + 3] = fmaf(o[3], fv, acc[i + 3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (dvalid) {
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int p = pbase + i;
+            if (p < P) ws[(((long)n * G + g) * P + p) * D + d] = acc[i];
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// grid N, 256 threads; a wave per prototype.
+__global__ __launch_bounds__(256) void xproto_finish_kernel(const float* __restrict__ ws, const float* __restrict__ protos,
+                                                            const float* __restrict__ fc_w, float* __restrict__ feat,
+                                                            float* __restrict__ sim, float* __restrict__ logits, int G, int P,
+                                                            int D, int K) {
+    extern __shared__ __attribute__((aligned(16))) float sims[];  // [P]
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = wave; p < P; p += 4) {
+        float* fp = feat + ((long)n * P + p) * D;
+        const float* pp = protos + (long)p * D;
+        float ssf = 0.0f, ssp = 0.0f;
+        for (int d = lane; d < D; d += 64) {
+            float v = 0.0f;
+            for (int g = 0; g < G; ++g) v += ws[(((long)n * G + g) * P + p) * D + d];
+            fp[d] = v;
+            ssf = fmaf(v, v, ssf);
+            const float q = pp[d];
+            ssp = fmaf(q, q, ssp);
+        }
+        ssf = wave_sum(ssf);
+        ssp = wave_sum(ssp);
+        const float nf = fmaxf(sqrtf(ssf), 1e-8f), np = fmaxf(sqrtf(ssp), 1e-8f);
+        float dot = 0.0f;
+        for (int d = lane; d < D; d += 64) dot = fmaf(fp[d] / nf, pp[d] / np, dot);
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            const float sv = (dot + 1.0f) / 2.0f;
+            sims[p] = sv;
+            sim[(long)n * P + p] = sv;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.0f;
+        for (int p = 0; p < P; ++p) s = fmaf(sims[p], fc_w[(long)k * P + p], s);
+        logits[(long)n * K + k] = s;
+    }
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct XpLayout {
+    size_t f1, f, o2, occ, slabs, total;
+};
+static XpLayout xp_layout(const pasn_xproto_desc& d, int dtype, int G) {
+    const size_t es = dtype == PASN_BF16 ? 2 : 4;
+    const size_t rows = (size_t)d.N * d.S;
+    XpLayout L;
+    size_t off = 0;
+    L.f1 = off;
+    off += align256(rows * d.Dp * es);
+    L.f = off;
+    off += align256(rows * d.Dp * es);
+    L.o2 = off;
+    off += align256(rows * d.Hp * es);
+    L.occ = off;
+    off += align256(rows * d.Pp * es);
+    L.slabs = off;
+    off += align256((size_t)d.N * G * d.P * d.D * sizeof(float));
+    L.total = off;
+    return L;
+}
+
+static pasn_conv_desc pointwise_desc(const pasn_xproto_desc& d, int cin, int cin_p, int cout, int cout_p, int act, int dtype) {
+    const int kstep = dtype == PASN_BF16 ? 16 : 8;
+    pasn_conv_desc c = {};
+    c.N = d.N; c.Ti = 1; c.Hi = 1; c.Wi = d.S;
+    c.Cin = cin; c.Cin_p = cin_p;
+    c.To = 1; c.Ho = 1; c.Wo = d.S;
+    c.Cout = cout; c.Cout_p = cout_p;
+    c.kt = c.kh = c.kw = 1;
+    c.st = c.sh = c.sw = 1;
+    c.act = act;
+    c.w_kc = (cin_p + kstep - 1) / kstep * kstep;
+    c.w_rows = (cout_p + 127) / 128 * 128;
+    return c;
+}
+
+}  // namespace pasn
+
+using namespace pasn;
+
+static bool xp_desc_ok(const pasn_xproto_desc* d) {
+    return d && d->N > 0 && d->S > 0 && d->Cb > 0 && d->D > 0 && d->Hd > 0 && d->P > 0 && d->K > 0 && d->Cbp >= d->Cb &&
+           d->Dp >= d->D && d->Hp >= d->Hd && d->Pp >= d->P && d->Cbp % 8 == 0 && d->Dp % 8 == 0 && d->Hp % 8 == 0 &&
+           d->Pp % 8 == 0;
+}
+
+extern "C" int pasn_xproto_head_splits(const pasn_xproto_desc* d) {
+    if (!xp_desc_ok(d)) return 0;
+    const int pc = d->P <= 32 ? 32 : 64;
+    const long base = (long)d->N * ceil_div(d->D, 256) * ceil_div(d->P, pc);
+    long G = (1024 + base - 1) / base;  // aim at >= 1024 blocks (4 per CU)
+    const long gmax = ceil_div(d->S, POOL_ST);
+    if (G > gmax) G = gmax;
+    if (G < 1) G = 1;
+    return (int)G;
+}
+
+extern "C" size_t pasn_xproto_head_workspace_bytes(const pasn_xproto_desc* d, int dtype) {
+    if (!xp_desc_ok(d)) return 0;
+    return xp_layout(*d, dtype, pasn_xproto_head_splits(d)).total;
+}
+
+extern "C" int pasn_xproto_head_fwd(const void* x, const void* a1, const float* a1b, const void* a2, const float* a2b,
+                                    const void* o1, const float* o1b, const void* o2, const float* o2b, const void* o3,
+                                    const float* protos, const float* fc_w, float* occ, float* feat, float* sim,
+                                    float* logits, void* ws, const pasn_xproto_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(xp_desc_ok(d), "bad descriptor (channel strides must be multiples of 8)");
+    PASN_REQUIRE(dtype == PASN_F32 || dtype == PASN_BF16, "unknown dtype");
+    PASN_REQUIRE(x && o1 && o1b && o2 && o2b && o3 && occ && ws, "null pointer");
+    PASN_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+    const bool full = d->mode == 0;
+    if (full) PASN_REQUIRE(a1 && a1b && a2 && a2b && protos && fc_w && feat && sim && logits, "null pointer (full mode)");
+    const int G = pasn_xproto_head_splits(d);
+    const XpLayout L = xp_layout(*d, dtype, G);
+    char* base = (char*)ws;
+    void* b_f1 = base + L.f1;
+    void* b_f = base + L.f;
+    void* b_o2 = base + L.o2;
+    void* b_occ = base + L.occ;
+    float* b_slabs = (float*)(base + L.slabs);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (full) {
+        pasn_conv_desc c1 = pointwise_desc(*d, d->Cb, d->Cbp, d->D, d->Dp, PASN_ACT_RELU, dtype);
+        if ((rc = pasn_conv3d_fwd(x, a1, nullptr, a1b, nullptr, nullptr, b_f1, &c1, dtype, stream))) return rc;
+        pasn_conv_desc c2 = pointwise_desc(*d, d->D, d->Dp, d->D, d->Dp, PASN_ACT_NONE, dtype);
+        if ((rc = pasn_conv3d_fwd(b_f1, a2, nullptr, a2b, nullptr, nullptr, b_f, &c2, dtype, stream))) return rc;
+    }
+    pasn_conv_desc c3 = pointwise_desc(*d, d->Cb, d->Cbp, d->D, d->Dp, PASN_ACT_RELU, dtype);
+    if ((rc = pasn_conv3d_fwd(x, o1, nullptr, o1b, nullptr, nullptr, b_f1, &c3, dtype, stream))) return rc;
+    pasn_conv_desc c4 = pointwise_desc(*d, d->D, d->Dp, d->Hd, d->Hp, PASN_ACT_RELU, dtype);
+    if ((rc = pasn_conv3d_fwd(b_f1, o2, nullptr, o2b, nullptr, nullptr, b_o2, &c4, dtype, stream))) return rc;
+    pasn_conv_desc c5 = pointwise_desc(*d, d->Hd, d->Hp, d->P, d->Pp, PASN_ACT_ABS, dtype);  // occurrence_module.4 has no bias
+    if ((rc = pasn_conv3d_fwd(b_o2, o3, nullptr, nullptr, nullptr, nullptr, b_occ, &c5, dtype, stream))) return rc;
+
+    const int pc = d->P <= 32 ? 32 : 64;
+    const int dchunks = full ? ceil_div(d->D, 256) : 1;
+    const int pchunks = ceil_div(d->P, pc);
+    const dim3 grid(dchunks * pchunks, G, d->N), block(256);
+#define PASN_POOL(T, PC)                                                                                              \
+    hipLaunchKernelGGL((xproto_pool_kernel<T, PC>), grid, block, 0, s, (const T*)b_occ, (const T*)b_f, occ, b_slabs, \
+                       d->S, d->P, d->Pp, d->D, d->Dp, G, dchunks, full ? 1 : 0)
+    if (dtype == PASN_F32) {
+        if (pc == 32) PASN_POOL(float, 32); else PASN_POOL(float, 64);
+    } else {
+        if (pc == 32) PASN_POOL(__bf16, 32); else PASN_POOL(__bf16, 64);
+    }
+#undef PASN_POOL
+    if ((rc = check_launch("xproto_pool_kernel"))) return rc;
+    if (full) {
+        hipLaunchKernelGGL(xproto_finish_kernel, dim3(d->N), dim3(256), (size_t)d->P * sizeof(float), s, b_slabs, protos,
+                           fc_w, feat, sim, logits, G, d->P, d->D, d->K);
+        if ((rc = check_launch("xproto_finish_kernel"))) return rc;
+    }
+    return PASN_OK;
+}

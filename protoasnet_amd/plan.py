@@ -1,0 +1,365 @@
+"""Trunk compiler: turns a parameter-holding module tree into a replayable list of fused HIP launches.
+
+``HipTrunk.forward`` (eval mode) = ``Plan.run``: the first call for a given (input shape, dtype) walks
+``build_plan`` once, which
+
+* folds every eval-mode norm layer into a per-channel fp32 (scale, bias) epilogue,
+* packs conv weights into the MFMA fragment-friendly layout of ``pasn_conv3d_fwd``,
+* assigns every intermediate activation an offset inside ONE arena by live-range analysis
+  (a buffer's bytes are reused as soon as its last consumer has been recorded), so the working set
+  of a trunk stays a few of its largest layers instead of the sum of all of them,
+* records one closure per launch with all pointers resolved.
+
+Replaying is then a tight loop of ctypes calls on torch's current stream -- no allocation (bar the
+output tensor), no host sync, capturable into a hipGraph.  Packed weights are refreshed automatically
+when a parameter changes (``load_state_dict``, optimizer step, ``.to()``).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ConvDesc
+
+ALIGN = 256
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _triple(v, lead) -> Tuple[int, int, int]:
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(a) for a in v)
+    return v if len(v) == 3 else (lead,) + v
+
+
+class Act:
+    """Symbolic channels-last activation [N][T][H][W][Cp] (or the planar network input)."""
+
+    __slots__ = ("N", "T", "H", "W", "C", "Cp", "buf", "planar")
+
+    def __init__(self, N, T, H, W, C, Cp, buf, planar=False):
+        self.N, self.T, self.H, self.W, self.C, self.Cp, self.buf, self.planar = N, T, H, W, C, Cp, buf, planar
+
+    @property
+    def positions(self) -> int:
+        return self.T * self.H * self.W
+
+
+class _Buf:
+    __slots__ = ("nbytes", "first", "last", "offset", "external")
+
+    def __init__(self, nbytes, first, external=False):
+        self.nbytes, self.first, self.last, self.offset, self.external = nbytes, first, first, -1, external
+
+
+def fold_norm(norm: Optional[nn.Module], conv_bias: Optional[torch.Tensor], cout: int, rows: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode BatchNorm (and/or a conv bias) as fp32 per-channel (scale, bias), zero padded to ``rows``."""
+    scale = torch.ones(cout, dtype=torch.float32, device=device)
+    bias = torch.zeros(cout, dtype=torch.float32, device=device)
+    if conv_bias is not None:
+        bias = conv_bias.detach().float().clone()
+    if norm is not None:
+        inv = (norm.running_var.detach().float() + norm.eps).rsqrt()
+        g = norm.weight.detach().float() if norm.weight is not None else torch.ones_like(inv)
+        b = norm.bias.detach().float() if norm.bias is not None else torch.zeros_like(inv)
+        scale = g * inv
+        bias = b + (bias - norm.running_mean.detach().float()) * scale
+    s = torch.zeros(rows, dtype=torch.float32, device=device)
+    o = torch.zeros(rows, dtype=torch.float32, device=device)
+    s[:cout] = scale
+    o[:cout] = bias
+    return s.contiguous(), o.contiguous()
+
+
+def pack_conv_weight(w: torch.Tensor, cin_p: int, dtype: torch.dtype) -> Tuple[torch.Tensor, int, int]:
+    """(Cout, Cin, [kt,] kh, kw) -> [rows][taps][kc] in ``dtype``; returns (packed, kc, rows)."""
+    w = w.detach()
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3] * w.shape[4]
+    kstep = 16 if dtype == torch.bfloat16 else 8
+    kc = round_up(cin_p, kstep)
+    rows = round_up(round_up(cout, 8), 128)
+    packed = torch.zeros(rows, taps, kc, dtype=torch.float32, device=w.device)
+    packed[:cout, :, :cin] = w.float().permute(0, 2, 3, 4, 1).reshape(cout, taps, cin)
+    return packed.to(dtype).contiguous(), kc, rows
+
+
+class PlanBuilder:
+    def __init__(self, device: torch.device, dtype: torch.dtype, in_dtype: torch.dtype):
+        self.device, self.dtype, self.in_dtype = device, dtype, in_dtype
+        self.es = 2 if dtype == torch.bfloat16 else 4
+        self.code = _lib.dtype_code(dtype)
+        self.bufs: List[_Buf] = []
+        self.ops: List[Callable[[List[int], int], None]] = []
+        self.keep: List[object] = []  # packed weights / descriptors kept alive with the plan
+        self.lib = _lib.lib()
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def _new_buf(self, nbytes: int, external: bool = False) -> int:
+        self.bufs.append(_Buf(round_up(max(nbytes, 1), ALIGN), len(self.ops), external))
+        return len(self.bufs) - 1
+
+    def _use(self, *buf_ids) -> None:
+        for b in buf_ids:
+            if b is not None:
+                self.bufs[b].last = len(self.ops)
+
+    def input(self, shape) -> Act:
+        if len(shape) == 4:
+            n, c, h, w = shape
+            t = 1
+        else:
+            n, c, t, h, w = shape
+        in_es = 2 if self.in_dtype == torch.bfloat16 else 4
+        return Act(n, t, h, w, c, c, self._new_buf(n * c * t * h * w * in_es, external=True), planar=True)
+
+    def _out_act(self, x: Act, cout: int, k, s, p) -> Act:
+        to = (x.T + 2 * p[0] - k[0]) // s[0] + 1
+        ho = (x.H + 2 * p[1] - k[1]) // s[1] + 1
+        wo = (x.W + 2 * p[2] - k[2]) // s[2] + 1
+        cp = round_up(cout, 8)
+        return Act(x.N, to, ho, wo, cout, cp, self._new_buf(x.N * to * ho * wo * cp * self.es))
+
+    def _desc(self, x: Act, y: Act, k, s, p, act: str, in_swish=False, w_kc=0, w_rows=0) -> ConvDesc:
+        d = ConvDesc(
+            N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=x.C, Cin_p=x.Cp, To=y.T, Ho=y.H, Wo=y.W, Cout=y.C, Cout_p=y.Cp,
+            kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
+            act=_lib.ACT[act], in_swish=int(bool(in_swish)), w_kc=w_kc, w_rows=w_rows,
+        )
+        self.keep.append(d)
+        return d
+
+    # ---- ops -------------------------------------------------------------------------------------
+    def first_conv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str) -> Act:
+        assert x.planar and x.C == 3, "the first conv reads the planar 3-channel clip"
+        k, s, p = _triple(conv.kernel_size, 1), _triple(conv.stride, 1), _triple(conv.padding, 0)
+        assert k[0] == 1 and s[0] == 1 and p[0] == 0, "first conv must be (1, kh, kw)"
+        y = self._out_act(x, conv.out_channels, k, s, p)
+        w = conv.weight.detach().float()
+        if w.dim() == 5:
+            w = w[:, :, 0]
+        wp = torch.zeros(3 * k[1] * k[2], y.Cp, dtype=torch.float32, device=self.device)
+        wp[:, : y.C] = w.permute(1, 2, 3, 0).reshape(3 * k[1] * k[2], y.C)
+        scale, bias = fold_norm(norm, conv.bias, y.C, y.Cp, self.device)
+        d = self._desc(x, y, k, s, p, act)
+        self.keep += [wp, scale, bias]
+        fn, code_in, code_out = self.lib.pasn_first_conv_fwd, _lib.dtype_code(self.in_dtype), self.code
+        a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
+        xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
+        self._use(xb, yb)
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, code_out, st)))
+        return y
+
+    def conv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, residual: Optional[Act] = None,
+             in_gate: Optional[int] = None, in_swish: bool = False) -> Act:
+        assert not x.planar and conv.groups == 1
+        k, s, p = _triple(conv.kernel_size, 1), _triple(conv.stride, 1), _triple(conv.padding, 0)
+        y = self._out_act(x, conv.out_channels, k, s, p)
+        wp, kc, rows = pack_conv_weight(conv.weight, x.Cp, self.dtype)
+        scale, bias = fold_norm(norm, conv.bias, y.C, rows, self.device)
+        d = self._desc(x, y, k, s, p, act, in_swish, kc, rows)
+        self.keep += [wp, scale, bias]
+        if residual is not None:
+            assert (residual.N, residual.T, residual.H, residual.W, residual.Cp) == (y.N, y.T, y.H, y.W, y.Cp)
+        fn, code = self.lib.pasn_conv3d_fwd, self.code
+        a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
+        xb, yb, rb, gb, dref = x.buf, y.buf, (residual.buf if residual is not None else None), in_gate, ctypes.byref(d)
+        self._use(xb, yb, rb, gb)
+        self.ops.append(
+            lambda ptrs, st: _lib.check(
+                fn(ptrs[xb], a[0], a[1], a[2], ptrs[rb] if rb is not None else 0, ptrs[gb] if gb is not None else 0,
+                   ptrs[yb], dref, code, st)
+            )
+        )
+        return y
+
+    def dwconv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, pool: bool = False):
+        assert not x.planar and conv.groups == conv.in_channels == conv.out_channels == x.C
+        k, s, p = _triple(conv.kernel_size, 1), _triple(conv.stride, 1), _triple(conv.padding, 0)
+        y = self._out_act(x, x.C, k, s, p)
+        taps = k[0] * k[1] * k[2]
+        wp = torch.zeros(taps, y.Cp, dtype=torch.float32, device=self.device)
+        wp[:, : y.C] = conv.weight.detach().float().reshape(y.C, taps).t()
+        scale, bias = fold_norm(norm, conv.bias, y.C, y.Cp, self.device)
+        d = self._desc(x, y, k, s, p, act)
+        self.keep += [wp, scale, bias]
+        pool_buf, pool_blocks = None, 0
+        if pool:
+            pool_blocks = int(self.lib.pasn_dwconv3d_pool_blocks(ctypes.byref(d)))
+            pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4)
+        fn, code = self.lib.pasn_dwconv3d_fwd, self.code
+        a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
+        xb, yb, pb, dref = x.buf, y.buf, pool_buf, ctypes.byref(d)
+        self._use(xb, yb, pb)
+        self.ops.append(
+            lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], ptrs[pb] if pb is not None else 0, dref, code, st))
+        )
+        if pool:
+            return y, (pool_buf, pool_blocks, y)
+        return y
+
+    def se_gate(self, pooled, fc1: nn.Module, fc2: nn.Module) -> int:
+        pool_buf, pool_blocks, y = pooled
+        c, cse = y.C, fc1.out_channels
+        w1 = fc1.weight.detach().float().reshape(cse, c).contiguous()
+        b1 = fc1.bias.detach().float().contiguous()
+        w2 = fc2.weight.detach().float().reshape(c, cse).contiguous()
+        b2 = fc2.bias.detach().float().contiguous()
+        self.keep += [w1, b1, w2, b2]
+        gate = self._new_buf(y.N * y.Cp * 4)
+        fn = self.lib.pasn_se_gate_fwd
+        a = (w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr())
+        n, cp, pos = y.N, y.Cp, y.positions
+        self._use(pool_buf, gate)
+        self.ops.append(
+            lambda ptrs, st: _lib.check(fn(ptrs[pool_buf], pool_blocks, pos, a[0], a[1], a[2], a[3], ptrs[gate], n, c, cp, cse, st))
+        )
+        return gate
+
+    def maxpool(self, x: Act, k, s, p) -> Act:
+        y = self._out_act(x, x.C, k, s, p)
+        d = self._desc(x, y, k, s, p, "none")
+        fn, code = self.lib.pasn_maxpool3d_fwd, self.code
+        xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
+        self._use(xb, yb)
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], ptrs[yb], dref, code, st)))
+        return y
+
+    # ---- arena planning ---------------------------------------------------------------------------
+    def finish(self, x_in: Act, y_out: Act) -> "Plan":
+        self.bufs[y_out.buf].external = True
+        live: List[Tuple[int, int, int]] = []  # (offset, size, last)
+        total = 0
+        for i, b in enumerate(self.bufs):
+            if b.external:
+                continue
+            live = [a for a in live if a[2] >= b.first]  # still needed by the op that produces b, or later
+            live.sort()
+            off = 0
+            for (o, sz, _) in live:
+                if off + b.nbytes <= o:
+                    break
+                off = max(off, o + sz)
+            b.offset = off
+            live.append((off, b.nbytes, b.last))
+            total = max(total, off + b.nbytes)
+        return Plan(self, x_in, y_out, total)
+
+
+class Plan:
+    def __init__(self, pb: PlanBuilder, x_in: Act, y_out: Act, arena_bytes: int):
+        self.ops, self.keep = pb.ops, pb.keep
+        self.in_buf, self.out_buf, self.out = x_in.buf, y_out.buf, y_out
+        self.dtype = pb.dtype
+        self.arena_bytes = arena_bytes
+        self.naive_bytes = sum(b.nbytes for b in pb.bufs if not b.external)
+        self.arena = torch.empty(max(arena_bytes, ALIGN), dtype=torch.uint8, device=pb.device)
+        base = self.arena.data_ptr()
+        assert base % ALIGN == 0
+        self.ptrs = [0 if b.external else base + b.offset for b in pb.bufs]
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        o = self.out
+        y = torch.empty((o.N, o.T, o.H, o.W, o.Cp), dtype=self.dtype, device=x.device)
+        ptrs = self.ptrs
+        ptrs[self.in_buf] = x.data_ptr()
+        ptrs[self.out_buf] = y.data_ptr()
+        st = _lib.current_stream()
+        for op in self.ops:
+            op(ptrs, st)
+        return y
+
+
+def logical_view(y: torch.Tensor, channels: int, video: bool) -> torch.Tensor:
+    """Channels-last storage [N][T][H][W][Cp] -> the reference's logical (N,C,[T,]H,W) tensor (a strided view)."""
+    v = y[..., :channels].permute(0, 4, 1, 2, 3)
+    return v if video else v[:, :, 0]
+
+
+def channels_last_rows(feat: torch.Tensor, dtype: torch.dtype) -> Tuple[torch.Tensor, int, int]:
+    """Logical (N,C,[T,]H,W) tensor -> ([N][S][Cp] storage, S, Cp); zero-copy for views made by ``logical_view``."""
+    n, c = feat.shape[0], feat.shape[1]
+    s = 1
+    for v in feat.shape[2:]:
+        s *= int(v)
+    if feat.dtype == dtype and feat.stride(1) == 1 and feat.stride(-1) % 8 == 0 and feat.stride(-1) >= c:
+        cp = feat.stride(-1)
+        strides, expect = feat.stride(), cp
+        ok = True
+        for dim in range(feat.dim() - 1, 1, -1):
+            if feat.shape[dim] != 1 and strides[dim] != expect:
+                ok = False
+            expect *= feat.shape[dim]
+        if ok and (n == 1 or strides[0] == expect):
+            rows = torch.as_strided(feat, (n, s, cp), (s * cp, cp, 1), feat.storage_offset())
+            return rows, s, cp
+    # foreign layout (e.g. a planar tensor from a non-HIP trunk): repack with torch, zero padded channels
+    cp = round_up(c, 8)
+    rows = torch.zeros((n, s, cp), dtype=dtype, device=feat.device)
+    rows[:, :, :c] = feat.reshape(n, c, s).transpose(1, 2).to(dtype)
+    return rows, s, cp
+
+
+class HipTrunk(nn.Module):
+    """Base of the feature trunks: parameter container + cached HIP plans (forward only, eval mode)."""
+
+    arch = "trunk"
+    out_channels = 0
+
+    def __init__(self):
+        super().__init__()
+        self._plans: Dict[tuple, Tuple[tuple, Plan]] = {}
+        self.compute_dtype: Optional[torch.dtype] = None  # None: follow the parameter dtype
+
+    def build_plan(self, pb: PlanBuilder, x: Act) -> Act:  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def _signature(self) -> tuple:
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def plan_for(self, x: torch.Tensor) -> Plan:
+        p0 = next(self.parameters())
+        dtype = self.compute_dtype or p0.dtype
+        key = (tuple(x.shape), x.dtype, dtype, x.device)
+        sig = self._signature()
+        hit = self._plans.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        pb = PlanBuilder(x.device, dtype, x.dtype)
+        x_in = pb.input(tuple(x.shape))
+        with torch.no_grad():
+            y_out = self.build_plan(pb, x_in)
+        plan = pb.finish(x_in, y_out)
+        self._plans = {k: v for k, v in self._plans.items() if v[0] == sig}  # drop plans packed from stale weights
+        self._plans[key] = (sig, plan)
+        return plan
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError(
+                f"{type(self).__name__}: train-mode forward (batch-statistics norm + backward) is not built yet; "
+                "call .eval() -- the HIP path implements the reference's eval / push / clips-per-second forward"
+            )
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                f"{type(self).__name__}: the HIP forward has no autograd backward yet; run it under torch.no_grad()"
+            )
+        if not x.is_cuda:
+            raise RuntimeError("protoasnet_amd trunks run on the GPU only (input is on %s); there is no CPU fallback" % x.device)
+        if x.dim() not in (4, 5) or x.shape[1] != 3:
+            raise ValueError("expected (N,3,H,W) or (N,3,T,H,W) input, got %s" % (tuple(x.shape),))
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        plan = self.plan_for(x)
+        y = plan.run(x)
+        return logical_view(y, plan.out.C, video=(x.dim() == 5))
