@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec forward of Video ProtoASNet on synthetic echo batches (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one eval-mode forward (logits, similarity, occurrence_map) of the whole model -- trunk + prototype layer --
+over one batch of 32 clips of (3,16,224,224), inputs resident in HBM, weights random (deterministic recipe), bf16
+activations with fp32 accumulation.  Multi-GPU: every rank runs its own batch (weak scaling, no data-path collective:
+clips are independent units); timing = barrier + synchronize on both sides, MAX over ranks.
+
+The JSON line also carries
+  roofline     -- the dominant kernel instance (by device time): algorithmic bytes per launch / its average launch
+                  duration, measured with HIP events recorded on the launch stream inside the timed region;
+  cpu_baseline -- the CPU oracle (restated reference op sequence, torch fp32, all host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling there is ~6300 GB/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--arch", default="x3d_s", choices=["x3d_s", "x3d_m", "resnet2p1d_18"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--prototypes", type=int, default=30)
+    ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from protoasnet_amd import model_builder, synth
+
+    cfg = dict(checkpoint_path="", name="Video_XProtoNet", base_architecture=args.arch, backbone_last_layer_num=-3,
+               pretrained=False, prototype_shape=f"({args.prototypes}, 256, 1, 1, 1)", num_classes=args.classes,
+               img_size=args.size)
+    model = model_builder.build(cfg)
+    synth.load_synth(model)
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and args.cpu_clips) else None
+    model = model.to(dev).eval()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.set_compute_dtype(dtype)
+    shape = (args.batch, 3, args.frames, args.size, args.size)
+    x_cpu = synth.echo_clips(shape, seed=synth.DEFAULT_SEED + rank)
+    x = x_cpu.to(dev).to(dtype)  # resident in HBM before the timed region
+    trunk = model.cnn_backbone
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (also compiles the plan) + pick the dominant kernel instance by device time -----------------
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    plan = trunk.plan_for(x)
+    dominant, timers = None, None
+    if not args.no_roofline:
+        probe = {i: [] for i in range(len(plan.ops))}
+        trunk._timers = probe
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        trunk._timers = None
+        per_kernel = {}
+        for i, evs in probe.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            per_kernel.setdefault(plan.meta[i]["kernel"], [0.0, []])
+            per_kernel[plan.meta[i]["kernel"]][0] += ms
+            per_kernel[plan.meta[i]["kernel"]][1].append(i)
+        dominant = max(per_kernel, key=lambda k: per_kernel[k][0])
+        timers = {i: [] for i in per_kernel[dominant][1]}
+        kernel_ms = {k: round(v[0], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+    else:
+        kernel_ms = {}
+
+    # ---- timed region ------------------------------------------------------------------------------------------
+    trunk._timers = timers
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    trunk._timers = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    logits = out[0]
+    assert torch.isfinite(logits).all(), "non-finite logits"
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    clips = args.batch * world * args.steps
+    value = clips / elapsed
+    result = {
+        "metric": "clips/sec forward", "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"Video ProtoASNet forward, {args.arch} trunk + prototype layer (P={args.prototypes}, D=256, "
+                               f"K={args.classes}), {args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world} (independent clips, no collective)"},
+    }
+
+    # ---- roofline of the dominant kernel -------------------------------------------------------------------------
+    total_bytes = sum(m["bytes"] for m in plan.meta)
+    total_flops = sum(m["flops"] for m in plan.meta)
+    if dominant is not None:
+        durs = [a.elapsed_time(b) for evs in timers.values() for a, b in evs]  # ms, one per launch in the timed region
+        avg_ms = sum(durs) / len(durs)
+        idx = list(timers.keys())
+        avg_bytes = sum(plan.meta[i]["bytes"] for i in idx) / len(idx)
+        avg_flops = sum(plan.meta[i]["flops"] for i in idx) / len(idx)
+        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        result["roofline"] = {
+            "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": len(idx),
+            "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
+            "mfma_tflops": round(avg_flops / (avg_ms * 1e-3) / 1e12, 2),
+        }
+        result["kernel_ms_per_step"] = kernel_ms
+    result["trunk_algorithmic"] = {
+        "bytes_per_clip": int(total_bytes / args.batch), "flops_per_clip": int(total_flops / args.batch),
+        "hbm_frac_whole_step": round(total_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        "arena_bytes": plan.arena_bytes,
+    }
+
+    # ---- CPU baseline: the oracle (restated reference op sequence) on a bounded sample of the same workload ---------
+    if cpu_state is not None:
+        import oracle
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        xs = x_cpu[: args.cpu_clips].float()
+        with torch.no_grad():
+            oracle.nets.xprotonet_forward(cpu_state, xs[:1], arch=args.arch)  # warm-up
+            t0 = time.perf_counter()
+            ref = oracle.nets.xprotonet_forward(cpu_state, xs, arch=args.arch)
+            dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(args.cpu_clips / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_clips} clips of 3x{args.frames}x{args.size}x{args.size}, fp32 torch oracle "
+                      f"(reference op sequence incl. broadcast-product pooling), {dt:.1f} s",
+        }
+        # the same clips through the HIP path must agree with what the CPU computed (bf16 tolerance)
+        err = float((out[1][: args.cpu_clips].float().cpu() - ref["similarity"]).abs().max())
+        result["cpu_baseline"]["max_abs_similarity_diff_vs_gpu"] = round(err, 5)
+    print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

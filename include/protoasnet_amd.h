@@ -84,6 +84,9 @@ int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const
  */
 int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
                     const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream);
+/* Which kernel instance pasn_conv3d_fwd picks for this geometry: NT*10 + MT (output-channel / position tiles per
+ * wave, i.e. conv3d_mfma_kernel<dtype, NT, MT>); 0 on a bad descriptor.  For profilers and benchmarks. */
+int pasn_conv3d_variant(const pasn_conv_desc* d);
 
 /*
  * Depthwise convolution (groups = C), channels-last, fused scale/bias/activation; optionally also

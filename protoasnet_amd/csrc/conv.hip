@@ -236,17 +236,26 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const T* __restrict__ 
     }
 }
 
+// Tile choice (also reported to the host by pasn_conv3d_variant so benchmarks can name the kernel instance).
+// NT: output-channel tiles per wave (weights are padded to 128 rows so any NT <= 4 stays in bounds).
+// MT: position tiles per wave.  Big position counts reuse each weight fragment twice -- but only while the
+// accumulators leave room for >= 3 waves per SIMD (NT*MT*16 accumulator registers; NT=4,MT=2 would drop to one
+// wave and cannot hide HBM latency).
+static void conv_variant(const pasn_conv_desc& d, int& NT, int& MT) {
+    const long M = (long)d.N * d.To * d.Ho * d.Wo;
+    const int tiles = ceil_div(d.Cout_p, 32);
+    NT = tiles >= 4 ? 4 : tiles;
+    if (tiles > 4 && tiles % 4 != 0 && tiles % 3 == 0) NT = 3;
+    MT = (M >= 256L * 1024 && NT <= 2) ? 2 : 1;
+}
+
 template <typename T>
 static int launch_conv3d(const void* x, const void* w, const float* scale, const float* bias, const void* res,
                          const float* gate, void* y, const pasn_conv_desc& d, hipStream_t s) {
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const int tiles = ceil_div(d.Cout_p, 32);
-    // NT: output-channel tiles per wave (weights are padded to 128 rows so any NT <= 4 stays in bounds)
-    int NT = tiles >= 4 ? 4 : tiles;
-    if (tiles > 4 && tiles % 4 != 0 && tiles % 3 == 0) NT = 3;
-    // big position counts: reuse each weight fragment twice -- but only while the accumulators leave room for
-    // >= 3 waves per SIMD (NT*MT*16 accumulator registers; NT=4,MT=2 drops to one wave and cannot hide HBM latency)
-    const int MT = (M >= 256L * 1024 && NT <= 2) ? 2 : 1;
+    int NT, MT;
+    conv_variant(d, NT, MT);
     const dim3 grid(ceil_div(M, 4 * 32 * MT), ceil_div(tiles, NT)), block(256);
     PASN_REQUIRE((long)grid.y * NT * 32 <= d.w_rows, "packed weight has too few rows for the chosen tiling");
 #define PASN_CV(NT_, MT_)                                                                                     \
@@ -483,6 +492,13 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     if (dtype == PASN_BF16) return launch_conv3d<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
     set_error("pasn_conv3d_fwd: unknown dtype");
     return PASN_ERR_ARG;
+}
+
+extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d) {
+    if (!conv_desc_ok(d)) return 0;
+    int NT, MT;
+    conv_variant(*d, NT, MT);
+    return NT * 10 + MT;
 }
 
 extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d) {

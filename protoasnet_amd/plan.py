@@ -101,7 +101,9 @@ class PlanBuilder:
         self.bufs: List[_Buf] = []
         self.ops: List[Callable[[List[int], int], None]] = []
         self.keep: List[object] = []  # packed weights / descriptors kept alive with the plan
+        self.meta: List[dict] = []  # per launch: kernel instance name, algorithmic bytes and flops (DESIGN.md "Measurement")
         self.lib = _lib.lib()
+        self.tname = "bf16" if dtype == torch.bfloat16 else "f32"
 
     # ---- buffers ---------------------------------------------------------------------------------
     def _new_buf(self, nbytes: int, external: bool = False) -> int:
@@ -138,6 +140,18 @@ class PlanBuilder:
         self.keep.append(d)
         return d
 
+    # ---- algorithmic work of one launch (true channel counts, every tensor moved once) -----------------
+    @staticmethod
+    def _touched(x: Act, y: Act, k, s) -> int:
+        """Input positions a window sweep really needs (a 1x1 stride-2 conv reads a quarter of its input)."""
+        t = x.T if k[0] >= s[0] else y.T * k[0]
+        h = x.H if k[1] >= s[1] else y.H * k[1]
+        w = x.W if k[2] >= s[2] else y.W * k[2]
+        return x.N * min(t, x.T) * min(h, x.H) * min(w, x.W)
+
+    def _note(self, kind: str, name: str, nbytes: int, flops: int) -> None:
+        self.meta.append({"kind": kind, "kernel": name, "bytes": int(nbytes), "flops": int(flops)})
+
     # ---- ops -------------------------------------------------------------------------------------
     def first_conv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str) -> Act:
         assert x.planar and x.C == 3, "the first conv reads the planar 3-channel clip"
@@ -156,6 +170,10 @@ class PlanBuilder:
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
         self._use(xb, yb)
+        in_es = 2 if self.in_dtype == torch.bfloat16 else 4
+        out_pos = y.N * y.positions
+        self._note("first_conv", f"first_conv_kernel<{'bf16' if in_es == 2 else 'f32'},{self.tname},{y.Cp}>",
+                   self._touched(x, y, k, s) * 3 * in_es + out_pos * y.C * self.es, 2 * out_pos * y.C * 3 * k[1] * k[2])
         self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, code_out, st)))
         return y
 
@@ -174,6 +192,12 @@ class PlanBuilder:
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, rb, gb, dref = x.buf, y.buf, (residual.buf if residual is not None else None), in_gate, ctypes.byref(d)
         self._use(xb, yb, rb, gb)
+        variant = int(self.lib.pasn_conv3d_variant(dref))
+        taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
+        self._note("conv", f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
+                   (self._touched(x, y, k, s) * x.C + out_pos * y.C * (2 if residual is not None else 1)
+                    + y.C * x.C * taps) * self.es + (x.N * x.C * 4 if in_gate is not None else 0),
+                   2 * out_pos * y.C * x.C * taps)
         self.ops.append(
             lambda ptrs, st: _lib.check(
                 fn(ptrs[xb], a[0], a[1], a[2], ptrs[rb] if rb is not None else 0, ptrs[gb] if gb is not None else 0,
@@ -200,6 +224,10 @@ class PlanBuilder:
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, pb, dref = x.buf, y.buf, pool_buf, ctypes.byref(d)
         self._use(xb, yb, pb)
+        out_pos = y.N * y.positions
+        self._note("dwconv", f"dwconv3d_kernel<{self.tname}>",
+                   (self._touched(x, y, k, s) + out_pos) * y.C * self.es + (y.N * pool_blocks * y.C * 4 if pool else 0),
+                   2 * out_pos * y.C * taps)
         self.ops.append(
             lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], ptrs[pb] if pb is not None else 0, dref, code, st))
         )
@@ -220,6 +248,7 @@ class PlanBuilder:
         a = (w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr())
         n, cp, pos = y.N, y.Cp, y.positions
         self._use(pool_buf, gate)
+        self._note("se_gate", "se_gate_kernel", (y.N * pool_blocks * c + y.N * c + 2 * c * cse) * 4, 4 * y.N * c * cse)
         self.ops.append(
             lambda ptrs, st: _lib.check(fn(ptrs[pool_buf], pool_blocks, pos, a[0], a[1], a[2], a[3], ptrs[gate], n, c, cp, cse, st))
         )
@@ -231,6 +260,7 @@ class PlanBuilder:
         fn, code = self.lib.pasn_maxpool3d_fwd, self.code
         xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
         self._use(xb, yb)
+        self._note("maxpool", f"maxpool3d_kernel<{self.tname}>", (self._touched(x, y, k, s) + y.N * y.positions) * y.C * self.es, 0)
         self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], ptrs[yb], dref, code, st)))
         return y
 
@@ -257,25 +287,38 @@ class PlanBuilder:
 
 class Plan:
     def __init__(self, pb: PlanBuilder, x_in: Act, y_out: Act, arena_bytes: int):
-        self.ops, self.keep = pb.ops, pb.keep
+        self.ops, self.keep, self.meta = pb.ops, pb.keep, pb.meta
         self.in_buf, self.out_buf, self.out = x_in.buf, y_out.buf, y_out
         self.dtype = pb.dtype
         self.arena_bytes = arena_bytes
         self.naive_bytes = sum(b.nbytes for b in pb.bufs if not b.external)
-        self.arena = torch.empty(max(arena_bytes, ALIGN), dtype=torch.uint8, device=pb.device)
-        base = self.arena.data_ptr()
-        assert base % ALIGN == 0
+        self.arena = torch.empty(arena_bytes + ALIGN, dtype=torch.uint8, device=pb.device)
+        base = round_up(self.arena.data_ptr(), ALIGN)
         self.ptrs = [0 if b.external else base + b.offset for b in pb.bufs]
 
-    def run(self, x: torch.Tensor) -> torch.Tensor:
+    def run(self, x: torch.Tensor, timers: Optional[Dict[int, list]] = None) -> torch.Tensor:
+        """Replay the launches on torch's current stream.  ``timers`` maps launch index -> list that receives one
+        (start, end) ``torch.cuda.Event`` pair per replay (events are recorded on the same stream as the kernel)."""
         o = self.out
         y = torch.empty((o.N, o.T, o.H, o.W, o.Cp), dtype=self.dtype, device=x.device)
         ptrs = self.ptrs
         ptrs[self.in_buf] = x.data_ptr()
         ptrs[self.out_buf] = y.data_ptr()
         st = _lib.current_stream()
-        for op in self.ops:
+        if not timers:
+            for op in self.ops:
+                op(ptrs, st)
+            return y
+        for i, op in enumerate(self.ops):
+            sink = timers.get(i)
+            if sink is None:
+                op(ptrs, st)
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             op(ptrs, st)
+            e1.record()
+            sink.append((e0, e1))
         return y
 
 
@@ -361,5 +404,5 @@ class HipTrunk(nn.Module):
             x = x.float()
         x = x.contiguous()
         plan = self.plan_for(x)
-        y = plan.run(x)
+        y = plan.run(x, getattr(self, "_timers", None))  # bench.py brackets chosen launches with HIP events
         return logical_view(y, plan.out.C, video=(x.dim() == 5))

@@ -1,0 +1,264 @@
+"""GPU: each trunk kernel, called through the C-ABI, against plain fp32 torch on the CPU for the same op.
+
+fp32 kernels must agree to 1e-3 (BASELINE north_star tolerance; in practice ~1e-5); bf16 kernels are compared
+with the fp32 result of the SAME bf16-rounded operands, so only accumulation / output rounding differs."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _pb(dtype, in_dtype=None):
+    from protoasnet_amd.plan import PlanBuilder
+
+    return PlanBuilder(torch.device(DEV), dtype, in_dtype or dtype)
+
+
+def _run_single(pb, x_in, y_out, x_storage):
+    plan = pb.finish(x_in, y_out)
+    y = plan.run(x_storage)
+    torch.cuda.synchronize()
+    return y
+
+
+def _to_cl(x, cp, dtype):
+    """(N,C,T,H,W) fp32 -> channels-last storage [N][T][H][W][Cp] in dtype, zero padded."""
+    n, c = x.shape[:2]
+    out = torch.zeros((n,) + tuple(x.shape[2:]) + (cp,), dtype=dtype, device=DEV)
+    out[..., :c] = x.permute(0, 2, 3, 4, 1).to(DEV).to(dtype)
+    return out
+
+
+def _from_cl(y, c):
+    return y[..., :c].permute(0, 4, 1, 2, 3).float().cpu()
+
+
+def _rt(x, dtype):
+    """Round-trip through the compute dtype (what the kernel actually sees)."""
+    return x.to(dtype).float()
+
+
+def _tols(dtype):
+    return (1e-3, 1e-4) if dtype == torch.float32 else (3e-2, 2e-2)
+
+
+def _cl_input(pb, x, dtype):
+    from protoasnet_amd.plan import Act, round_up
+
+    n, c, t, h, w = x.shape
+    cp = round_up(c, 8)
+    store = _to_cl(x, cp, dtype)
+    act = Act(n, t, h, w, c, cp, pb._new_buf(store.numel() * store.element_size(), external=True))
+    return act, store
+
+
+CONV_CASES = [
+    # cin, cout, k, s, p, shape(T,H,W), act, residual
+    (24, 54, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 9, 7), "relu", False),     # X3D expand (Cout 54 -> pad 56)
+    (54, 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 8), "relu", True),      # X3D project + residual
+    (24, 48, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 9, 9), "none", False),     # strided shortcut
+    (45, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 6, 6), "relu", False),     # R(2+1)D stem temporal conv
+    (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 7, 7), "relu", False),    # Conv2Plus1D spatial
+    (144, 64, (3, 1, 1), (2, 1, 1), (1, 0, 0), (5, 4, 4), "none", True),     # temporal, stride 2, residual
+    (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), (4, 8, 8), "swish", False),   # generic 3x3x3
+    (432, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 5, 5), "sigmoid", False),  # many k-steps, 6 output tiles (NT=3)
+    (216, 216, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 6, 6), "abs", False),    # 7 output tiles (NT=4, 2 chunks)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_mfma(case, dtype):
+    cin, cout, k, s, p, thw, act, use_res = case
+    torch.manual_seed(hash(case) % 1000)
+    n = 2
+    x = torch.randn(n, cin, *thw)
+    conv = nn.Conv3d(cin, cout, k, s, p, bias=False)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    xr = _rt(x, dtype)
+    conv_r = nn.Conv3d(cin, cout, k, s, p, bias=False)
+    conv_r.weight.data = _rt(conv.weight.data, dtype)
+    ref = bn(conv_r(xr))
+    res = torch.randn_like(ref) if use_res else None
+    if res is not None:
+        ref = ref + _rt(res, dtype)
+    ref = {"relu": F.relu, "none": lambda v: v, "swish": lambda v: v * torch.sigmoid(v), "sigmoid": torch.sigmoid,
+           "abs": torch.abs}[act](ref).detach()
+
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    ra = rs = None
+    if res is not None:
+        ra, rs = _cl_input(pb, res, dtype)
+    conv, bn = conv.to(DEV), bn.to(DEV)
+    y = pb.conv(xa, conv, bn, act, residual=ra)
+    plan = pb.finish(xa, y)
+    if ra is not None:
+        plan.ptrs[ra.buf] = rs.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"conv {case} {dtype}")
+    if out.shape[-1] > cout:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("gate", [False, True])
+def test_conv3d_input_gate_swish(dtype, gate):
+    """X3D project conv: x' = swish(x * gate[n][c]) fused into the operand load."""
+    torch.manual_seed(3)
+    n, cin, cout, thw = 3, 54, 24, (2, 5, 6)
+    x = torch.randn(n, cin, *thw)
+    g = torch.rand(n, cin) if gate else None
+    conv = nn.Conv3d(cin, cout, 1, bias=False)
+    xr = _rt(x, dtype)
+    xin = xr * g[:, :, None, None, None] if gate else xr
+    xin = _rt(xin * torch.sigmoid(xin), dtype)  # the kernel rounds the transformed operand to the MFMA input type
+    ref = F.conv3d(xin, _rt(conv.weight.data, dtype)).detach()
+
+    from protoasnet_amd.plan import round_up
+
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    gbuf = gt = None
+    if gate:
+        gt = torch.zeros(n, round_up(cin, 8), dtype=torch.float32, device=DEV)
+        gt[:, :cin] = g.to(DEV)
+        gbuf = pb._new_buf(gt.numel() * 4, external=True)
+    y = pb.conv(xa, conv.to(DEV), None, "none", in_gate=gbuf, in_swish=True)
+    plan = pb.finish(xa, y)
+    if gate:
+        plan.ptrs[gbuf] = gt.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, "gate+swish conv")
+
+
+FIRST_CASES = [
+    (24, (1, 3, 3), (1, 2, 2), (0, 1, 1), (3, 17, 19), "none"),   # X3D stem conv_xy
+    (45, (1, 7, 7), (1, 2, 2), (0, 3, 3), (2, 20, 22), "relu"),   # R(2+1)D stem
+    (64, (1, 7, 7), (1, 2, 2), (0, 3, 3), (1, 30, 30), "relu"),   # ResNet-18 conv1 (image = T 1)
+]
+
+
+@pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("case", FIRST_CASES)
+def test_first_conv(case, dtypes):
+    cout, k, s, p, thw, act = case
+    in_dtype, dtype = dtypes
+    torch.manual_seed(5)
+    n = 2
+    x = torch.randn(n, 3, *thw)
+    conv = nn.Conv3d(3, cout, k, s, p, bias=False)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    ref = bn(conv(_rt(x, in_dtype)))
+    ref = (F.relu(ref) if act == "relu" else ref).detach()
+    pb = _pb(dtype, in_dtype)
+    xa = pb.input(tuple(x.shape))
+    y = pb.first_conv(xa, conv.to(DEV), bn.to(DEV), act)
+    out = _run_single(pb, xa, y, x.to(DEV).to(in_dtype).contiguous())
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"first conv {case}")
+
+
+DW_CASES = [
+    (24, (5, 1, 1), (1, 1, 1), (2, 0, 0), (6, 5, 5), "relu", False),    # X3D stem conv_t
+    (54, (3, 3, 3), (1, 2, 2), (1, 1, 1), (3, 9, 9), "none", True),     # X3D conv_b stride 2 + SE pool
+    (108, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 7, 6), "swish", False),  # X3D conv_b stride 1, Swish epilogue
+    (432, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 13, 13), "none", True),  # widest stage, several pool blocks
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv3d_and_se(case, dtype):
+    c, k, s, p, thw, act, pool = case
+    torch.manual_seed(7)
+    n = 2
+    x = torch.randn(n, c, *thw)
+    conv = nn.Conv3d(c, c, k, s, p, groups=c, bias=False)
+    bn = nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    pre = bn(conv(_rt(x, dtype))).detach()
+    ref = {"relu": F.relu, "none": lambda v: v, "swish": lambda v: v * torch.sigmoid(v)}[act](pre)
+
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    conv, bn = conv.to(DEV), bn.to(DEV)
+    atol, rtol = _tols(dtype)
+    if not pool:
+        y = pb.dwconv(xa, conv, bn, act)
+        out = _run_single(pb, xa, y, xs)
+        assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"dwconv {case}")
+        return
+    from protoasnet_amd.backbones import _SE
+
+    se = _SE(c)
+    with torch.no_grad():
+        for q in se.parameters():
+            q.normal_(0, 0.2)
+    y, pooled = pb.dwconv(xa, conv, bn, act, pool=True)
+    gate_buf = pb.se_gate(pooled, se.fc1.to(DEV), se.fc2.to(DEV))
+    pb.bufs[gate_buf].external = True
+    plan = pb.finish(xa, y)
+    gate = torch.empty(n, y.Cp, dtype=torch.float32, device=DEV)
+    plan.ptrs[gate_buf] = gate.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"dwconv {case}")
+    se = se.cpu()
+    gm = pre.mean(dim=(2, 3, 4), keepdim=True)
+    gref = torch.sigmoid(se.fc2(F.relu(se.fc1(gm)))).reshape(n, c).detach()
+    assert_close(gate[:, :c], gref, 1e-3 if dtype == torch.float32 else 1e-2, 0, "SE gate")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool(dtype):
+    torch.manual_seed(9)
+    x = torch.randn(2, 64, 1, 15, 14)
+    ref = F.max_pool3d(_rt(x, dtype), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    y = pb.maxpool(xa, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    out = _run_single(pb, xa, y, xs)
+    assert_close(_from_cl(out, 64), ref, 0, 0, "maxpool is exact")
+
+
+def test_bad_arguments_raise():
+    """Error behaviour of the boundary: bad geometry -> ValueError with the library's message, no launch."""
+    from protoasnet_amd import _lib
+
+    d = _lib.ConvDesc(N=1, Ti=1, Hi=4, Wi=4, Cin=5, Cin_p=5, To=1, Ho=4, Wo=4, Cout=8, Cout_p=8, kt=1, kh=1, kw=1, st=1, sh=1, sw=1)
+    t = torch.zeros(1024, device=DEV)
+    with pytest.raises(ValueError, match="multiples of 8"):
+        _lib.check(_lib.lib().pasn_conv3d_fwd(t.data_ptr(), t.data_ptr(), 0, 0, 0, 0, t.data_ptr(), ctypes.byref(d), 0, 0))
+    with pytest.raises(ValueError, match="null pointer"):
+        _lib.check(_lib.lib().pasn_maxpool3d_fwd(0, 0, ctypes.byref(d), 0, 0))

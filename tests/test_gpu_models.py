@@ -1,0 +1,122 @@
+"""GPU: whole models behind the reference's nn.Module surface vs the oracle / the reference's golden vectors."""
+import pytest
+import torch
+
+import oracle
+from conftest import assert_close
+from protoasnet_amd import synth
+from util import (CFG_PPNET, CFG_PPNET_BOTTLENECK, CFG_VIDEO_R2P1D, CFG_VIDEO_X3D, CFG_XPROTO, synth_model)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gpu(cfg):
+    return synth_model(cfg).to(DEV).eval()
+
+
+@pytest.mark.parametrize("tag,cfg", [("regular", CFG_PPNET), ("bottleneck", CFG_PPNET_BOTTLENECK)])
+def test_ppnet_resnet18_vs_reference_golden(golden, tag, cfg):
+    g = golden("g1_ppnet_resnet18.npz")
+    m = _gpu(cfg)
+    x = synth.echo_clips((2, 3, 224, 224)).to(DEV)
+    with torch.no_grad():
+        logits, min_d = m(x)
+        conv_out, dist = m.push_forward(x)
+        feats = m.features(x)
+    assert tuple(feats.shape) == (2, 512, 7, 7) and tuple(conv_out.shape) == (2, m.prototype_shape[1], 7, 7)
+    scale = float(abs(g[f"{tag}_backbone_features"]).max())
+    assert_close(feats, g[f"{tag}_backbone_features"], 1e-4 * scale, 1e-4, "trunk features")
+    assert_close(conv_out, g[f"{tag}_conv_features"], 1e-3, 0, "conv_features")
+    assert_close(dist, g[f"{tag}_distances"], 1e-3 * float(g[f"{tag}_distances"].max()) / 10, 0, "distances")
+    assert_close(min_d, g[f"{tag}_min_distances"], 1e-3 * float(g[f"{tag}_distances"].max()) / 10, 0, "min_distances")
+    assert_close(logits, g[f"{tag}_logits"], 1e-3, 0, "logits")
+
+
+def test_xprotonet_resnet18_vs_reference_golden(golden):
+    g = golden("g2_xprotonet_resnet18.npz")
+    m = _gpu(CFG_XPROTO)
+    x = synth.echo_clips((2, 3, 224, 224)).to(DEV)
+    with torch.no_grad():
+        logits, sim, occ = m(x)
+        feats, pdist, occ2, logits2 = m.push_forward(x)
+        occ3 = m.compute_occurence_map(x)
+    assert tuple(occ.shape) == (2, 40, 1, 7, 7) and tuple(feats.shape) == (2, 40, 512)
+    assert_close(sim, g["similarity"], 1e-3, 0, "similarity")
+    assert_close(pdist, g["proto_dist"], 1e-3, 0, "1 - similarity")
+    assert_close(logits, g["logits"], 1e-3, 0, "logits")
+    assert_close(occ, g["occurrence_map"], 2e-3, 1e-3, "occurrence_map")
+    assert_close(feats, g["features_extracted"], 1.0, 1e-3, "features_extracted (|F| ~ 1e4)")
+    assert torch.equal(occ, occ2) and torch.equal(logits, logits2)
+    assert_close(occ3, occ, 0, 0, "compute_occurence_map == forward's map")
+
+
+@pytest.mark.parametrize("cfg,shape", [(CFG_VIDEO_X3D, (2, 3, 4, 64, 64)), (CFG_VIDEO_X3D, (1, 3, 5, 96, 80)),
+                                       (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32)), (CFG_VIDEO_R2P1D, (1, 3, 6, 48, 40))])
+def test_video_models_fp32_vs_oracle(cfg, shape):
+    m = _gpu(cfg)
+    x = synth.echo_clips(shape)
+    arch = cfg["base_architecture"]
+    ref = oracle.nets.xprotonet_forward({k: v.cpu() for k, v in m.state_dict().items()}, x, arch=arch)
+    with torch.no_grad():
+        feat = m.cnn_backbone(x.to(DEV))
+        logits, sim, occ = m(x.to(DEV))
+        feats, pdist, _, _ = m.push_forward(x.to(DEV))
+    assert tuple(feat.shape) == tuple(ref["backbone_features"].shape)
+    fs = float(ref["backbone_features"].abs().max())
+    assert_close(feat, ref["backbone_features"], 1e-3 * max(fs, 1.0), 1e-3, f"{arch} trunk features")
+    assert tuple(occ.shape) == tuple(ref["occurrence_map"].shape)
+    assert_close(occ, ref["occurrence_map"], 1e-3 * max(1.0, float(ref["occurrence_map"].max())), 1e-3, "occurrence_map")
+    assert_close(sim, ref["similarity"], 1e-3, 0, "similarity")
+    assert_close(pdist, ref["proto_dist"], 1e-3, 0, "prototype distances")
+    assert_close(logits, ref["logits"], 1e-3, 0, "logits")
+    assert_close(feats, ref["features_extracted"], 1e-3 * float(ref["features_extracted"].abs().max()), 1e-3, "features_extracted")
+
+
+@pytest.mark.parametrize("cfg,shape", [(CFG_VIDEO_X3D, (2, 3, 4, 64, 64)), (CFG_VIDEO_R2P1D, (1, 3, 8, 32, 32)), (CFG_XPROTO, (2, 3, 128, 128))])
+def test_bf16_compute_tolerance(cfg, shape):
+    """bf16 activations/weights with fp32 accumulate: report-style bound, not the 1e-3 fp32 gate."""
+    m = _gpu(cfg).set_compute_dtype(torch.bfloat16)
+    x = synth.echo_clips(shape)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = oracle.nets.xprotonet_forward(sd, x, arch=cfg["base_architecture"])
+    with torch.no_grad():
+        logits, sim, occ = m(x.to(DEV))
+    assert logits.dtype == torch.float32 and sim.dtype == torch.float32
+    assert_close(sim, ref["similarity"], 2e-2, 0, "bf16 similarity")
+    assert_close(logits, ref["logits"], 0.25, 0.05, "bf16 logits")
+    rel = (occ.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()
+    assert float(rel) < 0.05, f"bf16 occurrence map mean relative error {float(rel):.3g}"
+
+
+def test_module_surface_and_errors():
+    m = _gpu(CFG_VIDEO_X3D)
+    assert m.num_prototypes == 30 and m.num_classes == 3 and tuple(m.prototype_class_identity.shape) == (30, 3)
+    assert not hasattr(m, "epsilon")  # Video_XProtoNet skips PPNet.__init__ in the reference too
+    x = synth.echo_clips((1, 3, 4, 64, 64)).to(DEV)
+    with pytest.raises(NotImplementedError, match="no_grad"):
+        m(x)  # grad enabled + trainable parameters: refuse instead of silently returning graph-less tensors
+    m.train()
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="eval"):
+        m(x)
+    m.eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU only"):
+        m(x.cpu())
+    # weights changed in place -> packed copies are refreshed
+    with torch.no_grad():
+        a = m(x)[0].clone()
+        m.last_layer.weight.mul_(2.0)
+        b = m(x)[0]
+        m.cnn_backbone.stem.conv_xy.weight.mul_(1.5)
+        c = m(x)[0]
+    assert_close(b, 2 * a, 1e-5, 1e-5, "last layer refresh")
+    assert not torch.allclose(b, c)
+
+
+def test_arena_reuse_on_gpu():
+    m = _gpu(CFG_VIDEO_X3D)
+    x = synth.echo_clips((1, 3, 4, 64, 64)).to(DEV)
+    with torch.no_grad():
+        m(x)
+    plan = m.cnn_backbone.plan_for(x)
+    assert plan.arena_bytes < 0.25 * plan.naive_bytes, (plan.arena_bytes, plan.naive_bytes)

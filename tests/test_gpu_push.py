@@ -1,0 +1,153 @@
+"""GPU: the device-resident push sweeps vs the restated reference selection loops -- indices must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from protoasnet_amd import synth
+from util import CFG_PPNET_BOTTLENECK, CFG_VIDEO_X3D, synth_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _xproto_sweep(batches, ident, num_classes, class_specific, abstain, P, D, batch_size):
+    from protoasnet_amd import _lib
+    from protoasnet_amd.push import PushState, xproto_class_mask
+
+    state = PushState(P, D, DEV)
+    cls = torch.argmax(torch.from_numpy(ident), dim=1).to(torch.int32).to(DEV)
+    mask = xproto_class_mask(P, num_classes, class_specific, abstain).to(DEV)
+    for i, (feat, dist, gt) in enumerate(batches):
+        f, d, g = torch.from_numpy(feat).to(DEV), torch.from_numpy(dist).to(DEV), torch.from_numpy(gt).to(DEV)
+        _lib.check(_lib.lib().pasn_push_xproto_update(d.data_ptr(), f.data_ptr(), g.data_ptr(), cls.data_ptr(), mask.data_ptr(),
+                                                      state.dist.data_ptr(), state.index.data_ptr(), state.vec.data_ptr(),
+                                                      feat.shape[0], P, D, i * batch_size, 0))
+    torch.cuda.synchronize()
+    return state.dist.cpu().numpy(), state.index.cpu().numpy(), state.vec.cpu().numpy()
+
+
+@pytest.mark.parametrize("class_specific,abstain", [(True, True), (True, False), (False, False)])
+def test_xproto_push_kernel_bit_exact(class_specific, abstain):
+    rng = np.random.default_rng(5)
+    P, D, K, B, nb = 40, 32, 4, 7, 9
+    ident = oracle.heads.prototype_class_identity(P, K).numpy()
+    batches = []
+    for b in range(nb):
+        dist = rng.random((B, P)).astype(np.float32)
+        dist = np.round(dist * 8) / 8  # many exact ties inside and across batches
+        gt = rng.integers(0, 3, size=B).astype(np.int64)
+        if b == 2:
+            gt[:] = 1  # a batch where some classes are absent (mask.all() -> continue)
+        batches.append((rng.standard_normal((B, P, D)).astype(np.float32), dist, gt))
+    ref_d, ref_f, ref_w = oracle.push.xproto_push_select(batches, ident, K, class_specific, abstain)
+    d, idx, vec = _xproto_sweep(batches, ident, K, class_specific, abstain, P, D, B)
+    for j in range(P):
+        assert ref_w[j] is not None
+        assert idx[j] == ref_w[j][0] * B + ref_w[j][1], f"prototype {j}: {idx[j]} vs {ref_w[j]}"
+        assert d[j] == np.float32(ref_d[j])
+        assert np.array_equal(vec[j], ref_f[j])
+
+
+def test_xproto_push_never_seen_class_stays_empty():
+    P, D, K = 8, 4, 4
+    ident = oracle.heads.prototype_class_identity(P, K).numpy()
+    feat = np.ones((3, P, D), np.float32)
+    dist = np.full((3, P), 0.25, np.float32)
+    gt = np.zeros(3, np.int64)  # only class 0 present
+    d, idx, _ = _xproto_sweep([(feat, dist, gt)], ident, K, True, True, P, D, 3)
+    assert idx.tolist() == [0, 0, -1, -1, -1, -1, 0, 0]  # classes 1,2 unseen; abstain prototypes (last P/K) unmasked
+    assert np.isinf(d[2:6]).all()
+
+
+def _ppnet_sweep(batches, ident, num_classes, class_specific, P, D, S, batch_size):
+    from protoasnet_amd import _lib
+    from protoasnet_amd.push import PushState
+
+    state = PushState(P, D, DEV, ppnet=True)
+    cls = torch.argmax(torch.from_numpy(ident), dim=1).to(torch.int32).to(DEV)
+    for i, (conv, dist, y) in enumerate(batches):
+        B = conv.shape[0]
+        z = torch.from_numpy(conv).reshape(B, D, S).transpose(1, 2).contiguous().to(DEV)  # [B][S][D], D % 8 == 0
+        dd = torch.from_numpy(dist).reshape(B, P, S).contiguous().to(DEV)
+        yy = torch.from_numpy(y).to(DEV)
+        _lib.check(_lib.lib().pasn_push_ppnet_update(dd.data_ptr(), z.data_ptr(), yy.data_ptr(), cls.data_ptr(), int(class_specific),
+                                                     state.dist.data_ptr(), state.index.data_ptr(), state.vec.data_ptr(), B, P, S, D,
+                                                     D, 0, i * batch_size, 0))
+    torch.cuda.synchronize()
+    return state.dist.cpu().numpy(), state.index.cpu().numpy(), state.vec.cpu().numpy()
+
+
+@pytest.mark.parametrize("class_specific", [True, False])
+def test_ppnet_push_kernel_bit_exact(class_specific):
+    rng = np.random.default_rng(6)
+    P, D, K, B, H, W, nb = 30, 16, 3, 5, 4, 3, 6
+    ident = oracle.heads.prototype_class_identity(P, K).numpy()
+    batches = []
+    for b in range(nb):
+        dist = np.round(rng.random((B, P, H, W)).astype(np.float32) * 16) / 16
+        y = rng.integers(0, K, size=B).astype(np.int64)
+        if b == 1:
+            y[:] = 2
+        batches.append((rng.standard_normal((B, D, H, W)).astype(np.float32), dist, y))
+    ref_d, ref_p, ref_i = oracle.push.ppnet_push_select(batches, ident, K, (P, D, 1, 1), B, class_specific)
+    d, idx, vec = _ppnet_sweep(batches, ident, K, class_specific, P, D, H * W, B)
+    assert np.array_equal(idx[:, 0], ref_i[:, 0])
+    assert np.array_equal(idx[:, 1], ref_i[:, 1] * W + ref_i[:, 2])
+    assert np.array_equal(d, ref_d.astype(np.float32))
+    assert np.array_equal(vec, ref_p[:, :, 0, 0].astype(np.float32))
+
+
+class _Loader(list):
+    batch_size = 4
+
+
+def _loader(shape, nb, seed):
+    out = _Loader()
+    for b in range(nb):
+        out.append({"cine": synth.echo_clips((4,) + shape, seed=seed + b), "target_AS": synth.echo_labels(4, 3, seed=seed + b),
+                    "filename": [f"c{b}_{i}" for i in range(4)]})
+    return out
+
+
+def test_push_prototypes_video_end_to_end():
+    """push_prototypes over a loader (reference signature) == restated reference loop fed with the same push_forward outputs."""
+    from protoasnet_amd.push import push_prototypes
+
+    m = synth_model(CFG_VIDEO_X3D).to(DEV).eval()
+    loader = _loader((3, 4, 64, 64), nb=5, seed=40)
+    recorded = []
+    with torch.no_grad():
+        for s in loader:
+            f, d, _, _ = m.push_forward(s["cine"].to(DEV))
+            recorded.append((f.cpu().numpy(), d.cpu().numpy(), s["target_AS"].numpy()))
+    ref_d, ref_f, ref_w = oracle.push.xproto_push_select(recorded, m.prototype_class_identity.numpy(), m.num_classes, True, False)
+    out = push_prototypes(loader, m, class_specific=True, abstain_class=False, replace_prototypes=True, log=lambda *_: None)
+    idx = out["proto_index"].cpu().numpy()
+    assert [int(i) for i in idx] == [w[0] * 4 + w[1] for w in ref_w]
+    assert np.array_equal(out["proto_dist"].cpu().numpy(), ref_d.astype(np.float32))
+    want = oracle.push.xproto_push_update(ref_f, m.prototype_shape)
+    assert np.array_equal(m.prototype_vectors.detach().cpu().numpy(), want)
+    # idempotence: a second push over the same data keeps the same winners (later-batch tie rule included)
+    with torch.no_grad():
+        sim = m.push_forward(loader[ref_w[0][0]]["cine"].to(DEV))[1]
+    assert float(sim[ref_w[0][1], 0]) < 1e-5  # the projected prototype now sits on its source feature
+
+
+def test_push_prototypes_ppnet_end_to_end():
+    from protoasnet_amd.push import push_prototypes_ppnet
+
+    m = synth_model(CFG_PPNET_BOTTLENECK).to(DEV).eval()
+    loader = _loader((3, 96, 96), nb=4, seed=60)
+    recorded = []
+    with torch.no_grad():
+        for s in loader:
+            c, d = m.push_forward(s["cine"].to(DEV))
+            recorded.append((c.cpu().numpy(), d.cpu().numpy(), s["target_AS"].numpy()))
+    ref_d, ref_p, ref_i = oracle.push.ppnet_push_select(recorded, m.prototype_class_identity.numpy(), m.num_classes,
+                                                        m.prototype_shape, 4, True)
+    out = push_prototypes_ppnet(loader, m, class_specific=True, replace_prototypes=True, log=lambda *_: None)
+    idx = out["proto_index"].cpu().numpy()
+    W = recorded[0][1].shape[3]
+    assert np.array_equal(idx[:, 0], ref_i[:, 0]) and np.array_equal(idx[:, 1], ref_i[:, 1] * W + ref_i[:, 2])
+    assert np.array_equal(m.prototype_vectors.detach().cpu().numpy(), ref_p.astype(np.float32))
