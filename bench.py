@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--prototypes", type=int, default=30)
     ap.add_argument("--classes", type=int, default=3)
-    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--per-op", default="", help="write a per-launch timing table to this file")
     return ap.parse_args()
 
 
@@ -104,6 +105,13 @@ def main():
             per_kernel.setdefault(plan.meta[i]["kernel"], [0.0, []])
             per_kernel[plan.meta[i]["kernel"]][0] += ms
             per_kernel[plan.meta[i]["kernel"]][1].append(i)
+        if args.per_op and rank == 0:  # per-launch table for the optimisation log (not part of the JSON contract)
+            with open(args.per_op, "w") as fh:
+                for i, evs in probe.items():
+                    ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+                    m = plan.meta[i]
+                    fh.write(f"{i:3d} {m['kernel']:34s} {m.get('shape', ''):44s} {ms * 1e3:9.1f} us {m['bytes'] / 1e6:9.1f} MB "
+                             f"{m['bytes'] / ms / 1e6:8.1f} GB/s {m['flops'] / ms / 1e9:8.1f} TF/s\n")
         dominant = max(per_kernel, key=lambda k: per_kernel[k][0])
         timers = {i: [] for i in per_kernel[dominant][1]}
         kernel_ms = {k: round(v[0], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
@@ -169,7 +177,9 @@ def main():
     if cpu_state is not None:
         import oracle
 
-        cores = os.cpu_count() or 1
+        # a 1-GPU box owns a 16-core share of the host (the node reports all 256 hardware threads; using them
+        # oversubscribes the share and runs ~10x slower), so the baseline uses at most 16 threads and says so
+        cores = min(len(os.sched_getaffinity(0)), 16)
         torch.set_num_threads(cores)
         xs = x_cpu[: args.cpu_clips].float()
         with torch.no_grad():

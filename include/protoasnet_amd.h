@@ -96,6 +96,8 @@ int pasn_conv3d_variant(const pasn_conv_desc* d);
  *   pool_partial : fp32 [N][pool_blocks][Cp] or NULL; pool_blocks = pasn_dwconv3d_pool_blocks(d)
  */
 int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d);
+/* Kernel instance for this geometry: WT*100 + KW*10 + SW = dwconv3d_strip_kernel<dtype, WT, KW, SW>; 0 = generic kernel. */
+int pasn_dwconv3d_variant(const pasn_conv_desc* d);
 int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                       float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream);
 

@@ -358,6 +358,106 @@ __global__ __launch_bounds__(256) void dwconv3d_kernel(const T* __restrict__ x, 
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Strip variant (the one the X3D trunk runs): a thread owns WT consecutive outputs along W of one (n, to, ho)
+// row for one 8-channel group and keeps their WT x 8 fp32 accumulators in registers.  For every (kt, kh) it
+// walks the (WT-1)*SW + KW input columns of that row once; each loaded 16-byte chunk is converted once and
+// feeds every output whose window covers it (a register sliding window: 9*(WT+2)/WT loads per output instead
+// of 27 for the 3x3x3 stride-1 stencil), and the KW x 8 weights of the row are read from LDS once per strip.
+// Lanes are laid out channel-group fastest, so a wave's loads are runs of whole Cp-wide position rows.
+// Block = R strips x CG channel groups (R = 256 / CG) of ONE clip; SE partial sums are reduced over the R
+// strips in fixed order.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int WT, int KW, int SW>
+__global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ bias,
+                                                             T* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
+                                                             int CG, int R, int strips) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [taps][Cp] weights, then [R][Cp] pool scratch
+    constexpr int NC = (WT - 1) * SW + KW;                       // input columns a strip touches
+    const int taps = d.kt * d.kh * KW;
+    const int Cp = d.Cout_p;
+    float* wl = lds;
+    float* red = lds + taps * Cp;
+    for (int i = threadIdx.x; i < taps * Cp; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+
+    const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+    const int n = blockIdx.y;
+    const int rows_total = d.To * d.Ho * strips;
+    const int item = blockIdx.x * R + r;
+    const bool live = item < rows_total;
+    float psum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) psum[j] = 0.0f;
+    if (live) {
+        const int strip = item % strips;
+        const int ho = (item / strips) % d.Ho;
+        const int to = item / (strips * d.Ho);
+        const int wo0 = strip * WT;
+        const int wi0 = wo0 * SW - d.pw;
+        float acc[WT][8];
+#pragma unroll
+        for (int o = 0; o < WT; ++o)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[o][j] = 0.0f;
+        for (int a = 0; a < d.kt; ++a) {
+            const int ti = to * d.st - d.pt + a;
+            if (ti < 0 || ti >= d.Ti) continue;
+            for (int b = 0; b < d.kh; ++b) {
+                const int hi = ho * d.sh - d.ph + b;
+                if (hi < 0 || hi >= d.Hi) continue;
+                float wv[KW][8];
+#pragma unroll
+                for (int e = 0; e < KW; ++e) load8(wl + ((a * d.kh + b) * KW + e) * Cp + cg * 8, wv[e]);
+                const T* xrow = x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi) * d.Cin_p + cg * 8;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int wi = wi0 + c;
+                    if (wi < 0 || wi >= d.Wi) continue;
+                    float xv[8];
+                    load8(xrow + (long)wi * d.Cin_p, xv);
+#pragma unroll
+                    for (int e = 0; e < KW; ++e) {
+                        if ((c - e) >= 0 && (c - e) % SW == 0 && (c - e) / SW < WT) {  // resolved at compile time
+                            const int o = (c - e) / SW;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(xv[j], wv[e][j], acc[o][j]);
+                        }
+                    }
+                }
+            }
+        }
+        float sc[8], bs[8];
+        load8(scale + cg * 8, sc);
+        load8(bias + cg * 8, bs);
+        T* yrow = y + ((((long)n * d.To + to) * d.Ho + ho) * d.Wo) * Cp + cg * 8;
+#pragma unroll
+        for (int o = 0; o < WT; ++o) {
+            const int wo = wo0 + o;
+            if (wo >= d.Wo) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float s = acc[o][j] * sc[j] + bs[j];
+                psum[j] += s;
+                v[j] = (cg * 8 + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
+            }
+            store8(yrow + (long)wo * Cp, v);
+        }
+    }
+    if (pool) {  // block-uniform
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[r * Cp + cg * 8 + j] = psum[j];
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+            float s = 0.0f;
+            for (int q = 0; q < R; ++q) s += red[q * Cp + ch];
+            pool[((long)n * gridDim.x + blockIdx.x) * Cp + ch] = s;
+        }
+    }
+}
+
 static void dw_block_shape(int Cp, int& bx, int& by) {
     const int cgs = Cp / 8;
     bx = 1;
@@ -366,19 +466,65 @@ static void dw_block_shape(int Cp, int& bx, int& by) {
     by = 256 / bx;
 }
 
+// Strip geometry; WT = 0 means "use the generic kernel" (window / stride outside the specialised set).
+struct DwGeom {
+    int WT, CG, R, strips, blocks;
+};
+static DwGeom dw_geom(const pasn_conv_desc& d) {
+    DwGeom g = {0, d.Cout_p / 8, 0, 0, 0};
+    const bool special = (d.kw == 3 && (d.sw == 1 || d.sw == 2)) || (d.kw == 1 && d.sw == 1);
+    if (special && g.CG <= 256) {
+        g.WT = (d.Wo % 7 == 0) ? 7 : 8;
+        if (const char* e = getenv("PASN_DW_WT")) {  // tuning knob: 4, 7 or 8
+            const int v = atoi(e);
+            if (v == 4 || v == 7 || v == 8) g.WT = v;
+        }
+        g.R = 256 / g.CG;
+        g.strips = ceil_div(d.Wo, g.WT);
+        g.blocks = ceil_div((long)d.To * d.Ho * g.strips, g.R);
+    } else {
+        g.blocks = ceil_div((long)d.To * d.Ho * d.Wo, DW_POS);
+    }
+    return g;
+}
+
 template <typename T>
 static int launch_dwconv3d(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
                            const pasn_conv_desc& d, hipStream_t s) {
-    int bx, by;
-    dw_block_shape(d.Cout_p, bx, by);
     PASN_REQUIRE(d.Cout_p / 8 <= 256, "depthwise conv supports at most 2048 channels");
-    const int S = d.To * d.Ho * d.Wo;
-    const dim3 grid(ceil_div(S, DW_POS), d.N), block(bx, by);
     const int taps = d.kt * d.kh * d.kw;
-    const size_t lds = (size_t)(taps + by) * d.Cout_p * sizeof(float);
+    const DwGeom g = dw_geom(d);
+    if (g.WT == 0) {
+        int bx, by;
+        dw_block_shape(d.Cout_p, bx, by);
+        const dim3 grid(g.blocks, d.N), block(bx, by);
+        const size_t lds = (size_t)(taps + by) * d.Cout_p * sizeof(float);
+        PASN_REQUIRE(lds <= 64 * 1024, "depthwise conv window x channels too large for the LDS weight tile");
+        hipLaunchKernelGGL((dwconv3d_kernel<T>), grid, block, lds, s, (const T*)x, w, scale, bias, (T*)y, pool, d);
+        return check_launch("dwconv3d_kernel");
+    }
+    const dim3 grid(g.blocks, d.N), block(g.CG * g.R);
+    const size_t lds = (size_t)(taps + g.R) * d.Cout_p * sizeof(float);
     PASN_REQUIRE(lds <= 64 * 1024, "depthwise conv window x channels too large for the LDS weight tile");
-    hipLaunchKernelGGL((dwconv3d_kernel<T>), grid, block, lds, s, (const T*)x, w, scale, bias, (T*)y, pool, d);
-    return check_launch("dwconv3d_kernel");
+#define PASN_DW(WT_, KW_, SW_)                                                                                       \
+    hipLaunchKernelGGL((dwconv3d_strip_kernel<T, WT_, KW_, SW_>), grid, block, lds, s, (const T*)x, w, scale, bias, \
+                       (T*)y, pool, d, g.CG, g.R, g.strips)
+#define PASN_DW_WT(KW_, SW_)                   \
+    switch (g.WT) {                            \
+        case 4: PASN_DW(4, KW_, SW_); break;   \
+        case 7: PASN_DW(7, KW_, SW_); break;   \
+        default: PASN_DW(8, KW_, SW_); break;  \
+    }
+    if (d.kw == 1) {
+        PASN_DW_WT(1, 1)
+    } else if (d.sw == 1) {
+        PASN_DW_WT(3, 1)
+    } else {
+        PASN_DW_WT(3, 2)
+    }
+#undef PASN_DW_WT
+#undef PASN_DW
+    return check_launch("dwconv3d_strip_kernel");
 }
 
 // =================================================================================================
@@ -388,21 +534,30 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       float* __restrict__ gate, int C, int Cp, int Cse) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [Cp] mean, [Cse] hidden
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [Cp] mean, [Cse] hidden, [4][Cp] partial sums
     float* mean = sm;
     float* hid = sm + Cp;
+    float* part = sm + Cp + Cse;
     const int n = blockIdx.x;
-    for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // mean over positions: wave q-slices the block partials (lanes along channels: coalesced), fixed order throughout
+    for (int ch = lane; ch < Cp; ch += 64) {
         float s = 0.0f;
         const float* pp = pool + (long)n * pool_blocks * Cp + ch;
-        for (int q = 0; q < pool_blocks; ++q) s += pp[(long)q * Cp];
-        mean[ch] = s * inv_positions;
+        for (int q = wave; q < pool_blocks; q += 4) s += pp[(long)q * Cp];
+        part[wave * Cp + ch] = s;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < Cse; j += blockDim.x) {
-        float s = b1[j];
-        for (int ch = 0; ch < C; ++ch) s = fmaf(w1[(long)j * C + ch], mean[ch], s);
-        hid[j] = fmaxf(s, 0.0f);
+    for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x)
+        mean[ch] = ((part[ch] + part[Cp + ch]) + (part[2 * Cp + ch] + part[3 * Cp + ch])) * inv_positions;
+    __syncthreads();
+    // fc1 + ReLU: a wave per hidden unit, lanes along the C-long dot product
+    for (int j = wave; j < Cse; j += 4) {
+        float s = 0.0f;
+        for (int ch = lane; ch < C; ch += 64) s = fmaf(w1[(long)j * C + ch], mean[ch], s);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) hid[j] = fmaxf(s + b1[j], 0.0f);
     }
     __syncthreads();
     for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
@@ -501,9 +656,15 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d) {
     return NT * 10 + MT;
 }
 
+extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d) {
+    if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    const DwGeom g = dw_geom(*d);
+    return g.WT ? g.WT * 100 + d->kw * 10 + d->sw : 0;
+}
+
 extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d) {
-    if (!d) return 0;
-    return ceil_div((long)d->To * d->Ho * d->Wo, DW_POS);
+    if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    return dw_geom(*d).blocks;
 }
 
 extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
@@ -522,7 +683,7 @@ extern "C" int pasn_se_gate_fwd(const float* pool_partial, int pool_blocks, int 
                                 const float* w2, const float* b2, float* gate, int N, int C, int Cp, int Cse, void* stream) {
     PASN_REQUIRE(pool_partial && w1 && b1 && w2 && b2 && gate, "null pointer");
     PASN_REQUIRE(N > 0 && C > 0 && Cp >= C && Cse > 0 && pool_blocks > 0 && positions > 0, "bad sizes");
-    const size_t lds = (size_t)(Cp + Cse) * sizeof(float);
+    const size_t lds = (size_t)(5 * Cp + Cse) * sizeof(float);
     hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, pool_partial, pool_blocks,
                        1.0f / (float)positions, w1, b1, w2, b2, gate, C, Cp, Cse);
     return check_launch("se_gate_kernel");

@@ -150,7 +150,12 @@ class PlanBuilder:
         return x.N * min(t, x.T) * min(h, x.H) * min(w, x.W)
 
     def _note(self, kind: str, name: str, nbytes: int, flops: int) -> None:
-        self.meta.append({"kind": kind, "kernel": name, "bytes": int(nbytes), "flops": int(flops)})
+        shape = ""
+        if self.keep and isinstance(self.keep[-1], ConvDesc) or any(isinstance(o, ConvDesc) for o in self.keep[-4:]):
+            d = [o for o in self.keep[-4:] if isinstance(o, ConvDesc)][-1]
+            shape = (f"{d.Cin}->{d.Cout} k{d.kt}{d.kh}{d.kw} s{d.st}{d.sh}{d.sw} "
+                     f"in{d.Ti}x{d.Hi}x{d.Wi} out{d.To}x{d.Ho}x{d.Wo}")
+        self.meta.append({"kind": kind, "kernel": name, "bytes": int(nbytes), "flops": int(flops), "shape": shape})
 
     # ---- ops -------------------------------------------------------------------------------------
     def first_conv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str) -> Act:
@@ -225,7 +230,8 @@ class PlanBuilder:
         xb, yb, pb, dref = x.buf, y.buf, pool_buf, ctypes.byref(d)
         self._use(xb, yb, pb)
         out_pos = y.N * y.positions
-        self._note("dwconv", f"dwconv3d_kernel<{self.tname}>",
+        dv = int(self.lib.pasn_dwconv3d_variant(dref))
+        self._note("dwconv", f"dwconv3d_strip_kernel<{self.tname},{dv // 100},{dv // 10 % 10},{dv % 10}>" if dv else f"dwconv3d_kernel<{self.tname}>",
                    (self._touched(x, y, k, s) + out_pos) * y.C * self.es + (y.N * pool_blocks * y.C * 4 if pool else 0),
                    2 * out_pos * y.C * taps)
         self.ops.append(
