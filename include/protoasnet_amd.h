@@ -84,9 +84,10 @@ int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const
  */
 int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
                     const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream);
-/* Which kernel instance pasn_conv3d_fwd picks for this geometry: NT*10 + MT (output-channel / position tiles per
- * wave, i.e. conv3d_mfma_kernel<dtype, NT, MT>); 0 on a bad descriptor.  For profilers and benchmarks. */
-int pasn_conv3d_variant(const pasn_conv_desc* d);
+/* Which kernel instance pasn_conv3d_fwd picks for this geometry: 1000 + TM = pwconv_kernel<dtype> with TM-row tiles
+ * (1x1x1 stride-1 convs); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT> (output-channel / position tiles
+ * per wave); 0 on a bad descriptor.  For profilers and benchmarks. */
+int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype);
 
 /*
  * Depthwise convolution (groups = C), channels-last, fused scale/bias/activation; optionally also
@@ -100,6 +101,25 @@ int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d);
 int pasn_dwconv3d_variant(const pasn_conv_desc* d);
 int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                       float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream);
+
+/*
+ * Fused front half of an X3D bottleneck: 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 (stride (1,s,s), pad 1)
+ * + BN (+ Swish) (+ squeeze-excite partial sums) in ONE launch; the 2.25x-wide expanded activation lives only in an
+ * LDS ring while a block marches along T.  Same arithmetic as pasn_conv3d_fwd followed by pasn_dwconv3d_fwd (the
+ * expanded activation is rounded to `dtype` in between, exactly as the unfused pair does).
+ *   d      : geometry of the DEPTHWISE conv (kt=kh=kw=3, st=1, sh=sw in {1,2}, pads 1) with Cin/Cin_p = channels of x
+ *            (the block input), Cout/Cout_p = inner (expanded) channels, act = PASN_ACT_NONE | PASN_ACT_SWISH,
+ *            w_kc / w_rows = packing of the expand weight (as for pasn_conv3d_fwd, one tap)
+ *   x      : dtype [N][T][Hi][Wi][Cin_p];  wa : dtype [w_rows][w_kc];  sa, ba : fp32 [w_rows]  (BN after the expand conv)
+ *   wb     : fp32 [27][Cout_p];  sb, bb : fp32 [Cout_p]                                         (depthwise conv + its BN)
+ *   y      : dtype [N][T][Ho][Wo][Cout_p]
+ *   pool_partial : fp32 [N][pool_blocks][Cout_p] or NULL, pool_blocks = pasn_x3d_expand_dw_pool_blocks(d, dtype);
+ *            that query returns 0 when the geometry is not supported (caller then uses the two unfused calls).
+ */
+int pasn_x3d_expand_dw_pool_blocks(const pasn_conv_desc* d, int dtype);
+int pasn_x3d_expand_dw_fwd(const void* x, const void* wa, const float* sa, const float* ba, const float* wb,
+                           const float* sb, const float* bb, void* y, float* pool_partial, const pasn_conv_desc* d,
+                           int dtype, void* stream);
 
 /*
  * Squeeze-excite gate: mean over positions (from the partial sums above, fixed summation order),

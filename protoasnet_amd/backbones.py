@@ -255,13 +255,13 @@ class X3DFeatures(_plan.HipTrunk):
                 sc = x
                 if blk.shortcut is not None:
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
-                y = pb.conv(x, blk.conv_a, blk.bn_a, act="relu")
+                # expand conv + depthwise conv run as one launch: the 2.25x-wide tensor between them never reaches HBM
                 if blk.se is not None:
-                    y, pooled = pb.dwconv(y, blk.conv_b, blk.bn_b, act="none", pool=True)
+                    y, pooled = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act="none", pool=True)
                     gate = pb.se_gate(pooled, blk.se.fc1, blk.se.fc2)
                     x = pb.conv(y, blk.conv_c, blk.bn_c, act="relu", residual=sc, in_gate=gate, in_swish=True)
                 else:  # no gate between BN and Swish: the stencil's epilogue applies Swish once
-                    y = pb.dwconv(y, blk.conv_b, blk.bn_b, act="swish")
+                    y = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act="swish")
                     x = pb.conv(y, blk.conv_c, blk.bn_c, act="relu", residual=sc)
         return x
 

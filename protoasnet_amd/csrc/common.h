@@ -29,6 +29,15 @@ int check_launch(const char* what);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// pointwise-conv kernel (pwconv.hip): row tile, LDS row stride, channel chunk, LDS bytes; TM == 0 -> not applicable
+struct PwGeom {
+    int TM, xrow, co_chunk, lds;
+};
+PwGeom pw_geom(const pasn_conv_desc& d, int dtype);
+template <typename T>
+int launch_pwconv(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
+                  void* y, const pasn_conv_desc& d, const PwGeom& g, hipStream_t s);
+
 // ---- dtype traits: one MFMA "k-chunk" is the 16 bytes a lane feeds to the matrix core ---------------
 template <typename T>
 struct Traits;
@@ -125,7 +134,16 @@ __device__ __forceinline__ void load4(const __bf16* p, float (&v)[4]) {
     for (int j = 0; j < 4; ++j) v[j] = (float)a[j];
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Logical block id for physical workgroup `bid` of an `nwg`-block 1-D grid such that the blocks sharing an XCD
+// (bid % 8, observed round-robin dispatch) form ONE contiguous logical range.  Placement affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// v_exp_f32 + v_rcp_f32 (1 ulp each); an IEEE division here costs ~10 VALU instructions per element
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case PASN_ACT_RELU: return fmaxf(v, 0.0f);
@@ -133,6 +151,41 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case PASN_ACT_SWISH: return v * sigmoidf_(v);
         case PASN_ACT_ABS: return fabsf(v);
         default: return v;
+    }
+}
+
+// Activation of a whole register vector behind ONE wave-uniform switch.  (hipcc does not hoist the per-element
+// switch of apply_act out of unrolled epilogue loops: every element got its own scalar branch ladder.)
+template <int N>
+__device__ __forceinline__ void act_vec(float (&v)[N], int act) {
+    switch (act) {
+        case PASN_ACT_RELU:
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.0f);
+            break;
+        case PASN_ACT_SIGMOID:
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = sigmoidf_(v[j]);
+            break;
+        case PASN_ACT_SWISH:
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+            break;
+        case PASN_ACT_ABS:
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = fabsf(v[j]);
+            break;
+        default:
+            break;
+    }
+}
+// Zero the elements of a channel vector that lie at or beyond the real channel count (`nvalid` = C - first channel).
+template <int N>
+__device__ __forceinline__ void mask_tail(float (&v)[N], int nvalid) {
+    if (nvalid < N) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j >= nvalid) v[j] = 0.0f;
     }
 }
 

@@ -62,10 +62,9 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const TIN* __restrict__
     for (int c = 0; c < COP; c += 8) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float s = acc[c + j] * scale[c + j] + bias[c + j];
-            v[j] = (c + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
-        }
+        for (int j = 0; j < 8; ++j) v[j] = acc[c + j] * scale[c + j] + bias[c + j];
+        act_vec(v, d.act);
+        mask_tail(v, d.Cout - c);
         store8(yp + c, v);
     }
 }
@@ -223,13 +222,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const T* __restrict__ 
                 const int co = co_base + nt * 32 + 8 * g + 4 * h;
                 if (co >= d.Cout_p) continue;
                 float o[4];
-                float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sc[4] = {1.0f, 1.0f, 1.0f, 1.0f}, bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (rp) load4(rp + co, rv);
+                if (scale) load4(scale + co, sc);  // one 16-byte load per quad, not four dword gathers
+                if (bias) load4(bias + co, bs);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float s = acc[nt][mt][4 * g + j] * (scale ? scale[co + j] : 1.0f) + (bias ? bias[co + j] : 0.0f) + rv[j];
-                    o[j] = (co + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
-                }
+                for (int j = 0; j < 4; ++j) o[j] = acc[nt][mt][4 * g + j] * sc[j] + bs[j] + rv[j];
+                act_vec(o, d.act);
+                mask_tail(o, d.Cout - co);
                 store4(yp + co, o);
             }
         }
@@ -337,10 +337,11 @@ __global__ __launch_bounds__(256) void dwconv3d_kernel(const T* __restrict__ x, 
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float s = acc[j] * sc[j] + bs[j];
-                psum[j] += s;
-                o[j] = (cg * 8 + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
+                o[j] = acc[j] * sc[j] + bs[j];
+                psum[j] += o[j];
             }
+            act_vec(o, d.act);
+            mask_tail(o, d.Cout - cg * 8);
             store8(y + ((long)n * S + p) * Cp + cg * 8, o);
         }
     }
@@ -383,9 +384,14 @@ __global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict
     __syncthreads();
 
     const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
-    const int n = blockIdx.y;
+    // XCD-aware block order (speed only): workgroups are dealt round-robin to the 8 XCDs, each with a private L2.
+    // Rows (to, ho) and their (kt, kh) neighbours are read by adjacent blocks, so give every XCD one contiguous
+    // run of logical blocks (whole clips) instead of every 8th block.  Bijective for any grid size.
+    const int bpc = gridDim.x / d.N;  // blocks per clip
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = lb / bpc, bx = lb % bpc;
     const int rows_total = d.To * d.Ho * strips;
-    const int item = blockIdx.x * R + r;
+    const int item = bx * R + r;
     const bool live = item < rows_total;
     float psum[8];
 #pragma unroll
@@ -439,10 +445,11 @@ __global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float s = acc[o][j] * sc[j] + bs[j];
-                psum[j] += s;
-                v[j] = (cg * 8 + j < d.Cout) ? apply_act(s, d.act) : 0.0f;
+                v[j] = acc[o][j] * sc[j] + bs[j];
+                psum[j] += v[j];
             }
+            act_vec(v, d.act);
+            mask_tail(v, d.Cout - cg * 8);
             store8(yrow + (long)wo * Cp, v);
         }
     }
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict
         for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
             float s = 0.0f;
             for (int q = 0; q < R; ++q) s += red[q * Cp + ch];
-            pool[((long)n * gridDim.x + blockIdx.x) * Cp + ch] = s;
+            pool[((long)n * bpc + bx) * Cp + ch] = s;
         }
     }
 }
@@ -503,7 +510,7 @@ static int launch_dwconv3d(const void* x, const float* w, const float* scale, co
         hipLaunchKernelGGL((dwconv3d_kernel<T>), grid, block, lds, s, (const T*)x, w, scale, bias, (T*)y, pool, d);
         return check_launch("dwconv3d_kernel");
     }
-    const dim3 grid(g.blocks, d.N), block(g.CG * g.R);
+    const dim3 grid(g.blocks * d.N), block(g.CG * g.R);
     const size_t lds = (size_t)(taps + g.R) * d.Cout_p * sizeof(float);
     PASN_REQUIRE(lds <= 64 * 1024, "depthwise conv window x channels too large for the LDS weight tile");
 #define PASN_DW(WT_, KW_, SW_)                                                                                       \
@@ -643,14 +650,20 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     PASN_REQUIRE(d->w_kc >= d->Cin_p && d->w_kc % kstep == 0, "w_kc must cover Cin_p and be a multiple of the MFMA k-step");
     PASN_REQUIRE(d->w_rows % 128 == 0 && d->w_rows >= d->Cout_p, "w_rows must be a multiple of 128 covering Cout_p");
     hipStream_t s = (hipStream_t)stream;
+    PASN_REQUIRE(dtype == PASN_F32 || dtype == PASN_BF16, "unknown dtype");
+    const PwGeom pg = pw_geom(*d, dtype);  // 1x1x1 stride-1 convs take the row-streaming kernel
+    if (pg.TM) {
+        if (dtype == PASN_F32) return launch_pwconv<float>(x, w, scale, bias, residual, gate, y, *d, pg, s);
+        return launch_pwconv<__bf16>(x, w, scale, bias, residual, gate, y, *d, pg, s);
+    }
     if (dtype == PASN_F32) return launch_conv3d<float>(x, w, scale, bias, residual, gate, y, *d, s);
-    if (dtype == PASN_BF16) return launch_conv3d<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
-    set_error("pasn_conv3d_fwd: unknown dtype");
-    return PASN_ERR_ARG;
+    return launch_conv3d<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
 }
 
-extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d) {
+extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!conv_desc_ok(d)) return 0;
+    const PwGeom pg = pw_geom(*d, dtype);
+    if (pg.TM) return 1000 + pg.TM;
     int NT, MT;
     conv_variant(*d, NT, MT);
     return NT * 10 + MT;

@@ -197,9 +197,10 @@ class PlanBuilder:
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, rb, gb, dref = x.buf, y.buf, (residual.buf if residual is not None else None), in_gate, ctypes.byref(d)
         self._use(xb, yb, rb, gb)
-        variant = int(self.lib.pasn_conv3d_variant(dref))
+        variant = int(self.lib.pasn_conv3d_variant(dref, self.code))
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
+        self._note("conv", f"pwconv_kernel<{self.tname}>" if variant >= 1000 else
+                   f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
                    (self._touched(x, y, k, s) * x.C + out_pos * y.C * (2 if residual is not None else 1)
                     + y.C * x.C * taps) * self.es + (x.N * x.C * 4 if in_gate is not None else 0),
                    2 * out_pos * y.C * x.C * taps)
@@ -236,6 +237,50 @@ class PlanBuilder:
                    2 * out_pos * y.C * taps)
         self.ops.append(
             lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], ptrs[pb] if pb is not None else 0, dref, code, st))
+        )
+        if pool:
+            return y, (pool_buf, pool_blocks, y)
+        return y
+
+    def expand_dw(self, x: Act, conv_a: nn.Module, norm_a: nn.Module, conv_b: nn.Module, norm_b: nn.Module, act: str,
+                  pool: bool = False):
+        """X3D front half (1x1x1 expand + BN + ReLU -> depthwise 3x3x3 + BN [+Swish] [+SE partial sums]) as ONE launch;
+        falls back to the two unfused launches when the fused kernel does not cover the geometry."""
+        k, s, p = _triple(conv_b.kernel_size, 1), _triple(conv_b.stride, 1), _triple(conv_b.padding, 0)
+        ci = conv_a.out_channels
+        assert conv_b.groups == ci == conv_b.in_channels and _triple(conv_a.kernel_size, 1) == (1, 1, 1)
+        mid = Act(x.N, x.T, x.H, x.W, ci, round_up(ci, 8), -1)
+        y = self._out_act(mid, ci, k, s, p)
+        wa, kc, rows = pack_conv_weight(conv_a.weight, x.Cp, self.dtype)
+        d = ConvDesc(
+            N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=x.C, Cin_p=x.Cp, To=y.T, Ho=y.H, Wo=y.W, Cout=ci, Cout_p=y.Cp,
+            kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
+            act=_lib.ACT[act], in_swish=0, w_kc=kc, w_rows=rows,
+        )
+        dref = ctypes.byref(d)
+        pool_blocks = int(self.lib.pasn_x3d_expand_dw_pool_blocks(dref, self.code))
+        if pool_blocks == 0:  # geometry outside the fused kernel: the buffer made for y is simply never used
+            self.bufs[y.buf].nbytes = ALIGN
+            e = self.conv(x, conv_a, norm_a, act="relu")
+            return self.dwconv(e, conv_b, norm_b, act=act, pool=pool)
+        sa, ba = fold_norm(norm_a, conv_a.bias, ci, rows, self.device)
+        taps = k[0] * k[1] * k[2]
+        wb = torch.zeros(taps, y.Cp, dtype=torch.float32, device=self.device)
+        wb[:, :ci] = conv_b.weight.detach().float().reshape(ci, taps).t()
+        sb, bb = fold_norm(norm_b, conv_b.bias, ci, y.Cp, self.device)
+        self.keep += [wa, sa, ba, wb, sb, bb, d]
+        pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4) if pool else None
+        fn, code = self.lib.pasn_x3d_expand_dw_fwd, self.code
+        a = tuple(t.data_ptr() for t in (wa, sa, ba, wb, sb, bb))
+        xb, yb, pb = x.buf, y.buf, pool_buf
+        self._use(xb, yb, pb)
+        out_pos = y.N * y.positions
+        self._note("expand_dw", f"x3d_expand_dw_kernel<{self.tname},{s[1]}>",
+                   (x.N * x.positions * x.C + out_pos * ci + ci * x.C) * self.es + (y.N * pool_blocks * ci * 4 if pool else 0),
+                   2 * x.N * x.positions * ci * x.C + 2 * out_pos * ci * taps)
+        self.ops.append(
+            lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], a[4], a[5], ptrs[yb],
+                                           ptrs[pb] if pb is not None else 0, dref, code, st))
         )
         if pool:
             return y, (pool_buf, pool_blocks, y)

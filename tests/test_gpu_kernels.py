@@ -240,6 +240,77 @@ def test_dwconv3d_and_se(case, dtype):
     assert_close(gate[:, :c], gref, 1e-3 if dtype == torch.float32 else 1e-2, 0, "SE gate")
 
 
+FUSED_CASES = [
+    # cin, inner, stride, (T,H,W), act, pool
+    (24, 54, 1, (5, 13, 30), "swish", False),   # stage-2 style, W > tile width (2 W tiles), ragged H
+    (24, 54, 2, (3, 18, 20), "none", True),     # stride 2 + SE partial sums
+    (48, 108, 1, (4, 9, 9), "none", True),      # two 32-channel MFMA tiles + tail
+    (96, 216, 1, (3, 14, 14), "swish", False),  # channel-chunked (216 inner channels)
+    (192, 432, 1, (2, 7, 7), "none", True),     # widest stage, many chunks, T = 2 (prologue-only ring)
+    (96, 432, 2, (1, 14, 14), "swish", False),  # T = 1
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_x3d_expand_dw_fused(case, dtype, monkeypatch):
+    """Fused expand(1x1x1)+BN+ReLU -> depthwise 3x3x3+BN(+Swish)(+SE sums) == the two unfused torch ops."""
+    monkeypatch.setenv("PASN_FUSED", "1")  # the fused launch is opt-in (profiles/README.md); this test always exercises it
+    cin, ci, s, thw, act, pool = case
+    torch.manual_seed(13)
+    n = 2
+    x = torch.randn(n, cin, *thw)
+    conv_a = nn.Conv3d(cin, ci, 1, bias=False)
+    conv_b = nn.Conv3d(ci, ci, 3, (1, s, s), 1, groups=ci, bias=False)
+    bn_a, bn_b = nn.BatchNorm3d(ci), nn.BatchNorm3d(ci)
+    with torch.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.5, 1.5)
+    bn_a.eval(), bn_b.eval()
+    ca = nn.Conv3d(cin, ci, 1, bias=False)
+    ca.weight.data = _rt(conv_a.weight.data, dtype)
+    e = _rt(F.relu(bn_a(ca(_rt(x, dtype)))), dtype)  # the expanded activation is held in the compute dtype
+    pre = bn_b(conv_b(e)).detach()
+    ref = pre * torch.sigmoid(pre) if act == "swish" else pre
+
+    from protoasnet_amd import _lib
+    from protoasnet_amd.backbones import _SE
+
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    mods = [m.to(DEV) for m in (conv_a, bn_a, conv_b, bn_b)]
+    atol, rtol = _tols(dtype)
+    if not pool:
+        y = pb.expand_dw(xa, *mods, act=act)
+        assert pb.meta[-1]["kind"] == "expand_dw", "the fused kernel must cover this geometry"
+        out = _run_single(pb, xa, y, xs)
+        assert_close(_from_cl(out, ci), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"fused {case}")
+        if out.shape[-1] > ci:
+            assert float(out[..., ci:].float().abs().max()) == 0.0
+        return
+    se = _SE(ci)
+    with torch.no_grad():
+        for q in se.parameters():
+            q.normal_(0, 0.2)
+    y, pooled = pb.expand_dw(xa, *mods, act=act, pool=True)
+    assert pb.meta[-1]["kind"] == "expand_dw"
+    gate_buf = pb.se_gate(pooled, se.fc1.to(DEV), se.fc2.to(DEV))
+    pb.bufs[gate_buf].external = True
+    plan = pb.finish(xa, y)
+    gate = torch.empty(n, y.Cp, dtype=torch.float32, device=DEV)
+    plan.ptrs[gate_buf] = gate.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    assert_close(_from_cl(out, ci), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"fused {case}")
+    se = se.cpu()
+    gm = pre.mean(dim=(2, 3, 4), keepdim=True)
+    gref = torch.sigmoid(se.fc2(F.relu(se.fc1(gm)))).reshape(n, ci).detach()
+    assert_close(gate[:, :ci], gref, 1e-3 if dtype == torch.float32 else 1e-2, 0, "SE gate from fused partial sums")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool(dtype):
     torch.manual_seed(9)
