@@ -84,9 +84,9 @@ int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const
  */
 int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
                     const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream);
-/* Which kernel instance pasn_conv3d_fwd picks for this geometry: 1000 + TM = pwconv_kernel<dtype> with TM-row tiles
- * (1x1x1 stride-1 convs); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT> (output-channel / position tiles
- * per wave); 0 on a bad descriptor.  For profilers and benchmarks. */
+/* Which kernel instance pasn_conv3d_fwd picks for this geometry: 1000 + KS*10 + NT = pwconv_persist_kernel<dtype, KS, NT>
+ * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT>
+ * (output-channel / position tiles per wave); 0 on a bad descriptor.  For profilers and benchmarks. */
 int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype);
 
 /*

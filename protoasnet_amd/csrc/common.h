@@ -134,6 +134,24 @@ __device__ __forceinline__ void load4(const __bf16* p, float (&v)[4]) {
     for (int j = 0; j < 4; ++j) v[j] = (float)a[j];
 }
 
+// 8 channels held as raw 16-byte words (register prefetch buffers) -> fp32.  bf16 -> fp32 is a 16-bit shift / mask.
+template <typename T>
+__device__ __forceinline__ void raw_to_f8(const uint4 (&r)[(8 * sizeof(T)) / 16], float (&v)[8]);
+template <>
+__device__ __forceinline__ void raw_to_f8<__bf16>(const uint4 (&r)[1], float (&v)[8]) {
+    const unsigned w[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <>
+__device__ __forceinline__ void raw_to_f8<float>(const uint4 (&r)[2], float (&v)[8]) {
+    v[0] = __uint_as_float(r[0].x); v[1] = __uint_as_float(r[0].y); v[2] = __uint_as_float(r[0].z); v[3] = __uint_as_float(r[0].w);
+    v[4] = __uint_as_float(r[1].x); v[5] = __uint_as_float(r[1].y); v[6] = __uint_as_float(r[1].z); v[7] = __uint_as_float(r[1].w);
+}
+
 // Logical block id for physical workgroup `bid` of an `nwg`-block 1-D grid such that the blocks sharing an XCD
 // (bid % 8, observed round-robin dispatch) form ONE contiguous logical range.  Placement affects speed only.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

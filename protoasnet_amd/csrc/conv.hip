@@ -407,22 +407,39 @@ __global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict
         for (int o = 0; o < WT; ++o)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[o][j] = 0.0f;
-        for (int a = 0; a < d.kt; ++a) {
-            const int ti = to * d.st - d.pt + a;
-            if (ti < 0 || ti >= d.Ti) continue;
-            for (int b = 0; b < d.kh; ++b) {
-                const int hi = ho * d.sh - d.ph + b;
-                if (hi < 0 || hi >= d.Hi) continue;
+        // One "step" = one (kt, kh) input row of the window.  The row of step s+1 is requested (raw 16-byte words,
+        // zeros where the window leaves the image) BEFORE the row of step s is converted and consumed, so a wave
+        // always has a full row of loads in flight under its FMAs instead of 9 dependent load->wait->compute rounds.
+        constexpr int NV = (8 * sizeof(T)) / 16;
+        uint4 cur[NC][NV], nxt[NC][NV];
+        bool curv = false, nxtv = false;
+        auto fetch = [&](int step, uint4 (&buf)[NC][NV]) -> bool {
+            const int a = step / d.kh, b = step - a * d.kh;
+            const int ti = to * d.st - d.pt + a, hi = ho * d.sh - d.ph + b;
+            if (ti < 0 || ti >= d.Ti || hi < 0 || hi >= d.Hi) return false;
+            const T* xrow = x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi) * d.Cin_p + cg * 8;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int wi = wi0 + c;
+                const bool ok = wi >= 0 && wi < d.Wi;
+                const uint4* src = reinterpret_cast<const uint4*>(xrow + (long)(ok ? wi : 0) * d.Cin_p);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) buf[c][q] = ok ? src[q] : make_uint4(0, 0, 0, 0);
+            }
+            return true;
+        };
+        const int nsteps = d.kt * d.kh;
+        curv = fetch(0, cur);
+        for (int step = 0; step < nsteps; ++step) {
+            if (step + 1 < nsteps) nxtv = fetch(step + 1, nxt);
+            if (curv) {
                 float wv[KW][8];
 #pragma unroll
-                for (int e = 0; e < KW; ++e) load8(wl + ((a * d.kh + b) * KW + e) * Cp + cg * 8, wv[e]);
-                const T* xrow = x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi) * d.Cin_p + cg * 8;
+                for (int e = 0; e < KW; ++e) load8(wl + (step * KW + e) * Cp + cg * 8, wv[e]);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const int wi = wi0 + c;
-                    if (wi < 0 || wi >= d.Wi) continue;
                     float xv[8];
-                    load8(xrow + (long)wi * d.Cin_p, xv);
+                    raw_to_f8<T>(cur[c], xv);
 #pragma unroll
                     for (int e = 0; e < KW; ++e) {
                         if ((c - e) >= 0 && (c - e) % SW == 0 && (c - e) / SW < WT) {  // resolved at compile time
@@ -433,6 +450,11 @@ __global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict
                     }
                 }
             }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < NV; ++q) cur[c][q] = nxt[c][q];
+            curv = nxtv;
         }
         float sc[8], bs[8];
         load8(scale + cg * 8, sc);
@@ -481,7 +503,9 @@ static DwGeom dw_geom(const pasn_conv_desc& d) {
     DwGeom g = {0, d.Cout_p / 8, 0, 0, 0};
     const bool special = (d.kw == 3 && (d.sw == 1 || d.sw == 2)) || (d.kw == 1 && d.sw == 1);
     if (special && g.CG <= 256) {
-        g.WT = (d.Wo % 7 == 0) ? 7 : 8;
+        // stride 2 touches 2*WT+1 columns per row: WT = 4 keeps the double-buffered row (prefetch) within the register
+        // budget (measured 370 vs 450 us on the 54-channel 112^2 layer); stride 1 prefers long strips (fewer reloads)
+        g.WT = d.sw == 2 ? 4 : (d.Wo % 7 == 0) ? 7 : 8;
         if (const char* e = getenv("PASN_DW_WT")) {  // tuning knob: 4, 7 or 8
             const int v = atoi(e);
             if (v == 4 || v == 7 || v == 8) g.WT = v;
@@ -551,7 +575,16 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     for (int ch = lane; ch < Cp; ch += 64) {
         float s = 0.0f;
         const float* pp = pool + (long)n * pool_blocks * Cp + ch;
-        for (int q = wave; q < pool_blocks; q += 4) s += pp[(long)q * Cp];
+        // 8 independent partial sums: 8 loads in flight per lane instead of one dependent chain (this tiny kernel is
+        // pure latency: ~44 sequential L2 round trips per lane cost 27 us per launch); the order stays fixed
+        float p8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int q = wave;
+        for (; q + 28 < pool_blocks; q += 32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p8[k] += pp[(long)(q + 4 * k) * Cp];
+        }
+        for (int k = 0; q < pool_blocks; q += 4, ++k) p8[k] += pp[(long)q * Cp];
+        s = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
         part[wave * Cp + ch] = s;
     }
     __syncthreads();
@@ -663,7 +696,7 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
 extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!conv_desc_ok(d)) return 0;
     const PwGeom pg = pw_geom(*d, dtype);
-    if (pg.TM) return 1000 + pg.TM;
+    if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
     int NT, MT;
     conv_variant(*d, NT, MT);
     return NT * 10 + MT;
