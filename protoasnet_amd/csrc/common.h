@@ -38,6 +38,12 @@ template <typename T>
 int launch_pwconv(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                   void* y, const pasn_conv_desc& d, const PwGeom& g, hipStream_t s);
 
+// LDS-tiled MFMA GEMM for large-K pointwise convs (gemm_pw.hip)
+bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype);
+template <typename T>
+int launch_gemm_pw(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
+                   void* y, const pasn_conv_desc& d, hipStream_t s);
+
 // ---- dtype traits: one MFMA "k-chunk" is the 16 bytes a lane feeds to the matrix core ---------------
 template <typename T>
 struct Traits;

@@ -391,12 +391,16 @@ __global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int n = lb / bpc, bx = lb % bpc;
     const int rows_total = d.To * d.Ho * strips;
-    const int item = bx * R + r;
-    const bool live = item < rows_total;
     float psum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) psum[j] = 0.0f;
-    if (live) {
+    // Persistent per clip: a block stages the window weights (up to 46 KB) ONCE and walks chunks of R row strips
+    // (chunk += blocks per clip), so neighbouring chunks (shared input rows) run on neighbouring blocks of one XCD and the
+    // squeeze-excite partial sums shrink to one row per block (<= 32 per clip instead of one per chunk).
+    const int nchunks = (rows_total + R - 1) / R;
+    for (int chunk = bx; chunk < nchunks; chunk += bpc) {
+        const int item = chunk * R + r;
+        if (item >= rows_total) continue;
         const int strip = item % strips;
         const int ho = (item / strips) % d.Ho;
         const int to = item / (strips * d.Ho);
@@ -512,7 +516,8 @@ static DwGeom dw_geom(const pasn_conv_desc& d) {
         }
         g.R = 256 / g.CG;
         g.strips = ceil_div(d.Wo, g.WT);
-        g.blocks = ceil_div((long)d.To * d.Ho * g.strips, g.R);
+        const int nchunks = ceil_div((long)d.To * d.Ho * g.strips, g.R);
+        g.blocks = nchunks < 32 ? nchunks : 32;  // blocks per clip (persistent over the chunks); also the SE partial count
     } else {
         g.blocks = ceil_div((long)d.To * d.Ho * d.Wo, DW_POS);
     }
@@ -689,6 +694,10 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
         if (dtype == PASN_F32) return launch_pwconv<float>(x, w, scale, bias, residual, gate, y, *d, pg, s);
         return launch_pwconv<__bf16>(x, w, scale, bias, residual, gate, y, *d, pg, s);
     }
+    if (gemm_pw_applicable(*d, dtype)) {  // large K / N pointwise: LDS-tiled GEMM
+        if (dtype == PASN_F32) return launch_gemm_pw<float>(x, w, scale, bias, residual, gate, y, *d, s);
+        return launch_gemm_pw<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
+    }
     if (dtype == PASN_F32) return launch_conv3d<float>(x, w, scale, bias, residual, gate, y, *d, s);
     return launch_conv3d<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
 }
@@ -697,6 +706,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!conv_desc_ok(d)) return 0;
     const PwGeom pg = pw_geom(*d, dtype);
     if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
+    if (gemm_pw_applicable(*d, dtype)) return 2000;   // gemm_pw_kernel<dtype>
     int NT, MT;
     conv_variant(*d, NT, MT);
     return NT * 10 + MT;
