@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--prototypes", type=int, default=30)
     ap.add_argument("--classes", type=int, default=3)
-    ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-clips", type=int, default=96, help="max clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU-baseline sample after this much CPU work")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--per-op", default="", help="write a per-launch timing table to this file")
     return ap.parse_args()
@@ -54,12 +55,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU under the driver; the modulo only serves rehearsals
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") over xGMI on a real node.  PASN_BENCH_BACKEND=gloo rehearses the N > 1 code path with several
+        # ranks on ONE GPU (RCCL refuses two ranks on the same device); the data path has no collective either way.
+        backend = os.environ.get("PASN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from protoasnet_amd import model_builder, synth
 
@@ -128,7 +136,7 @@ def main():
     elapsed = time.perf_counter() - t0
     trunk._timers = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     logits = out[0]
@@ -160,9 +168,18 @@ def main():
         avg_bytes = sum(plan.meta[i]["bytes"] for i in idx) / len(idx)
         avg_flops = sum(plan.meta[i]["flops"] for i in idx) / len(idx)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected in
+        # their own runs by tools/pmc_traffic.py -- a profiler cannot run inside this process
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(dominant, {}).get("traffic_bytes_per_launch")
+            except (ValueError, OSError):
+                traffic = None
         result["roofline"] = {
             "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": len(idx),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": len(idx),
             "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
             "mfma_tflops": round(avg_flops / (avg_ms * 1e-3) / 1e12, 2),
         }
@@ -181,19 +198,27 @@ def main():
         # oversubscribes the share and runs ~10x slower), so the baseline uses at most 16 threads and says so
         cores = min(len(os.sched_getaffinity(0)), 16)
         torch.set_num_threads(cores)
-        xs = x_cpu[: args.cpu_clips].float()
+        # bounded sample: the batch's clips re-used round robin, 8 at a time (bounds the broadcast-product intermediate),
+        # until ~args.cpu_seconds of CPU work or args.cpu_clips clips are done
+        chunk, done, sims = 8, 0, []
         with torch.no_grad():
-            oracle.nets.xprotonet_forward(cpu_state, xs[:1], arch=args.arch)  # warm-up
+            oracle.nets.xprotonet_forward(cpu_state, x_cpu[:1].float(), arch=args.arch)  # warm-up
             t0 = time.perf_counter()
-            ref = oracle.nets.xprotonet_forward(cpu_state, xs, arch=args.arch)
+            while done < args.cpu_clips and (time.perf_counter() - t0) < args.cpu_seconds:
+                lo = done % args.batch
+                xs = x_cpu[lo: lo + min(chunk, args.batch - lo)].float()
+                ref = oracle.nets.xprotonet_forward(cpu_state, xs, arch=args.arch)
+                if done < args.batch:
+                    sims.append((lo, ref["similarity"]))
+                done += xs.shape[0]
             dt = time.perf_counter() - t0
         result["cpu_baseline"] = {
-            "value": round(args.cpu_clips / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_clips} clips of 3x{args.frames}x{args.size}x{args.size}, fp32 torch oracle "
-                      f"(reference op sequence incl. broadcast-product pooling), {dt:.1f} s",
+            "value": round(done / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{done} clips of 3x{args.frames}x{args.size}x{args.size} in chunks of {chunk}, fp32 torch oracle "
+                      f"(reference op sequence incl. broadcast-product pooling), {dt:.1f} s of CPU work",
         }
         # the same clips through the HIP path must agree with what the CPU computed (bf16 tolerance)
-        err = float((out[1][: args.cpu_clips].float().cpu() - ref["similarity"]).abs().max())
+        err = max(float((out[1][lo: lo + s.shape[0]].float().cpu() - s).abs().max()) for lo, s in sims)
         result["cpu_baseline"]["max_abs_similarity_diff_vs_gpu"] = round(err, 5)
     print(json.dumps(result))
     if world > 1:
