@@ -417,18 +417,37 @@ __global__ __launch_bounds__(256) void dwconv3d_strip_kernel(const T* __restrict
         constexpr int NV = (8 * sizeof(T)) / 16;
         uint4 cur[NC][NV], nxt[NC][NV];
         bool curv = false, nxtv = false;
+        // at most the first / last column of a strip can leave the image: pad <= 1, no ragged strip, <= 1 column overhang
+        const bool edge1 = d.pw <= 1 && d.Wo % WT == 0 && ((d.Wo - 1) * SW + KW - 1 - d.pw - (d.Wi - 1)) <= 1;
         auto fetch = [&](int step, uint4 (&buf)[NC][NV]) -> bool {
             const int a = step / d.kh, b = step - a * d.kh;
             const int ti = to * d.st - d.pt + a, hi = ho * d.sh - d.ph + b;
             if (ti < 0 || ti >= d.Ti || hi < 0 || hi >= d.Hi) return false;
             const T* xrow = x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi) * d.Cin_p + cg * 8;
+            // Loads are UNCONDITIONAL (address clamped into the row) and columns outside the image are zeroed with
+            // selects afterwards: `ok ? load : 0` made hipcc wrap every column in its own exec-masked branch, which
+            // serialised the 9-17 loads of a row.  With `edge1` (pad <= 1 and no ragged last strip) only the first and
+            // the last column of a strip can leave the image, so the interior columns carry no select at all.
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int wi = wi0 + c;
-                const bool ok = wi >= 0 && wi < d.Wi;
-                const uint4* src = reinterpret_cast<const uint4*>(xrow + (long)(ok ? wi : 0) * d.Cin_p);
+                const int wc = min(max(wi, 0), d.Wi - 1);
+                const uint4* src = reinterpret_cast<const uint4*>(xrow + (long)wc * d.Cin_p);
 #pragma unroll
-                for (int q = 0; q < NV; ++q) buf[c][q] = ok ? src[q] : make_uint4(0, 0, 0, 0);
+                for (int q = 0; q < NV; ++q) buf[c][q] = src[q];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (edge1 && c != 0 && c != NC - 1) continue;
+                const int wi = wi0 + c;
+                const bool ok = wi >= 0 && wi < d.Wi;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    buf[c][q].x = ok ? buf[c][q].x : 0u;
+                    buf[c][q].y = ok ? buf[c][q].y : 0u;
+                    buf[c][q].z = ok ? buf[c][q].z : 0u;
+                    buf[c][q].w = ok ? buf[c][q].w : 0u;
+                }
             }
             return true;
         };
