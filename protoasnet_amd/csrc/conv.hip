@@ -725,7 +725,8 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!conv_desc_ok(d)) return 0;
     const PwGeom pg = pw_geom(*d, dtype);
     if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
-    if (gemm_pw_applicable(*d, dtype)) return 2000;   // gemm_pw_kernel<dtype>
+    if (gemm_pw_applicable(*d, dtype))                // gemm_conv_kernel<dtype, pointwise?>
+        return 2000 + ((d->kt * d->kh * d->kw == 1 && d->st * d->sh * d->sw == 1) ? 0 : 1);
     int NT, MT;
     conv_variant(*d, NT, MT);
     return NT * 10 + MT;

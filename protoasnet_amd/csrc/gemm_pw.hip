@@ -1,33 +1,37 @@
-// Pointwise (1x1x1, stride 1) convolution with LARGE K / N (X3D stages 4-5, head B's five convs): a classic LDS-tiled
-// MFMA GEMM   Y[m][n] = act(scale[n] * sum_k X'[m][k] W[n][k] + bias[n] [+ R[m][n]])   with a fused epilogue.
+// Dense convolution as an LDS-tiled implicit GEMM on MFMA with a fused epilogue:
+//     Y[m][n] = act(scale[n] * sum_{tap,ci} X'[in(m,tap)][ci] * W[n][tap][ci] + bias[n] [+ R[m][n]])
+// m = output position (n,t,h,w flattened), K = taps x (per-tap padded) input channels.
+// Used for (a) pointwise convs with large K / N (X3D stages 4-5, head B) -- compile-time fast path PW = true -- and
+// (b) every windowed dense conv of the R(2+1)D-18 and ResNet-18 trunks ((1,3,3), (3,1,1), 3x3, strided 1x1).
 //
-// The small-K kernel (pwconv.hip) keeps the whole weight matrix in registers; here K*N is up to 432x432, so the reuse
-// has to come from a block tile: BM = 128 rows x BN = 128 output channels, K walked in BK = 32 slices through
-// double-buffered LDS.  Per slice every thread requests its two 16-byte pieces of the X and W tiles for slice s+1
-// BEFORE the MFMAs of slice s (register staging, write after the barrier), so global latency hides under the matrix
-// work.  4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA 32x32 tiles; A operand = weights (row = channel), B operand =
-// activations (column = position), so the accumulator has the position on the lane and 4 consecutive channels per
-// quad.  Epilogue: scale/bias in fp32 -> block LDS image [128 rows][128 ch] -> whole-row 16-byte-per-lane residual read
-// + activation + store (fully coalesced; the accumulator layout alone would give 8-byte stores at an 864-byte stride).
-// LDS rows are padded to an odd number of 16-byte slots: conflict-free ds_read_b128 fragment reads.
+// The small-K pointwise kernel (pwconv.hip) keeps the whole weight matrix in registers; here the reuse comes from a block
+// tile: BM = 128 positions x BN = 128 output channels, K walked in BK = 32 slices through double-buffered LDS.  Per
+// slice every thread requests its 16-byte pieces of the X and W tiles for slice s+1 BEFORE the MFMAs of slice s (register
+// staging, LDS write after the barrier), so global latency hides under the matrix work.  A 16-byte piece = 8 (bf16) /
+// 4 (fp32) consecutive input channels of ONE tap (channel strides are multiples of 8), so the im2col gather is a plain
+// vector load from the tap's neighbour position, or zeros outside the image / in the channel padding.
+// 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA 32x32 tiles; A operand = weights (row = channel), B operand = activations
+// (column = position): the accumulator has the position on the lane and 4 consecutive channels per quad.
+// Epilogue: scale/bias in fp32 -> block LDS image [128 rows][128 ch] -> whole-row 16-byte-per-lane residual read +
+// activation + store (fully coalesced).  LDS rows are padded to an odd number of 16-byte slots (conflict-free b128 reads).
 #include "common.h"
 
 namespace pasn {
 
 constexpr int G_BM = 128, G_BN = 128, G_BK = 32;
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_pw_kernel(const T* __restrict__ x, const T* __restrict__ w,
-                                                      const float* __restrict__ scale, const float* __restrict__ bias,
-                                                      const T* __restrict__ res, const float* __restrict__ gate,
-                                                      T* __restrict__ y, long M, int S, int Cin_p, int Cout, int Cout_p,
-                                                      int w_kc, int act, int in_swish) {
+template <typename T, bool PW>
+__global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ bias,
+                                                        const T* __restrict__ res, const float* __restrict__ gate,
+                                                        T* __restrict__ y, pasn_conv_desc d) {
     using frag = typename Traits<T>::frag;
     constexpr int CH = Traits<T>::CH;            // elements per 16-byte piece
     constexpr int KSTEP = Traits<T>::KSTEP;
-    constexpr int ROW = G_BK + CH;               // padded LDS row (elements): G_BK*es/16 slots (even) + 1
+    constexpr int ROW = G_BK + CH;               // padded LDS row (elements)
     constexpr int PIECES = G_BK / CH;            // 16-byte pieces per tile row
     constexpr int PPT = G_BM * PIECES / 256;     // pieces per thread per tile (2 for bf16, 4 for fp32)
+    constexpr int RSTEP = 256 / PIECES;          // tile rows between a thread's consecutive pieces
     constexpr int OROW = G_BN + CH;              // output image row (elements)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);                      // [2][G_BM][ROW]
@@ -35,42 +39,93 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(const T* __restrict__ x, c
     T* os = reinterpret_cast<T*>(smem);                      // [G_BM][OROW]  (aliases the tiles after the K loop)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;                 // wave's 64-row / 64-channel quadrant
+    const int wm = wave & 1, wn = wave >> 1;                 // wave's 64-position / 64-channel quadrant
+    const long M = (long)d.N * d.To * d.Ho * d.Wo;
+    const int S = d.To * d.Ho * d.Wo;
     const long m0 = (long)blockIdx.x * G_BM;
     const int n0 = blockIdx.y * G_BN;
-    const bool xform = (gate != nullptr) || (in_swish != 0);
-    const int nk = (w_kc + G_BK - 1) / G_BK;
+    const int Cin_p = d.Cin_p, Cout_p = d.Cout_p, kc = d.w_kc;
+    const int taps = d.kt * d.kh * d.kw;
+    const int Ktot = taps * kc;
+    const int nk = (Ktot + G_BK - 1) / G_BK;
+    const bool xform = (gate != nullptr) || (d.in_swish != 0);
+
+    // this thread's tile rows (fixed over the K loop): row = prow0 + i * RSTEP, piece column pc
+    const int pc = tid % PIECES, prow0 = tid / PIECES;
+    long rm[PPT];
+    int rn[PPT], rt[PPT], rh[PPT], rw[PPT];
+    bool rv[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        rm[i] = m0 + prow0 + i * RSTEP;
+        rv[i] = rm[i] < M;
+        if (!PW) {
+            const long mm = rv[i] ? rm[i] : 0;
+            rw[i] = (int)(mm % d.Wo);
+            long r = mm / d.Wo;
+            rh[i] = (int)(r % d.Ho);
+            r /= d.Ho;
+            rt[i] = (int)(r % d.To);
+            rn[i] = (int)(r / d.To);
+        }
+    }
 
     uint4 xr[PPT], wr[PPT];
     auto fetch = [&](int kt) {  // global -> registers for K slice kt
+        const int k = kt * G_BK + pc * CH;          // flattened K index of this thread's piece
+        int tap = 0, ci = k;
+        if (!PW) {
+            tap = k / kc;
+            ci = k - tap * kc;
+        }
+        const bool kvalid = k < Ktot && ci < Cin_p;
+        int da = 0, db = 0, de = 0;
+        if (!PW) {
+            da = tap / (d.kh * d.kw);
+            const int r2 = tap - da * d.kh * d.kw;
+            db = r2 / d.kw;
+            de = r2 - db * d.kw;
+        }
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const int p = tid + i * 256;
-            const int row = p / PIECES, pc = p - row * PIECES;
-            const int k = kt * G_BK + pc * CH;
-            const long m = m0 + row;
-            xr[i] = (m < M && k < Cin_p) ? *reinterpret_cast<const uint4*>(x + m * Cin_p + k) : make_uint4(0, 0, 0, 0);
+            const int row = prow0 + i * RSTEP;
+            bool ok = rv[i] && kvalid;
+            long off;
+            if (PW) {
+                off = rm[i] * Cin_p + ci;
+            } else {
+                const int ti = rt[i] * d.st - d.pt + da, hi = rh[i] * d.sh - d.ph + db, wi = rw[i] * d.sw - d.pw + de;
+                ok = ok && ti >= 0 && ti < d.Ti && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
+                off = ((((long)rn[i] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * Cin_p + ci;
+            }
+            const uint4 v = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));  // unconditional load, select after
+            xr[i].x = ok ? v.x : 0u;
+            xr[i].y = ok ? v.y : 0u;
+            xr[i].z = ok ? v.z : 0u;
+            xr[i].w = ok ? v.w : 0u;
             const int n = n0 + row;  // weight rows are zero padded to a multiple of 128
-            wr[i] = (k < w_kc) ? *reinterpret_cast<const uint4*>(w + (long)n * w_kc + k) : make_uint4(0, 0, 0, 0);
+            const uint4 wv = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
+            wr[i].x = k < Ktot ? wv.x : 0u;
+            wr[i].y = k < Ktot ? wv.y : 0u;
+            wr[i].z = k < Ktot ? wv.z : 0u;
+            wr[i].w = k < Ktot ? wv.w : 0u;
         }
     };
     auto stash = [&](int kt, int buf) {  // registers -> LDS (applying the fused input transform to X once)
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const int p = tid + i * 256;
-            const int row = p / PIECES, pc = p - row * PIECES;
+            const int row = prow0 + i * RSTEP;
             uint4 xv = xr[i];
-            if (xform) {
+            if (PW && xform) {
                 const int k = kt * G_BK + pc * CH;
-                const long m = m0 + row;
-                if (m < M && k < Cin_p) {
+                if (rv[i] && k < Cin_p) {
                     T* e = reinterpret_cast<T*>(&xv);
-                    const float* gp = gate ? gate + (m / S) * Cin_p + k : nullptr;
+                    const float* gp = gate ? gate + (rm[i] / S) * Cin_p + k : nullptr;
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
                         float v = (float)e[j];
                         if (gp) v *= gp[j];
-                        if (in_swish) v = v * sigmoidf_(v);
+                        if (d.in_swish) v = v * sigmoidf_(v);
                         e[j] = (T)v;
                     }
                 }
@@ -80,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(const T* __restrict__ x, c
         }
     };
 
-    f32x16 acc[2][2];  // [channel tile][row tile]
+    f32x16 acc[2][2];  // [channel tile][position tile]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -146,21 +201,25 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(const T* __restrict__ x, c
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] += r[q];
             }
-            act_vec(v, act);
-            mask_tail(v, Cout - n);
+            act_vec(v, d.act);
+            mask_tail(v, d.Cout - n);
             store8(y + m * Cout_p + n, v);
         }
     }
 }
 
+static bool is_pointwise(const pasn_conv_desc& d) {
+    return d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
+}
+
 bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype) {
-    const bool pointwise = d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 &&
-                           d.ph == 0 && d.pw == 0;
-    if (!pointwise) return false;
     if (const char* e = getenv("PASN_NO_GEMM"))
         if (e[0] == '1') return false;
     (void)dtype;
-    return d.w_rows % G_BN == 0 && d.Cin_p >= 64;  // below that the register-resident kernel (pwconv.hip) wins
+    if (d.w_rows % G_BN != 0 || d.w_kc % 8 != 0) return false;
+    if (is_pointwise(d)) return d.Cin_p >= 64;  // below that the register-resident kernel (pwconv.hip) wins
+    if (d.in_swish) return false;               // the fused input transform exists on the pointwise paths only
+    return d.Cin_p * d.kt * d.kh * d.kw >= 64;  // windowed dense convs with a real K
 }
 
 template <typename T>
@@ -168,20 +227,26 @@ int launch_gemm_pw(const void* x, const void* w, const float* scale, const float
                    void* y, const pasn_conv_desc& d, hipStream_t s) {
     constexpr int CH = Traits<T>::CH;
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
-    const int S = d.To * d.Ho * d.Wo;
     const size_t tiles = (size_t)2 * (G_BM + G_BN) * (G_BK + CH) * sizeof(T);
     const size_t image = (size_t)G_BM * (G_BN + CH) * sizeof(T);
     const size_t lds = tiles > image ? tiles : image;
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pw_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  96 * 1024);
-        attr = true;
-    }
     const dim3 grid(ceil_div(M, G_BM), ceil_div(d.Cout_p, G_BN)), block(256);
-    hipLaunchKernelGGL((gemm_pw_kernel<T>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias, (const T*)res, gate,
-                       (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish);
-    return check_launch("gemm_pw_kernel");
+    const bool pw = is_pointwise(d);
+    if (!pw) PASN_REQUIRE(gate == nullptr, "the SE gate transform is only fused into pointwise convs");
+#define PASN_GC(PW_)                                                                                                       \
+    do {                                                                                                                    \
+        static bool attr = false;                                                                                           \
+        if (!attr && lds > 64 * 1024) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<T, PW_>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
+            attr = true;                                                                                                    \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_conv_kernel<T, PW_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,          \
+                           (const T*)res, gate, (T*)y, d);                                                                  \
+    } while (0)
+    if (pw) PASN_GC(true); else PASN_GC(false);
+#undef PASN_GC
+    return check_launch("gemm_conv_kernel");
 }
 
 template int launch_gemm_pw<float>(const void*, const void*, const float*, const float*, const void*, const float*, void*,

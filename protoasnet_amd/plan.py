@@ -199,7 +199,7 @@ class PlanBuilder:
         self._use(xb, yb, rb, gb)
         variant = int(self.lib.pasn_conv3d_variant(dref, self.code))
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", f"gemm_pw_kernel<{self.tname}>" if variant >= 2000 else
+        self._note("conv", f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
                    f"pwconv_persist_kernel<{self.tname},{(variant - 1000) // 10},{variant % 10},{'true' if residual is not None else 'false'}>" if variant >= 1000 else
                    f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
                    (self._touched(x, y, k, s) * x.C + out_pos * y.C * (2 if residual is not None else 1)
