@@ -68,6 +68,17 @@ int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const
                         const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream);
 
 /*
+ * Fused X3D stem: (1,3,3) stride-(1,2,2) conv 3->24 -> depthwise (5,1,1) temporal conv -> BN -> ReLU in one launch
+ * (a thread marches along T with a 5-frame register ring; the 24-channel tensor between the two convs never reaches
+ * HBM).  Bit-identical to pasn_first_conv_fwd (no norm, no activation) followed by pasn_dwconv3d_fwd.
+ *   d    : geometry of the (1,3,3) conv as for pasn_first_conv_fwd; pasn_x3d_stem_supported(d) says whether it fits
+ *   w_xy : fp32 [27][24] (rows ordered ci, r, s);  w_t : fp32 [5][24];  scale, bias : fp32 [24] (BN after the temporal conv)
+ */
+int pasn_x3d_stem_supported(const pasn_conv_desc* d);
+int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias, void* y,
+                      const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream);
+
+/*
  * Dense convolution as an implicit GEMM on the matrix cores (MFMA), channels-last, groups=1, any
  * window/stride/padding, fused epilogue  y = act(acc*scale + bias [+ residual]).
  * Optional fused input transform (X3D project conv): x' = swish(x * gate[n][ci]).

@@ -31,6 +31,8 @@ SIGNATURES = {
     "pasn_version": (c_int, []),
     "pasn_last_error": (c_char_p, []),
     "pasn_first_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
+    "pasn_x3d_stem_supported": (c_int, [POINTER(ConvDesc)]),
+    "pasn_x3d_stem_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
     "pasn_conv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_variant": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_pool_blocks": (c_int, [POINTER(ConvDesc)]),

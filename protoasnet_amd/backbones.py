@@ -248,8 +248,7 @@ class X3DFeatures(_plan.HipTrunk):
         return f"{self.arch}_features(stem={X3D_STEM_DIM}, stages={X3D_STAGES})"
 
     def build_plan(self, pb, x):
-        x = pb.first_conv(x, self.stem.conv_xy, None, act="none")
-        x = pb.dwconv(x, self.stem.conv_t, self.stem.bn, act="relu")
+        x = pb.x3d_stem(x, self.stem.conv_xy, self.stem.conv_t, self.stem.bn)  # one T-marching launch (two if unsupported)
         for stage in self.stages:
             for blk in stage:
                 sc = x

@@ -1,0 +1,158 @@
+// Fused X3D stem: (1,3,3) stride-(1,2,2) conv 3 -> C  ->  depthwise (5,1,1) temporal conv  ->  BN -> ReLU, one launch.
+//
+// Unfused, the C-channel tensor between the two convs (308 MB at the benchmark shape) is written once and then read
+// by the temporal conv -- whose 5 taps are 5 different frames 600 KB apart, so L2 does not catch the reuse: PMC shows
+// 1.26 GB of HBM traffic for 0.62 GB of algorithmic bytes (profiles/pmc_traffic.json, dwconv3d_strip_kernel<bf16,7,1,1>).
+// Here a thread owns one output position (n, ho, wo) x all C channels and MARCHES ALONG T: it computes the spatial conv
+// of frame t (3*3*3 planar taps, weights from the scalar cache), keeps the last five results in a register ring, and emits
+// output frame t-2.  Traffic = clip in + stem out, nothing else.  The ring holds values rounded to the activation dtype,
+// so the result is bit-identical to the two unfused launches.
+#include "common.h"
+
+namespace pasn {
+
+template <typename TIN, typename T, int COP>
+__global__ __launch_bounds__(256) void x3d_stem_kernel(const TIN* __restrict__ x, const float* __restrict__ wxy,
+                                                       const float* __restrict__ wt, const float* __restrict__ scale,
+                                                       const float* __restrict__ bias, T* __restrict__ y, pasn_conv_desc d) {
+    // weights / scale / bias are wave-uniform with compile-time offsets: the compiler reads them with s_load through the
+    // scalar cache and feeds them to v_fmac as SGPR operands -- no LDS traffic, no vector registers
+    const long P = (long)d.N * d.Ho * d.Wo;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int wo = (int)(p % d.Wo);
+    const int ho = (int)((p / d.Wo) % d.Ho);
+    const int n = (int)(p / ((long)d.Wo * d.Ho));
+    const int T_ = d.Ti, Hi = d.Hi, Wi = d.Wi;
+    const long plane = (long)Hi * Wi;
+    // the 9 spatial taps of this position: offsets inside a frame, -1 where the window leaves the image
+    int off[9];
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int hi = ho * 2 - 1 + kr, wi = wo * 2 - 1 + ks;
+            off[kr * 3 + ks] = (hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) ? hi * Wi + wi : -1;
+        }
+    // spatial-conv results of frames t-4 .. t, slot = frame % 5, held IN THE ACTIVATION DTYPE as 8-wide vectors
+    // (bf16: 5 x 12 registers instead of 5 x 24) -- exactly the values the unfused path would have stored
+    typedef T RV __attribute__((ext_vector_type(8)));
+    RV ring[5][COP / 8];
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int c = 0; c < COP; ++c) ring[u][c >> 3][c & 7] = (T)0.0f;
+
+#pragma unroll 1
+    for (int t = 0; t < T_ + 2; ++t) {
+        // ---- spatial conv of frame t (zeros beyond the clip: they flush the last two outputs) ----
+        // an opaque zero in an SGPR, renewed per frame: keeps the 768 weight s_loads INSIDE the loop (hoisted, they
+        // spill ~250 SGPRs)
+        int zo = 0;
+        asm volatile("" : "+s"(zo));
+        const float* wq = wxy + zo;
+        const float* wk = wt + zo;
+        float acc[COP];
+#pragma unroll
+        for (int c = 0; c < COP; ++c) acc[c] = 0.0f;
+        if (t < T_) {
+            float xv[27];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const TIN* xp = x + (((long)n * 3 + ci) * T_ + t) * plane;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {  // unconditional load (clamped), select after: no per-tap branches
+                    const float v = (float)xp[off[q] >= 0 ? off[q] : 0];
+                    xv[ci * 9 + q] = off[q] >= 0 ? v : 0.0f;
+                }
+            }
+            // software pipeline over taps: the s_loads of tap q+1 are issued before the FMAs of tap q, and scheduling
+            // barriers stop the scheduler from front-loading all 27 taps (which spills ~250 SGPRs)
+            float wc[COP], wn[COP];
+#pragma unroll
+            for (int c = 0; c < COP; ++c) wc[c] = wq[c];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) {
+                if (q + 1 < 27) {
+#pragma unroll
+                    for (int c = 0; c < COP; ++c) wn[c] = wq[(q + 1) * COP + c];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < COP; ++c) acc[c] = fmaf(xv[q], wc[c], acc[c]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < COP; ++c) wc[c] = wn[c];
+            }
+        }
+        // ---- rotate the ring (oldest frame out), newest in slot 4, rounded as the unfused path stores it ----
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < COP / 8; ++j) ring[u][j] = ring[u + 1][j];
+#pragma unroll
+        for (int c = 0; c < COP; ++c) ring[4][c >> 3][c & 7] = (T)acc[c];
+        // ---- temporal conv: output frame to = t - 2 from frames t-4 .. t = slots 0 .. 4 ----
+        const int to = t - 2;
+        if (to >= 0) {
+            float o[COP];
+#pragma unroll
+            for (int c = 0; c < COP; ++c) o[c] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                float wv[COP];
+#pragma unroll
+                for (int c = 0; c < COP; ++c) wv[c] = wk[k * COP + c];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < COP; ++c) o[c] = fmaf((float)ring[k][c >> 3][c & 7], wv[c], o[c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float* sc = scale + zo;
+            const float* bi = bias + zo;
+            T* yp = y + ((((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo) * COP;
+#pragma unroll
+            for (int c = 0; c < COP; c += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(o[c + j] * sc[c + j] + bi[c + j], 0.0f);
+                mask_tail(v, d.Cout - c);
+                store8(yp + c, v);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+}  // namespace pasn
+
+using namespace pasn;
+
+extern "C" int pasn_x3d_stem_supported(const pasn_conv_desc* d) {
+    if (!d) return 0;
+    if (const char* e = getenv("PASN_NO_STEM"))
+        if (e[0] == '1') return 0;
+    return d->Cin == 3 && d->kt == 1 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 0 &&
+           d->ph == 1 && d->pw == 1 && d->To == d->Ti && d->Cout_p == 24 && d->Cout <= 24;
+}
+
+extern "C" int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias,
+                                 void* y, const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream) {
+    PASN_REQUIRE(x && w_xy && w_t && scale && bias && y && d, "null pointer");
+    PASN_REQUIRE(pasn_x3d_stem_supported(d), "geometry is not the X3D stem ((1,3,3) s(1,2,2) p(0,1,1), 24 channels)");
+    const long P = (long)d->N * d->Ho * d->Wo;
+    const dim3 grid(ceil_div(P, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define PASN_ST(TIN, T) \
+    hipLaunchKernelGGL((x3d_stem_kernel<TIN, T, 24>), grid, block, 0, s, (const TIN*)x, w_xy, w_t, scale, bias, (T*)y, *d)
+    if (in_dtype == PASN_F32 && out_dtype == PASN_F32) PASN_ST(float, float);
+    else if (in_dtype == PASN_F32 && out_dtype == PASN_BF16) PASN_ST(float, __bf16);
+    else if (in_dtype == PASN_BF16 && out_dtype == PASN_BF16) PASN_ST(__bf16, __bf16);
+    else if (in_dtype == PASN_BF16 && out_dtype == PASN_F32) PASN_ST(__bf16, float);
+    else {
+        set_error("pasn_x3d_stem_fwd: unknown dtype");
+        return PASN_ERR_ARG;
+    }
+#undef PASN_ST
+    return check_launch("x3d_stem_kernel");
+}

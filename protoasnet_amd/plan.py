@@ -182,6 +182,36 @@ class PlanBuilder:
         self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, code_out, st)))
         return y
 
+    def x3d_stem(self, x: Act, conv_xy: nn.Module, conv_t: nn.Module, norm: nn.Module) -> Act:
+        """X3D stem ((1,3,3) s2 conv -> depthwise (5,1,1) conv -> BN -> ReLU) as ONE launch; otherwise the two unfused ones."""
+        k, s, p = _triple(conv_xy.kernel_size, 1), _triple(conv_xy.stride, 1), _triple(conv_xy.padding, 0)
+        kt, st_, pt_ = _triple(conv_t.kernel_size, 1), _triple(conv_t.stride, 1), _triple(conv_t.padding, 0)
+        c = conv_xy.out_channels
+        y = self._out_act(x, c, k, s, p)
+        d = self._desc(x, y, k, s, p, "relu")
+        fusable = (x.planar and x.C == 3 and kt == (5, 1, 1) and st_ == (1, 1, 1) and pt_ == (2, 0, 0) and conv_t.groups == c
+                   and conv_xy.bias is None and conv_t.bias is None and bool(self.lib.pasn_x3d_stem_supported(ctypes.byref(d))))
+        if not fusable:
+            self.bufs[y.buf].nbytes = ALIGN  # the buffer reserved above stays unused
+            e = self.first_conv(x, conv_xy, None, act="none")
+            return self.dwconv(e, conv_t, norm, act="relu")
+        wxy = torch.zeros(27, y.Cp, dtype=torch.float32, device=self.device)
+        wxy[:, :c] = conv_xy.weight.detach().float()[:, :, 0].permute(1, 2, 3, 0).reshape(27, c)
+        wt = torch.zeros(5, y.Cp, dtype=torch.float32, device=self.device)
+        wt[:, :c] = conv_t.weight.detach().float().reshape(c, 5).t()
+        scale, bias = fold_norm(norm, None, c, y.Cp, self.device)
+        self.keep += [wxy, wt, scale, bias, d]
+        fn, code_in, code_out = self.lib.pasn_x3d_stem_fwd, _lib.dtype_code(self.in_dtype), self.code
+        a = (wxy.data_ptr(), wt.data_ptr(), scale.data_ptr(), bias.data_ptr())
+        xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
+        self._use(xb, yb)
+        in_es = 2 if self.in_dtype == torch.bfloat16 else 4
+        out_pos = y.N * y.positions
+        self._note("stem", f"x3d_stem_kernel<{'bf16' if in_es == 2 else 'f32'},{self.tname},{y.Cp}>",
+                   x.N * 3 * x.positions * in_es + out_pos * c * self.es, 2 * out_pos * c * (27 + 5))
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], ptrs[yb], dref, code_in, code_out, st)))
+        return y
+
     def conv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, residual: Optional[Act] = None,
              in_gate: Optional[int] = None, in_swish: bool = False) -> Act:
         assert not x.planar and conv.groups == 1

@@ -140,7 +140,8 @@ def test_plan_shapes_and_arena(cfg, shape):
     n_ops = len(plan.ops)
     # x3d: stem 2 + 26 blocks x (expand, depthwise, project) + 4 shortcuts + 15 SE gates (the fused expand+depthwise
     # launch is opt-in via PASN_FUSED=1 and would make it 26 x 2)
-    assert n_ops == {"x3d_s": 2 + 26 * (2 if os.environ.get("PASN_FUSED") == "1" else 3) + 4 + 15,"resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
+    # (the stem's two convs are one fused T-marching launch)
+    assert n_ops == {"x3d_s": 1 + 26 * (2 if os.environ.get("PASN_FUSED") == "1" else 3) + 4 + 15,"resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
 
 
 def test_packed_weight_layout():

@@ -311,6 +311,47 @@ def test_x3d_expand_dw_fused(case, dtype, monkeypatch):
     assert_close(gate[:, :ci], gref, 1e-3 if dtype == torch.float32 else 1e-2, 0, "SE gate from fused partial sums")
 
 
+@pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("thw", [(7, 18, 22), (2, 9, 9), (1, 16, 16), (12, 11, 14)])
+def test_x3d_stem_fused(thw, dtypes, monkeypatch):
+    """Fused stem (spatial conv -> temporal depthwise conv -> BN -> ReLU, T-marching register ring) == torch, and
+    bit-identical to the two unfused launches (ring values are rounded to the activation dtype exactly like the tensor
+    the unfused path stores)."""
+    in_dtype, dtype = dtypes
+    torch.manual_seed(21)
+    n, c = 2, 24
+    x = torch.randn(n, 3, *thw)
+    from protoasnet_amd.backbones import _X3DStem
+
+    stem = _X3DStem(c)
+    with torch.no_grad():
+        stem.bn.weight.uniform_(0.5, 1.5)
+        stem.bn.bias.normal_(0, 0.3)
+        stem.bn.running_mean.normal_(0, 0.3)
+        stem.bn.running_var.uniform_(0.5, 1.5)
+    stem.eval()
+    xy = _rt(stem.conv_xy(_rt(x, in_dtype)), dtype)
+    ref = F.relu(stem.bn(stem.conv_t(xy))).detach()
+    stem = stem.to(DEV)
+    xin = x.to(DEV).to(in_dtype).contiguous()
+
+    def run():
+        pb = _pb(dtype, in_dtype)
+        xa = pb.input(tuple(x.shape))
+        y = pb.x3d_stem(xa, stem.conv_xy, stem.conv_t, stem.bn)
+        kinds = [m["kind"] for m in pb.meta]
+        return _run_single(pb, xa, y, xin), kinds
+
+    fused, kinds = run()
+    assert kinds == ["stem"]
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(fused, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"fused stem {thw}")
+    monkeypatch.setenv("PASN_NO_STEM", "1")
+    unfused, kinds = run()
+    assert kinds == ["first_conv", "dwconv"]
+    assert torch.equal(fused, unfused), "fused stem must be bit-identical to the unfused pair"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool(dtype):
     torch.manual_seed(9)
