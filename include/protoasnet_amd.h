@@ -105,11 +105,12 @@ int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype);
  * emits per-block partial channel sums of the (pre-activation) output for the squeeze-excite pool.
  * Replaces: X3D stem conv_t + BN + ReLU and X3D conv_b + BN (+Swish); HBM-bound stencil.
  *   w     : fp32 [kt*kh*kw][Cp]
- *   pool_partial : fp32 [N][pool_blocks][Cp] or NULL; pool_blocks = pasn_dwconv3d_pool_blocks(d)
+ *   pool_partial : fp32 [N][pool_blocks][Cp] or NULL; pool_blocks = pasn_dwconv3d_pool_blocks(d, dtype)
  */
-int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d);
-/* Kernel instance for this geometry: WT*100 + KW*10 + SW = dwconv3d_strip_kernel<dtype, WT, KW, SW>; 0 = generic kernel. */
-int pasn_dwconv3d_variant(const pasn_conv_desc* d);
+int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype);
+/* Kernel instance for this geometry: 3000 + WT*10 + SW = dwconv3d_march_kernel<SW, WT> (bf16, 3x3x3, stride (1,s,s));
+ * WT*100 + KW*10 + SW = dwconv3d_strip_kernel<dtype, WT, KW, SW>; 0 = generic kernel. */
+int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype);
 int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                       float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream);
 

@@ -40,6 +40,13 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
 
 // LDS-tiled MFMA GEMM for large-K pointwise convs (gemm_pw.hip)
 bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype);
+// dwmarch.hip: T-marching depthwise 3x3x3 stencil (bf16).  WT = 0: geometry / dtype not covered.
+struct DwMarchGeom {
+    int WT, CG, R, strips, Tc, bpc;  // outputs per strip, channel groups, items per block, strips per row, T chunk, blocks per clip
+};
+DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype);
+int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s);
 template <typename T>
 int launch_gemm_pw(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                    void* y, const pasn_conv_desc& d, hipStream_t s);

@@ -732,14 +732,18 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype) {
     return NT * 10 + MT;
 }
 
-extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d) {
+extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    if (m.WT) return 3000 + m.WT * 10 + d->sw;  // dwconv3d_march_kernel<SW, WT>
     const DwGeom g = dw_geom(*d);
     return g.WT ? g.WT * 100 + d->kw * 10 + d->sw : 0;
 }
 
-extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d) {
+extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    if (m.WT) return m.bpc;
     return dw_geom(*d).blocks;
 }
 
@@ -749,6 +753,8 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     PASN_REQUIRE(conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
     PASN_REQUIRE(d->Cin == d->Cout && d->Cin_p == d->Cout_p, "depthwise conv keeps the channel count");
     hipStream_t s = (hipStream_t)stream;
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    if (m.WT) return launch_dw_march(x, w, scale, bias, y, pool_partial, *d, m, s);
     if (dtype == PASN_F32) return launch_dwconv3d<float>(x, w, scale, bias, y, pool_partial, *d, s);
     if (dtype == PASN_BF16) return launch_dwconv3d<__bf16>(x, w, scale, bias, y, pool_partial, *d, s);
     set_error("pasn_dwconv3d_fwd: unknown dtype");

@@ -1,0 +1,253 @@
+// T-marching depthwise 3x3x3 stencil (stride (1,s,s), pad 1), bf16 activations -- the X3D conv_b of every block.
+//
+// Why: PMC on the strip kernel (tools/pmc_dw.sh) shows it ISSUE-bound, not bandwidth-bound: 360 VALU instructions per
+// 8-channel output vector, of which only 108 are the packed FMAs; the rest is the bf16->fp32 conversion of every input
+// vector once per (kt) it is used in (93), register double-buffer copies (46), address arithmetic and edge selects.  On
+// the small-spatial stages it is latency-bound instead: 9 dependent load rounds per thread and a 46 KB weight stage per
+// block for ~1 strip of work.
+//
+// Here a thread owns WT consecutive outputs along W of one (ho) row for one 8-channel group and MARCHES ALONG T with
+// three accumulator sets in flight (outputs t-1, t, t+1).  Every input row (ti, hi) is loaded and converted ONCE and
+// feeds all three kt taps: loads, conversions and address arithmetic per output drop 3x, and there is no double-buffer
+// copy (the raw row registers are refilled for the next row right after conversion, so the loads fly under ~430 packed
+// FMAs).  T is split into chunks (halo frames recomputed) only as far as needed to keep >= 2 waves per SIMD.
+//
+// Weights live in LDS as two 16-byte planes per tap ([tap][half][CG][4] fp32) so a wave's ds_read_b128 walks consecutive
+// slots (conflict-free; lanes of the same channel group broadcast).
+#include "common.h"
+
+namespace pasn {
+
+constexpr int DWM_CGS = 64;   // LDS slot stride of the weight planes = max channel groups (512 channels)
+constexpr int DWM_ROWS = 29;  // 27 taps + scale + bias
+static size_t dwm_lds_bytes(int R, int Cp) { return (size_t)(DWM_ROWS * 2 * DWM_CGS * 4 + R * Cp) * sizeof(float); }
+
+template <int SW, int WT>
+__global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ bias,
+                                                             __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
+                                                             int CG, int R, int strips, int Tc, int bpc) {
+    // [27 taps + scale + bias][2 halves][DWM_CGS slots][4] fp32 (fixed slot stride: every tap is an immediate ds_read
+    // offset), then [R][Cp] pool scratch
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NC = (WT - 1) * SW + 3;  // input columns a strip touches
+    const int Cp = d.Cout_p;
+    float* red = lds + DWM_ROWS * 2 * DWM_CGS * 4;
+    for (int i = threadIdx.x; i < DWM_ROWS * 2 * CG; i += blockDim.x) {
+        const int row = i / (2 * CG), rem = i - row * 2 * CG, half = rem / CG, g = rem - half * CG;
+        const float* src = row < 27 ? w + (long)row * Cp : (row == 27 ? scale : bias);
+        *reinterpret_cast<f32x4*>(lds + ((row * 2 + half) * DWM_CGS + g) * 4) = *reinterpret_cast<const f32x4*>(src + g * 8 + half * 4);
+    }
+    __syncthreads();
+
+    const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);  // whole clips per XCD: halo rows of neighbouring items share an L2
+    const int n = lb / bpc, bx = lb % bpc;
+    const int nT = (d.To + Tc - 1) / Tc;
+    const int items = nT * d.Ho * strips;
+    const int item = bx * R + r;
+    float psum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) psum[j] = 0.0f;
+
+    if (item < items) {
+        const int strip = item % strips;
+        const int ho = (item / strips) % d.Ho;
+        const int t0 = (item / (strips * d.Ho)) * Tc;
+        const int t1 = min(t0 + Tc, d.To);
+        const int wo0 = strip * WT;
+        const int wi0 = wo0 * SW - 1;
+        const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
+        // per-thread column byte offsets (clamped into the row) and validity bits; the row base is added per row
+        unsigned colofs[NC];
+        unsigned colok = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int wi = wi0 + c;
+            colofs[c] = (unsigned)(min(max(wi, 0), Wi - 1) * Cp * 2 + cg * 16);
+            colok |= (wi >= 0 && wi < Wi) ? (1u << c) : 0u;
+        }
+        // only the first / last column of a strip can leave the image when there is no ragged strip
+        const bool edge1 = d.Wo % WT == 0 && ((d.Wo - 1) * SW + 1 - (Wi - 1)) <= 1;
+        const char* xb = reinterpret_cast<const char*>(x);
+        const unsigned rowbytes = (unsigned)(Wi * Cp * 2);
+        uint4 raw[NC];
+        auto issue = [&](int ti, int kh) {  // unconditional loads from a clamped (always valid) row
+            const int tic = min(max(ti, 0), Ti - 1);
+            const int hic = min(max(ho * SW - 1 + kh, 0), Hi - 1);
+            const unsigned base = (unsigned)((n * Ti + tic) * Hi + hic) * rowbytes;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) raw[c] = *reinterpret_cast<const uint4*>(xb + (size_t)(base + colofs[c]));
+        };
+
+        float A[3][WT][8];  // A[0]: output frame ti-1 (kt = 2), A[1]: ti (kt = 1), A[2]: ti+1 (kt = 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int o = 0; o < WT; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) A[a][o][j] = 0.0f;
+
+        issue(t0 - 1, 0);
+#pragma unroll 1
+        for (int ti = t0 - 1; ti <= t1; ++ti) {
+            const bool tv = ti >= 0 && ti < Ti;
+            // opaque per-frame zero: keeps the 54 weight reads of a frame INSIDE the loop (hoisted, they are 216 registers)
+            int zo = 0;
+            asm volatile("" : "+v"(zo));
+            const float* wl = lds + cg * 4 + zo;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hi = ho * SW - 1 + kh;
+                const bool rv = tv && hi >= 0 && hi < Hi;
+                // convert the row once (columns outside the image become zeros)
+                float xr[NC][8];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    uint4 v[1] = {raw[c]};
+                    if (!(edge1 && c != 0 && c != NC - 1)) {
+                        const bool ok = (colok >> c) & 1u;
+                        v[0].x = ok ? v[0].x : 0u;
+                        v[0].y = ok ? v[0].y : 0u;
+                        v[0].z = ok ? v[0].z : 0u;
+                        v[0].w = ok ? v[0].w : 0u;
+                    }
+                    raw_to_f8<__bf16>(v, xr[c]);
+                }
+                // refill the raw registers with the next row; it lands under this row's FMAs
+                __builtin_amdgcn_sched_barrier(0);  // the refill must not be hoisted above the conversion (a second raw row live)
+                if (kh < 2) issue(ti, kh + 1);
+                else issue(ti + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rv) {
+#pragma unroll
+                    for (int kt = 0; kt < 3; ++kt) {
+                        __builtin_amdgcn_sched_barrier(0);  // keep one kt group (24 weight registers) live at a time
+                        float wv[3][8];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            const int tap = (kt * 3 + kh) * 3 + e;
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(wl + (tap * 2 + 0) * DWM_CGS * 4);
+                            const f32x4 hh = *reinterpret_cast<const f32x4*>(wl + (tap * 2 + 1) * DWM_CGS * 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                wv[e][j] = lo[j];
+                                wv[e][4 + j] = hh[j];
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                if ((c - e) >= 0 && (c - e) % SW == 0 && (c - e) / SW < WT) {  // resolved at compile time
+                                    const int o = (c - e) / SW;
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) A[2 - kt][o][j] = fmaf(xr[c][j], wv[e][j], A[2 - kt][o][j]);
+                                }
+                    }
+                }
+            }
+            // output frame ti-1 has now seen frames ti-2, ti-1, ti
+            const int to = ti - 1;
+            if (to >= t0 && to < t1) {
+                float sc[8], bs[8];
+                {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (27 * 2 + 0) * DWM_CGS * 4);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(wl + (27 * 2 + 1) * DWM_CGS * 4);
+                    const f32x4 e = *reinterpret_cast<const f32x4*>(wl + (28 * 2 + 0) * DWM_CGS * 4);
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(wl + (28 * 2 + 1) * DWM_CGS * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sc[j] = a[j];
+                        sc[4 + j] = b[j];
+                        bs[j] = e[j];
+                        bs[4 + j] = f[j];
+                    }
+                }
+                __bf16* yrow = y + ((((long)n * d.To + to) * d.Ho + ho) * d.Wo) * Cp + cg * 8;
+#pragma unroll
+                for (int o = 0; o < WT; ++o) {
+                    const int wo = wo0 + o;
+                    if (wo >= d.Wo) continue;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = A[0][o][j] * sc[j] + bs[j];
+                        psum[j] += v[j];
+                    }
+                    act_vec(v, d.act);
+                    mask_tail(v, d.Cout - cg * 8);
+                    store8(yrow + (long)wo * Cp, v);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < WT; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    A[0][o][j] = A[1][o][j];
+                    A[1][o][j] = A[2][o][j];
+                    A[2][o][j] = 0.0f;
+                }
+        }
+    }
+    if (pool) {  // block-uniform; squeeze-excite partial sums reduced over the R items in fixed order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[r * Cp + cg * 8 + j] = psum[j];
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+            float s = 0.0f;
+            for (int q = 0; q < R; ++q) s += red[q * Cp + ch];
+            pool[((long)n * bpc + bx) * Cp + ch] = s;
+        }
+    }
+}
+
+// Geometry: WT = 0 means "not this kernel".
+DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
+    DwMarchGeom g = {0, 0, 0, 0, 0, 0};
+    if (dtype != PASN_BF16) return g;
+    if (const char* e = getenv("PASN_NO_DWMARCH"))
+        if (e[0] == '1') return g;
+    const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == d.sw && (d.sw == 1 || d.sw == 2) && d.pt == 1 &&
+                       d.ph == 1 && d.pw == 1 && d.To == d.Ti && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0 && d.Cout_p / 8 <= DWM_CGS;
+    if (!shape) return g;
+    if (d.Ho != (d.Hi + 2 - 3) / d.sh + 1 || d.Wo != (d.Wi + 2 - 3) / d.sw + 1) return g;
+    // 32-bit byte offsets inside the kernel
+    if ((long)d.N * d.Ti * d.Hi * d.Wi * d.Cin_p * 2 >= (1L << 32)) return g;
+    g.CG = d.Cout_p / 8;
+    g.R = 256 / g.CG;
+    g.WT = 2;  // WT = 4 (stride 1) halves the loads per output but does not fit 256 registers yet (measured 1.4-1.8x slower)
+    if (const char* e = getenv("PASN_DWM_WT")) {
+        const int v = atoi(e);
+        if (v == 2 || (v == 4 && d.sw == 1)) g.WT = v;
+    }
+    g.strips = ceil_div(d.Wo, g.WT);
+    // split T only as far as needed for >= 2 waves per SIMD (2048 waves of 64 lanes)
+    g.Tc = d.To;
+    int want = 2048;
+    if (const char* e = getenv("PASN_DWM_WAVES")) want = atoi(e) > 0 ? atoi(e) : want;
+    while (g.Tc > 2 && (long)d.N * ceil_div(d.To, g.Tc) * d.Ho * g.strips * g.CG < (long)want * 64) g.Tc = (g.Tc + 1) / 2;
+    if (const char* e = getenv("PASN_DWM_TC")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= d.To) g.Tc = v;
+    }
+    g.bpc = ceil_div((long)ceil_div(d.To, g.Tc) * d.Ho * g.strips, g.R);
+    if (dwm_lds_bytes(g.R, d.Cout_p) > 72 * 1024) return DwMarchGeom{0, 0, 0, 0, 0, 0};
+    return g;
+}
+
+int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s) {
+    const dim3 grid(g.bpc * d.N), block(g.CG * g.R);
+    const size_t lds = dwm_lds_bytes(g.R, d.Cout_p);
+#define PASN_DWM(SW_, WT_)                                                                                           \
+    hipLaunchKernelGGL((dwconv3d_march_kernel<SW_, WT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
+                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc)
+    if (d.sw == 1 && g.WT == 4) PASN_DWM(1, 4);
+    else if (d.sw == 1) PASN_DWM(1, 2);
+    else PASN_DWM(2, 2);
+#undef PASN_DWM
+    return check_launch("dwconv3d_march_kernel");
+}
+
+}  // namespace pasn

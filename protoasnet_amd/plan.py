@@ -255,15 +255,21 @@ class PlanBuilder:
         self.keep += [wp, scale, bias]
         pool_buf, pool_blocks = None, 0
         if pool:
-            pool_blocks = int(self.lib.pasn_dwconv3d_pool_blocks(ctypes.byref(d)))
+            pool_blocks = int(self.lib.pasn_dwconv3d_pool_blocks(ctypes.byref(d), self.code))
             pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4)
         fn, code = self.lib.pasn_dwconv3d_fwd, self.code
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, pb, dref = x.buf, y.buf, pool_buf, ctypes.byref(d)
         self._use(xb, yb, pb)
         out_pos = y.N * y.positions
-        dv = int(self.lib.pasn_dwconv3d_variant(dref))
-        self._note("dwconv", f"dwconv3d_strip_kernel<{self.tname},{dv // 100},{dv // 10 % 10},{dv % 10}>" if dv else f"dwconv3d_kernel<{self.tname}>",
+        dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
+        if dv >= 3000:
+            kname = f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>"
+        elif dv:
+            kname = f"dwconv3d_strip_kernel<{self.tname},{dv // 100},{dv // 10 % 10},{dv % 10}>"
+        else:
+            kname = f"dwconv3d_kernel<{self.tname}>"
+        self._note("dwconv", kname,
                    (self._touched(x, y, k, s) + out_pos) * y.C * self.es + (y.N * pool_blocks * y.C * 4 if pool else 0),
                    2 * out_pos * y.C * taps)
         self.ops.append(
