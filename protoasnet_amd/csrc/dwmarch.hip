@@ -222,9 +222,10 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
         if (v == 2 || (v == 4 && d.sw == 1)) g.WT = v;
     }
     g.strips = ceil_div(d.Wo, g.WT);
-    // split T only as far as needed for >= 2 waves per SIMD (2048 waves of 64 lanes)
+    // split T (halo frames are recomputed) only while the grid is well short of 2 waves per SIMD: measured on the 7x7 and
+    // 14x14 layers, Tc = 8 beats both 16 (too few waves) and 4 (50 % halo work)
     g.Tc = d.To;
-    int want = 2048;
+    int want = 1400;
     if (const char* e = getenv("PASN_DWM_WAVES")) want = atoi(e) > 0 ? atoi(e) : want;
     while (g.Tc > 2 && (long)d.N * ceil_div(d.To, g.Tc) * d.Ho * g.strips * g.CG < (long)want * 64) g.Tc = (g.Tc + 1) / 2;
     if (const char* e = getenv("PASN_DWM_TC")) {
