@@ -615,20 +615,61 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x)
         mean[ch] = ((part[ch] + part[Cp + ch]) + (part[2 * Cp + ch] + part[3 * Cp + ch])) * inv_positions;
     __syncthreads();
-    // fc1 + ReLU: a wave per hidden unit, lanes along the C-long dot product
-    for (int j = wave; j < Cse; j += 4) {
-        float s = 0.0f;
-        for (int ch = lane; ch < C; ch += 64) s = fmaf(w1[(long)j * C + ch], mean[ch], s);
+    // fc1 + ReLU: a wave per hidden unit, lanes along the C-long dot product.  Eight units per wave are computed together
+    // and the C loop is unrolled so all of a wave's weight loads are independent and in flight at once: this kernel is pure
+    // latency (one block per clip), and the rolled version paid Cse/4 dependent L2 round trips (36 us at Cse = 32).
+    constexpr int JU = 8;
+    for (int j0 = wave; j0 < Cse; j0 += 4 * JU) {
+        float s[JU];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) hid[j] = fmaxf(s + b1[j], 0.0f);
+        for (int u = 0; u < JU; ++u) s[u] = 0.0f;
+        for (int c0 = 0; c0 < C; c0 += 256) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = c0 + lane + 64 * k;
+                const bool ok = ch < C;
+                const float m = ok ? mean[ch] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    const int j = j0 + 4 * u;
+                    const bool use = ok && j < Cse;  // unconditional load from a clamped index, select after (no branches)
+                    const float wv = w1[use ? (long)j * C + ch : 0];
+                    s[u] = fmaf(use ? wv : 0.0f, m, s[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+            float t = s[u];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+            const int j = j0 + 4 * u;
+            if (lane == 0 && j < Cse) hid[j] = fmaxf(t + b1[j], 0.0f);
+        }
     }
     __syncthreads();
+    // fc2 + sigmoid: a thread per channel; its Cse-long weight row is contiguous -> independent 16-byte loads
     for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
         float g = 0.0f;
         if (ch < C) {
             float s = b2[ch];
-            for (int j = 0; j < Cse; ++j) s = fmaf(w2[(long)ch * Cse + j], hid[j], s);
+            const float* wr = w2 + (long)ch * Cse;
+            if ((Cse & 3) == 0) {
+                for (int j0 = 0; j0 < Cse; j0 += 32) {
+                    f32x4 wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        wv[u] = *reinterpret_cast<const f32x4*>(wr + (j0 + 4 * u < Cse ? j0 + 4 * u : 0));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + 4 * u < Cse) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s = fmaf(wv[u][e], hid[j0 + 4 * u + e], s);
+                        }
+                }
+            } else {
+                for (int j = 0; j < Cse; ++j) s = fmaf(wr[j], hid[j], s);
+            }
             g = sigmoidf_(s);
         }
         gate[(long)n * Cp + ch] = g;
