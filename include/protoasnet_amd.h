@@ -52,6 +52,9 @@ typedef struct pasn_conv_desc {
     int32_t in_swish;         /* conv3d: apply x*sigmoid(x) to the INPUT while loading it  */
     int32_t w_kc;             /* conv3d: per-tap K extent of the packed weight (elements)  */
     int32_t w_rows;           /* conv3d: rows of the packed weight / scale / bias arrays   */
+    int32_t w_frag;           /* conv3d: 0 = w is [w_rows][taps][w_kc]; 1 = MFMA-fragment-major
+                                 [w_rows/32][w_kc/KSTEP][2][32][CH] (KSTEP/CH = 16/8 bf16, 8/4 fp32):
+                                 only where pasn_conv3d_variant() reports 2500/2501           */
 } pasn_conv_desc;
 
 /*
@@ -86,7 +89,7 @@ int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const 
  * (resnet_features.py:49-66,202-213; torchvision Conv2Plus1D/BasicBlock at :316-320), the 1x1(x1)
  * add-on convs of PPNet (ProtoPNet.py:117-130) and the X3D expand / project / shortcut convs.
  *   x     : dtype [N][Ti][Hi][Wi][Cin_p]
- *   w     : dtype [w_rows][kt*kh*kw][w_kc], zero padded (w_rows multiple of 128, w_kc multiple of
+ *   w     : dtype [w_rows][kt*kh*kw][w_kc] (or fragment-major, see w_frag), zero padded (w_rows multiple of 128, w_kc multiple of
  *           16 (bf16) / 8 (fp32) and >= Cin_p)
  *   scale, bias : fp32 [w_rows]
  *   residual : dtype [N][To][Ho][Wo][Cout_p] or NULL
@@ -96,8 +99,10 @@ int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const 
 int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
                     const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream);
 /* Which kernel instance pasn_conv3d_fwd picks for this geometry: 1000 + KS*10 + NT = pwconv_persist_kernel<dtype, KS, NT>
- * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT>
- * (output-channel / position tiles per wave); 0 on a bad descriptor.  For profilers and benchmarks. */
+ * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); 2500 (+1 with in_swish) = pwconv_xtile_kernel<dtype, ..>
+ * (1x1x1 stride-1 convs with Cin_p >= 64: whole-K position tiles in LDS); 2000 / 2001 = gemm_conv_kernel<dtype, pointwise /
+ * windowed> (LDS-tiled implicit GEMM); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT> (output-channel /
+ * position tiles per wave); 0 on a bad descriptor.  For profilers and benchmarks. */
 int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype);
 
 /*

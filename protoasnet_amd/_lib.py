@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libp
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "N", "Ti", "Hi", "Wi", "Cin", "Cin_p", "To", "Ho", "Wo", "Cout", "Cout_p",
-        "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "in_swish", "w_kc", "w_rows",
+        "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "in_swish", "w_kc", "w_rows", "w_frag",
     )]
 
 

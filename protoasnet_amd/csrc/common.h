@@ -38,6 +38,11 @@ template <typename T>
 int launch_pwconv(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                   void* y, const pasn_conv_desc& d, const PwGeom& g, hipStream_t s);
 
+// X-stationary pointwise conv for wide layers (pwconv_xtile.hip)
+bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype);
+template <typename T>
+int launch_pw_xtile(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
+                    void* y, const pasn_conv_desc& d, hipStream_t s);
 // LDS-tiled MFMA GEMM for large-K pointwise convs (gemm_pw.hip)
 bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype);
 // dwmarch.hip: T-marching depthwise 3x3x3 stencil (bf16).  WT = 0: geometry / dtype not covered.

@@ -749,10 +749,16 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     PASN_REQUIRE(d->w_rows % 128 == 0 && d->w_rows >= d->Cout_p, "w_rows must be a multiple of 128 covering Cout_p");
     hipStream_t s = (hipStream_t)stream;
     PASN_REQUIRE(dtype == PASN_F32 || dtype == PASN_BF16, "unknown dtype");
+    PASN_REQUIRE(d->w_frag == 0 || pw_xtile_applicable(*d, dtype) && !pw_geom(*d, dtype).TM,
+                 "fragment-major weights are only read by the pwconv_xtile kernel (variant 2500/2501)");
     const PwGeom pg = pw_geom(*d, dtype);  // 1x1x1 stride-1 convs take the row-streaming kernel
     if (pg.TM) {
         if (dtype == PASN_F32) return launch_pwconv<float>(x, w, scale, bias, residual, gate, y, *d, pg, s);
         return launch_pwconv<__bf16>(x, w, scale, bias, residual, gate, y, *d, pg, s);
+    }
+    if (pw_xtile_applicable(*d, dtype)) {  // wide pointwise layers: whole-K X tiles in LDS, weights streamed from L2
+        if (dtype == PASN_F32) return launch_pw_xtile<float>(x, w, scale, bias, residual, gate, y, *d, s);
+        return launch_pw_xtile<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
     }
     if (gemm_pw_applicable(*d, dtype)) {  // large K / N pointwise: LDS-tiled GEMM
         if (dtype == PASN_F32) return launch_gemm_pw<float>(x, w, scale, bias, residual, gate, y, *d, s);
@@ -766,6 +772,8 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!conv_desc_ok(d)) return 0;
     const PwGeom pg = pw_geom(*d, dtype);
     if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
+    if (pw_xtile_applicable(*d, dtype))               // pwconv_xtile_kernel<dtype, input transform?>
+        return 2500 + ((d->in_swish != 0) ? 1 : 0);
     if (gemm_pw_applicable(*d, dtype))                // gemm_conv_kernel<dtype, pointwise?>
         return 2000 + ((d->kt * d->kh * d->kw == 1 && d->st * d->sh * d->sw == 1) ? 0 : 1);
     int NT, MT;

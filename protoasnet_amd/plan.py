@@ -228,8 +228,17 @@ class PlanBuilder:
         xb, yb, rb, gb, dref = x.buf, y.buf, (residual.buf if residual is not None else None), in_gate, ctypes.byref(d)
         self._use(xb, yb, rb, gb)
         variant = int(self.lib.pasn_conv3d_variant(dref, self.code))
+        if variant >= 2500:
+            # pwconv_xtile_kernel reads its weights as MFMA fragments: store them fragment-major, so a wave's fragment
+            # load is one contiguous 1 KB run instead of a 32-row gather (the gather saturated the CU's address unit)
+            kstep, ch = (16, 8) if self.dtype == torch.bfloat16 else (8, 4)
+            wf = wp.view(rows // 32, 32, kc // kstep, 2, ch).permute(0, 2, 3, 1, 4).contiguous()
+            self.keep.append(wf)
+            a = (wf.data_ptr(), a[1], a[2])
+            d.w_frag = 1
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
+        self._note("conv", f"pwconv_xtile_kernel<{self.tname},{'true' if (in_gate is not None or variant == 2501) else 'false'}>" if variant >= 2500 else
+                   f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
                    f"pwconv_persist_kernel<{self.tname},{(variant - 1000) // 10},{variant % 10},{'true' if residual is not None else 'false'}>" if variant >= 1000 else
                    f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
                    (self._touched(x, y, k, s) * x.C + out_pos * y.C * (2 if residual is not None else 1)
