@@ -15,18 +15,45 @@
 
 namespace pasn {
 
+// 4 consecutive channels of a residual row, kept as loaded until the epilogue
+template <typename T>
+struct RawQuad;
+template <>
+struct RawQuad<__bf16> {
+    using type = uint2;
+    static __device__ __forceinline__ void to_f4(const uint2& r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x << 16);
+        v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16);
+        v[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+};
+template <>
+struct RawQuad<float> {
+    using type = uint4;
+    static __device__ __forceinline__ void to_f4(const uint4& r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x);
+        v[1] = __uint_as_float(r.y);
+        v[2] = __uint_as_float(r.z);
+        v[3] = __uint_as_float(r.w);
+    }
+};
+
 template <typename T, int KS, int NT, bool RES>
 __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              const T* __restrict__ res, const float* __restrict__ gate,
                                                              T* __restrict__ y, long M, int S, int Cin_p, int Cout, int Cout_p,
-                                                             int w_kc, int act, int in_swish) {
+                                                             int w_kc, int act, int in_swish, int gate_rows) {
     using frag = typename Traits<T>::frag;
     constexpr int CH = Traits<T>::CH;
     constexpr int KSTEP = Traits<T>::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sbl = reinterpret_cast<float*>(smem);                  // [2][NT*32] scale | bias of the channel chunk
     T* stage = reinterpret_cast<T*>(smem + 2 * NT * 32 * 4);       // [4 waves][32 rows][Cout_p] output images
+    // [gate_rows][Cin_p] the WHOLE squeeze-excite gate tensor (a few KB), staged once per block: the transform then reads
+    // LDS instead of issuing 8 dependent dword loads per k-step (64 L2 round trips per tile in the first version)
+    float* gl = reinterpret_cast<float*>(smem + 2 * NT * 32 * 4 + (size_t)4 * 32 * Cout_p * sizeof(T));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int co_base = blockIdx.y * (NT * 32);
@@ -34,6 +61,8 @@ __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict
         sbl[i] = scale ? scale[co_base + i] : 1.0f;
         sbl[NT * 32 + i] = bias ? bias[co_base + i] : 0.0f;
     }
+    if (gate_rows)
+        for (int i = threadIdx.x; i < gate_rows * Cin_p; i += 256) gl[i] = gate[i];
     __syncthreads();
 
     const int ks_real = w_kc / KSTEP;  // <= KS; the extra template steps are zero
@@ -50,12 +79,17 @@ __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict
     const bool xform = (gate != nullptr) || (in_swish != 0);
 
     frag Bc[KS], Bn[KS];
+    // ISSUE ONLY: unconditional loads from clamped (existing) addresses; rows beyond M / columns beyond Cin_p are zeroed
+    // when the fragments are consumed.  (`cond ? load : 0` puts every load in its own branch, and any use of the value
+    // next to the load makes hipcc wait for it before issuing the next one.)
     auto load_rows = [&](long t, frag (&B)[KS]) {
-        const long m = t * 32 + c;
-        const T* xp = x + m * Cin_p + h * CH;
+        const long m = min(t * 32 + c, M - 1);
+        const T* xp = x + m * Cin_p;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            B[ks] = (m < M && ks * KSTEP + h * CH < Cin_p) ? load_frag<T>(xp + ks * KSTEP) : zero_frag<T>();
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * KSTEP + h * CH;
+            B[ks] = load_frag<T>(xp + (k < Cin_p ? k : 0));
+        }
     };
     if (tile < ntiles) load_rows(tile, Bc);
 
@@ -64,30 +98,39 @@ __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict
         const bool mv = m < M;
         if (tile + stride < ntiles) load_rows(tile + stride, Bn);  // next tile's rows: in flight during everything below
         // this tile's residual rows, requested before the MFMAs that hide them
-        float rv[RES ? NT : 1][4][4];  // compile-time: expand convs (no residual) do not pay 16*NT registers
+        // raw (unconverted), unconditional, clamped: see load_rows.  Compile-time RES: expand convs pay no registers.
+        typename RawQuad<T>::type rq[RES ? NT : 1][4];
         if (RES) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = co_base + nt * 32 + 8 * g + 4 * h;
-                    if (mv && co < Cout_p) {
-                        load4(res + m * Cout_p + co, rv[nt][g]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) rv[nt][g][j] = 0.0f;
-                    }
+                    const bool ok = mv && co < Cout_p;
+                    rq[nt][g] = *reinterpret_cast<const typename RawQuad<T>::type*>(res + (ok ? m * Cout_p + co : 0));
                 }
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)  // zero what load_rows clamped
+            if (!(mv && ks * KSTEP + h * CH < Cin_p)) Bc[ks] = zero_frag<T>();
         if (xform) {  // x' = swish(x * gate[n][ci]), rounded back to the MFMA input type
-            const float* gp = gate ? gate + (mv ? m / S : 0) * Cin_p + h * CH : nullptr;
+            const long n = mv ? m / S : 0;
+            const float* gp = gate ? (gate_rows ? gl : gate) + n * Cin_p + h * CH : nullptr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks * KSTEP + h * CH < Cin_p) {
+                    float gv[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; j += 4) {
+                        const f32x4 q = gp ? *reinterpret_cast<const f32x4*>(gp + ks * KSTEP + j) : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+                        gv[j] = q[0];
+                        gv[j + 1] = q[1];
+                        gv[j + 2] = q[2];
+                        gv[j + 3] = q[3];
+                    }
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
-                        float v = (float)Bc[ks][j];
-                        if (gp) v *= gp[ks * KSTEP + j];
+                        float v = (float)Bc[ks][j] * gv[j];
                         if (in_swish) v = v * sigmoidf_(v);
                         Bc[ks][j] = (T)v;
                     }
@@ -120,8 +163,11 @@ __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = acc[nt][4 * g + j] * sc[j] + bs[j];
                 if (RES) {
+                    float r4[4];
+                    RawQuad<T>::to_f4(rq[nt][g], r4);
+                    const bool ok = mv && co_base + col < Cout_p;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += rv[nt][g][j];
+                    for (int j = 0; j < 4; ++j) o[j] += ok ? r4[j] : 0.0f;
                 }
                 act_vec(o, act);
                 mask_tail(o, Cout - col);
@@ -188,7 +234,7 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
             }                                                                                                                 \
         }                                                                                                                     \
         hipLaunchKernelGGL((pwconv_persist_kernel<T, KS_, NT_, RES_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,   \
-                           (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish);           \
+                           (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gate_rows); \
     } while (0)
 #define PASN_PW(KS_, NT_)                 \
     do {                                  \
@@ -196,7 +242,12 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
         else PASN_PW2(KS_, NT_, false);    \
     } while (0)
     const int KS = g.TM, NT = g.xrow;
-    const size_t lds = (size_t)2 * NT * 32 * 4 + (size_t)4 * 32 * d.Cout_p * sizeof(T);  // <= 64.5 KB (fp32, 128 channels)
+    size_t lds = (size_t)2 * NT * 32 * 4 + (size_t)4 * 32 * d.Cout_p * sizeof(T);  // <= 64.5 KB (fp32, 128 channels)
+    int gate_rows = 0;  // the whole gate tensor rides in LDS when it is small (it is: N x Cin_p floats)
+    if (gate && (size_t)d.N * d.Cin_p * 4 <= 32 * 1024 && lds + (size_t)d.N * d.Cin_p * 4 <= 80 * 1024) {
+        gate_rows = d.N;
+        lds += (size_t)d.N * d.Cin_p * 4;
+    }
     if (KS == 2) {
         if (NT == 1) PASN_PW(2, 1); else if (NT == 2) PASN_PW(2, 2); else PASN_PW(2, 4);
     } else if (KS == 4) {
