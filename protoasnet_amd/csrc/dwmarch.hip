@@ -80,17 +80,17 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
             for (int c = 0; c < NC; ++c) raw[c] = *reinterpret_cast<const uint4*>(xb + (size_t)(base + colofs[c]));
         };
 
-        float A[3][WT][8];  // A[0]: output frame ti-1 (kt = 2), A[1]: ti (kt = 1), A[2]: ti+1 (kt = 0)
+        // Three accumulator sets, one per output frame in flight.  Their ROLES rotate (the set that held output ti-1 is
+        // emitted, zeroed and becomes output ti+2's), so the frame loop is unrolled x3 with the sets passed by name:
+        // no register moves (the rolled version copied 2 x WT x 8 registers per frame).
+        float A0[WT][8], A1[WT][8], A2[WT][8];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int o = 0; o < WT; ++o)
 #pragma unroll
-            for (int o = 0; o < WT; ++o)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) A[a][o][j] = 0.0f;
+            for (int j = 0; j < 8; ++j) A0[o][j] = A1[o][j] = A2[o][j] = 0.0f;
 
-        issue(t0 - 1, 0);
-#pragma unroll 1
-        for (int ti = t0 - 1; ti <= t1; ++ti) {
+        // one input frame ti: P = output ti-1 (kt = 2), C = output ti (kt = 1), N = output ti+1 (kt = 0)
+        auto frame = [&](int ti, float (&P)[WT][8], float (&C)[WT][8], float (&N)[WT][8]) {
             const bool tv = ti >= 0 && ti < Ti;
             // opaque per-frame zero: keeps the 54 weight reads of a frame INSIDE the loop (hoisted, they are 216 registers)
             int zo = 0;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                                 wv[e][4 + j] = hh[j];
                             }
                         }
+                        float (&T_)[WT][8] = kt == 0 ? N : kt == 1 ? C : P;
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                                 if ((c - e) >= 0 && (c - e) % SW == 0 && (c - e) / SW < WT) {  // resolved at compile time
                                     const int o = (c - e) / SW;
 #pragma unroll
-                                    for (int j = 0; j < 8; ++j) A[2 - kt][o][j] = fmaf(xr[c][j], wv[e][j], A[2 - kt][o][j]);
+                                    for (int j = 0; j < 8; ++j) T_[o][j] = fmaf(xr[c][j], wv[e][j], T_[o][j]);
                                 }
                     }
                 }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        v[j] = A[0][o][j] * sc[j] + bs[j];
+                        v[j] = P[o][j] * sc[j] + bs[j];
                         psum[j] += v[j];
                     }
                     act_vec(v, d.act);
@@ -183,11 +184,15 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
 #pragma unroll
             for (int o = 0; o < WT; ++o)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    A[0][o][j] = A[1][o][j];
-                    A[1][o][j] = A[2][o][j];
-                    A[2][o][j] = 0.0f;
-                }
+                for (int j = 0; j < 8; ++j) P[o][j] = 0.0f;  // becomes the set of output frame ti+2
+        };
+
+        issue(t0 - 1, 0);
+#pragma unroll 1
+        for (int ti = t0 - 1; ti <= t1; ti += 3) {
+            frame(ti, A0, A1, A2);
+            if (ti + 1 <= t1) frame(ti + 1, A1, A2, A0);
+            if (ti + 2 <= t1) frame(ti + 2, A2, A0, A1);
         }
     }
     if (pool) {  // block-uniform; squeeze-excite partial sums reduced over the R items in fixed order
@@ -216,22 +221,34 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
     if ((long)d.N * d.Ti * d.Hi * d.Wi * d.Cin_p * 2 >= (1L << 32)) return g;
     g.CG = d.Cout_p / 8;
     g.R = 256 / g.CG;
-    g.WT = 2;  // WT = 4 (stride 1) halves the loads per output but does not fit 256 registers yet (measured 1.4-1.8x slower)
-    if (const char* e = getenv("PASN_DWM_WT")) {
-        const int v = atoi(e);
-        if (v == 2 || (v == 4 && d.sw == 1)) g.WT = v;
+    // Pick (WT, Tc) with a small cost model.  One work item per thread makes the grid a fixed number of blocks; at 2
+    // resident blocks per CU the kernel runs in ceil(blocks / 512) "rounds", and a half-empty last round is pure loss
+    // (measured: 704 blocks = 2 rounds for 1.4 rounds of work).  Per-thread cost = frames x instructions per frame.
+    const int force_wt = getenv("PASN_DWM_WT") ? atoi(getenv("PASN_DWM_WT")) : 0;
+    const int force_tc = getenv("PASN_DWM_TC") ? atoi(getenv("PASN_DWM_TC")) : 0;
+    double best = 1e30;
+    for (int wt = 2; wt <= 3; ++wt) {
+        if (force_wt && wt != force_wt) continue;
+        if (wt == 3 && d.sw == 2) continue;  // 7 input columns: the stride-2 WT = 3 instance spills 30 registers
+        const int nc = (wt - 1) * d.sw + 3;
+        const double per_frame = 27.0 * wt * 4 + 3.0 * nc * 8 + 54 + 3.0 * nc * 2 + 30.0 * wt + 60;
+        for (int tc = d.To; tc >= 4; tc = (tc + 1) / 2) {
+            if (force_tc && tc != force_tc && !(force_tc > d.To && tc == d.To)) continue;
+            const int nT = ceil_div(d.To, tc), strips = ceil_div(d.Wo, wt);
+            const long blocks = (long)d.N * ceil_div((long)nT * d.Ho * strips, g.R);
+            const double rounds = (double)ceil_div(blocks, 512);
+            const double frames = tc + (nT > 1 ? 2.0 * (nT - 1) / nT : 0.0);
+            const double t = rounds * frames * per_frame;
+            if (t < best) {
+                best = t;
+                g.WT = wt;
+                g.Tc = tc;
+            }
+            if (tc == 4) break;
+        }
     }
+    if (g.WT == 0) return DwMarchGeom{0, 0, 0, 0, 0, 0};
     g.strips = ceil_div(d.Wo, g.WT);
-    // split T (halo frames are recomputed) only while the grid is well short of 2 waves per SIMD: measured on the 7x7 and
-    // 14x14 layers, Tc = 8 beats both 16 (too few waves) and 4 (50 % halo work)
-    g.Tc = d.To;
-    int want = 1400;
-    if (const char* e = getenv("PASN_DWM_WAVES")) want = atoi(e) > 0 ? atoi(e) : want;
-    while (g.Tc > 2 && (long)d.N * ceil_div(d.To, g.Tc) * d.Ho * g.strips * g.CG < (long)want * 64) g.Tc = (g.Tc + 1) / 2;
-    if (const char* e = getenv("PASN_DWM_TC")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= d.To) g.Tc = v;
-    }
     g.bpc = ceil_div((long)ceil_div(d.To, g.Tc) * d.Ho * g.strips, g.R);
     if (dwm_lds_bytes(g.R, d.Cout_p) > 72 * 1024) return DwMarchGeom{0, 0, 0, 0, 0, 0};
     return g;
@@ -244,8 +261,9 @@ int launch_dw_march(const void* x, const float* w, const float* scale, const flo
 #define PASN_DWM(SW_, WT_)                                                                                           \
     hipLaunchKernelGGL((dwconv3d_march_kernel<SW_, WT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
                        (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc)
-    if (d.sw == 1 && g.WT == 4) PASN_DWM(1, 4);
+    if (d.sw == 1 && g.WT == 3) PASN_DWM(1, 3);
     else if (d.sw == 1) PASN_DWM(1, 2);
+    else if (g.WT == 3) PASN_DWM(2, 3);
     else PASN_DWM(2, 2);
 #undef PASN_DWM
     return check_launch("dwconv3d_march_kernel");
