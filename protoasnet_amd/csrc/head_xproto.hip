@@ -75,31 +75,59 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// grid N, 256 threads; a wave per prototype.
-__global__ __launch_bounds__(256) void xproto_finish_kernel(const float* __restrict__ ws, const float* __restrict__ protos,
-                                                            const float* __restrict__ fc_w, float* __restrict__ feat,
-                                                            float* __restrict__ sim, float* __restrict__ logits, int G, int P,
-                                                            int D, int K) {
+// grid N, 1024 threads (16 waves); a wave per prototype, a lane per 4 consecutive feature dims (D <= 1024).
+// Pure latency kernel (32 clips x 30 prototypes x G slabs of 256 floats): the slab sum is unrolled x8 so eight 16-byte
+// loads are in flight per lane (same summation order g = 0, 1, ... as a rolled loop), and the pooled feature stays in
+// registers for the norm and the dot product instead of being re-read from global memory.  (The first version walked
+// 8 prototypes per wave with rolled scalar loads: 216 us per launch.)
+// XF_MAXC = 4-float chunks per lane: D <= 256 (1024 threads) or D <= 1024 (256 threads: the registers of 4 chunks)
+template <int XF_MAXC, int THREADS>
+__global__ __launch_bounds__(THREADS) void xproto_finish_kernel(const float* __restrict__ ws, const float* __restrict__ protos,
+                                                             const float* __restrict__ fc_w, float* __restrict__ feat,
+                                                             float* __restrict__ sim, float* __restrict__ logits, int G, int P,
+                                                             int D, int K) {
     extern __shared__ __attribute__((aligned(16))) float sims[];  // [P]
     const int n = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int p = wave; p < P; p += 4) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int p = wave; p < P; p += nwaves) {
         float* fp = feat + ((long)n * P + p) * D;
         const float* pp = protos + (long)p * D;
+        const float* wp = ws + ((long)n * G * P + p) * D;  // slab g at + g * P * D
+        f32x4 fv[XF_MAXC], pv[XF_MAXC];
         float ssf = 0.0f, ssp = 0.0f;
-        for (int d = lane; d < D; d += 64) {
-            float v = 0.0f;
-            for (int g = 0; g < G; ++g) v += ws[(((long)n * G + g) * P + p) * D + d];
-            fp[d] = v;
-            ssf = fmaf(v, v, ssf);
-            const float q = pp[d];
-            ssp = fmaf(q, q, ssp);
+#pragma unroll
+        for (int ci = 0; ci < XF_MAXC; ++ci) {
+            const int d0 = ci * 256 + lane * 4;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            pv[ci] = v;
+            if (d0 < D) {  // D is a multiple of 4 (checked on the host)
+                int g = 0;
+                for (; g + 8 <= G; g += 8) {
+                    f32x4 t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(wp + (long)(g + u) * P * D + d0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v += t[u];
+                }
+                for (; g < G; ++g) v += *reinterpret_cast<const f32x4*>(wp + (long)g * P * D + d0);
+                *reinterpret_cast<f32x4*>(fp + d0) = v;
+                pv[ci] = *reinterpret_cast<const f32x4*>(pp + d0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ssf = fmaf(v[j], v[j], ssf);
+                    ssp = fmaf(pv[ci][j], pv[ci][j], ssp);
+                }
+            }
+            fv[ci] = v;
         }
         ssf = wave_sum(ssf);
         ssp = wave_sum(ssp);
         const float nf = fmaxf(sqrtf(ssf), 1e-8f), np = fmaxf(sqrtf(ssp), 1e-8f);
         float dot = 0.0f;
-        for (int d = lane; d < D; d += 64) dot = fmaf(fp[d] / nf, pp[d] / np, dot);
+#pragma unroll
+        for (int ci = 0; ci < XF_MAXC; ++ci)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dot = fmaf(fv[ci][j] / nf, pv[ci][j] / np, dot);
         dot = wave_sum(dot);
         if (lane == 0) {
             const float sv = (dot + 1.0f) / 2.0f;
@@ -228,8 +256,13 @@ extern "C" int pasn_xproto_head_fwd(const void* x, const void* a1, const float* 
 #undef PASN_POOL
     if ((rc = check_launch("xproto_pool_kernel"))) return rc;
     if (full) {
-        hipLaunchKernelGGL(xproto_finish_kernel, dim3(d->N), dim3(256), (size_t)d->P * sizeof(float), s, b_slabs, protos,
-                           fc_w, feat, sim, logits, G, d->P, d->D, d->K);
+        PASN_REQUIRE(d->D % 4 == 0 && d->D <= 1024, "prototype dimension must be a multiple of 4, at most 1024");
+        if (d->D <= 256)
+            hipLaunchKernelGGL((xproto_finish_kernel<1, 1024>), dim3(d->N), dim3(1024), (size_t)d->P * sizeof(float), s, b_slabs,
+                               protos, fc_w, feat, sim, logits, G, d->P, d->D, d->K);
+        else
+            hipLaunchKernelGGL((xproto_finish_kernel<4, 256>), dim3(d->N), dim3(256), (size_t)d->P * sizeof(float), s, b_slabs,
+                               protos, fc_w, feat, sim, logits, G, d->P, d->D, d->K);
         if ((rc = check_launch("xproto_finish_kernel"))) return rc;
     }
     return PASN_OK;
