@@ -76,15 +76,16 @@ __global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__
         }
     }
     frag A[KS];  // stationary weights: rows co + c, the whole K extent
-    {
-        // fragment-major: (tile ct, step ks) is 64 lanes x 16 bytes, contiguous; row-major: a 32-row gather.
-        // Unconditional loads from clamped (existing) fragments; steps beyond w_kc are zeroed after the staging barrier.
-        const int ctc = live ? ct : ctiles - 1;
-        const T* abase = w_frag ? w + ((long)ctc * nks * 64 + lane) * CH : w + (long)(ctc * 32 + c) * w_kc + h * CH;
-        const int astep = w_frag ? 64 * CH : KSTEP;
+    // fragment-major: (tile ct, step ks) is 64 lanes x 16 bytes, contiguous; row-major: a 32-row gather.
+    // Unconditional loads from clamped (existing) fragments; steps beyond w_kc are zeroed after the staging barrier.
+    // Wide layers (KS > 16) request only the first half here and the rest once the staging registers `xr` are dead
+    // (both halves live with xr is > 256 registers = one wave per SIMD); the second half lands under the first MFMAs.
+    constexpr int KA = KS > 16 ? KS / 2 : KS;
+    const int ctc = live ? ct : ctiles - 1;
+    const T* abase = w_frag ? w + ((long)ctc * nks * 64 + lane) * CH : w + (long)(ctc * 32 + c) * w_kc + h * CH;
+    const int astep = w_frag ? 64 * CH : KSTEP;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) A[ks] = load_frag<T>(abase + (size_t)(ks < nks ? ks : nks - 1) * astep);
-    }
+    for (int ks = 0; ks < KA; ++ks) A[ks] = load_frag<T>(abase + (size_t)(ks < nks ? ks : nks - 1) * astep);
     uint4 rr[2][2][sizeof(T) == 2 ? 1 : 2];
     if (res && live) {
 #pragma unroll
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__
         }
         *reinterpret_cast<uint4*>(xs + (size_t)prow * KP + pcol * CH) = xv;
     }
+#pragma unroll
+    for (int ks = KA; ks < KS; ++ks) A[ks] = load_frag<T>(abase + (size_t)(ks < nks ? ks : nks - 1) * astep);
     __syncthreads();
     if (!live) return;
 
@@ -212,7 +215,7 @@ static bool xt_pointwise(const pasn_conv_desc& d) {
 static int xt_ks(const pasn_conv_desc& d, int dtype) {
     const int nks = d.w_kc / (dtype == PASN_BF16 ? 16 : 8);
     if (dtype == PASN_BF16) {
-        const int opts[] = {6, 8, 12, 14, 16, 28};
+        const int opts[] = {4, 6, 8, 12, 14, 16, 28};
         for (int o : opts)
             if (nks <= o) return o;
         return 0;
@@ -227,7 +230,7 @@ static size_t xt_lds(const pasn_conv_desc& d, int dtype) {
 bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype) {
     if (const char* e = getenv("PASN_NO_XTILE"))
         if (e[0] == '1') return false;
-    if (!xt_pointwise(d) || d.Cin_p < 64) return false;
+    if (!xt_pointwise(d) || d.Cin_p < 32) return false;  // narrower layers: pwconv.hip (weights for ALL channels in registers)
     const int ch = dtype == PASN_BF16 ? 8 : 4;
     if (d.w_kc % (2 * ch) != 0 || d.w_kc < d.Cin_p || d.w_rows < ((d.Cout_p + 31) / 32) * 32) return false;
     if (2 * d.w_kc > 1024) return false;       // gate staging slots
@@ -262,6 +265,7 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
 #define PASN_XT_KS(XF_)                            \
     if (sizeof(T) == 2) {                          \
         switch (ks) {                              \
+            case 4: PASN_XT(4, XF_); break;        \
             case 6: PASN_XT(6, XF_); break;        \
             case 8: PASN_XT(8, XF_); break;        \
             case 12: PASN_XT(12, XF_); break;      \

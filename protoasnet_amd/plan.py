@@ -151,8 +151,8 @@ class PlanBuilder:
 
     def _note(self, kind: str, name: str, nbytes: int, flops: int) -> None:
         shape = ""
-        if self.keep and isinstance(self.keep[-1], ConvDesc) or any(isinstance(o, ConvDesc) for o in self.keep[-4:]):
-            d = [o for o in self.keep[-4:] if isinstance(o, ConvDesc)][-1]
+        if any(isinstance(o, ConvDesc) for o in self.keep[-6:]):
+            d = [o for o in self.keep[-6:] if isinstance(o, ConvDesc)][-1]
             shape = (f"{d.Cin}->{d.Cout} k{d.kt}{d.kh}{d.kw} s{d.st}{d.sh}{d.sw} "
                      f"in{d.Ti}x{d.Hi}x{d.Wi} out{d.To}x{d.Ho}x{d.Wo}")
         self.meta.append({"kind": kind, "kernel": name, "bytes": int(nbytes), "flops": int(flops), "shape": shape})
