@@ -54,7 +54,7 @@ typedef struct pasn_conv_desc {
     int32_t w_rows;           /* conv3d: rows of the packed weight / scale / bias arrays   */
     int32_t w_frag;           /* conv3d: 0 = w is [w_rows][taps][w_kc]; 1 = MFMA-fragment-major
                                  [w_rows/32][w_kc/KSTEP][2][32][CH] (KSTEP/CH = 16/8 bf16, 8/4 fp32):
-                                 only where pasn_conv3d_variant() reports 2500/2501           */
+                                 only where pasn_conv3d_variant() reports >= 2500           */
 } pasn_conv_desc;
 
 /*
@@ -99,7 +99,7 @@ int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const 
 int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
                     const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream);
 /* Which kernel instance pasn_conv3d_fwd picks for this geometry: 1000 + KS*10 + NT = pwconv_persist_kernel<dtype, KS, NT>
- * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); 2500 (+1 with in_swish) = pwconv_xtile_kernel<dtype, ..>
+ * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); 2500 + 2*KS (+1 with in_swish) = pwconv_xtile_kernel<dtype, KS, ..>
  * (1x1x1 stride-1 convs with Cin_p >= 64: whole-K position tiles in LDS); 2000 / 2001 = gemm_conv_kernel<dtype, pointwise /
  * windowed> (LDS-tiled implicit GEMM); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT> (output-channel /
  * position tiles per wave); 0 on a bad descriptor.  For profilers and benchmarks. */

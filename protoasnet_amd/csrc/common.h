@@ -40,6 +40,7 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
 
 // X-stationary pointwise conv for wide layers (pwconv_xtile.hip)
 bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype);
+int pw_xtile_ks(const pasn_conv_desc& d, int dtype);  // template k-steps of the instance picked
 template <typename T>
 int launch_pw_xtile(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                     void* y, const pasn_conv_desc& d, hipStream_t s);

@@ -773,7 +773,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype) {
     const PwGeom pg = pw_geom(*d, dtype);
     if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
     if (pw_xtile_applicable(*d, dtype))               // pwconv_xtile_kernel<dtype, input transform?>
-        return 2500 + ((d->in_swish != 0) ? 1 : 0);
+        return 2500 + 2 * pw_xtile_ks(*d, dtype) + ((d->in_swish != 0) ? 1 : 0);
     if (gemm_pw_applicable(*d, dtype))                // gemm_conv_kernel<dtype, pointwise?>
         return 2000 + ((d->kt * d->kh * d->kw == 1 && d->st * d->sh * d->sw == 1) ? 0 : 1);
     int NT, MT;

@@ -227,6 +227,8 @@ static size_t xt_lds(const pasn_conv_desc& d, int dtype) {
     return (size_t)XT_BM * (ks * kstep + ch) * (dtype == PASN_BF16 ? 2 : 4) + (size_t)(4 * 32 * XT_SROW + 2 * d.w_kc) * sizeof(float);
 }
 
+int pw_xtile_ks(const pasn_conv_desc& d, int dtype) { return xt_ks(d, dtype); }
+
 bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype) {
     if (const char* e = getenv("PASN_NO_XTILE"))
         if (e[0] == '1') return false;

@@ -237,7 +237,7 @@ class PlanBuilder:
             a = (wf.data_ptr(), a[1], a[2])
             d.w_frag = 1
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", f"pwconv_xtile_kernel<{self.tname},{'true' if (in_gate is not None or variant == 2501) else 'false'}>" if variant >= 2500 else
+        self._note("conv", f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if variant >= 2500 else
                    f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
                    f"pwconv_persist_kernel<{self.tname},{(variant - 1000) // 10},{variant % 10},{'true' if residual is not None else 'false'}>" if variant >= 1000 else
                    f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
