@@ -102,8 +102,9 @@ int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const floa
  * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); 2500 + 2*KS (+1 with in_swish) = pwconv_xtile_kernel<dtype, KS, ..>
  * (1x1x1 stride-1 convs with Cin_p >= 64: whole-K position tiles in LDS); 2000 / 2001 = gemm_conv_kernel<dtype, pointwise /
  * windowed> (LDS-tiled implicit GEMM); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT> (output-channel /
- * position tiles per wave); 0 on a bad descriptor.  For profilers and benchmarks. */
-int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype);
+ * position tiles per wave); 0 on a bad descriptor.  has_gate = whether `gate` will be non-NULL (the choice between the
+ * two pointwise kernels depends on it).  For profilers, benchmarks and the weight packing (w_frag). */
+int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int has_gate);
 
 /*
  * Depthwise convolution (groups = C), channels-last, fused scale/bias/activation; optionally also

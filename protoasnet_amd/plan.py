@@ -227,7 +227,7 @@ class PlanBuilder:
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, rb, gb, dref = x.buf, y.buf, (residual.buf if residual is not None else None), in_gate, ctypes.byref(d)
         self._use(xb, yb, rb, gb)
-        variant = int(self.lib.pasn_conv3d_variant(dref, self.code))
+        variant = int(self.lib.pasn_conv3d_variant(dref, self.code, int(in_gate is not None)))
         if variant >= 2500:
             # pwconv_xtile_kernel reads its weights as MFMA fragments: store them fragment-major, so a wave's fragment
             # load is one contiguous 1 KB run instead of a 32-row gather (the gather saturated the CU's address unit)
