@@ -215,7 +215,7 @@ static bool xt_pointwise(const pasn_conv_desc& d) {
 static int xt_ks(const pasn_conv_desc& d, int dtype) {
     const int nks = d.w_kc / (dtype == PASN_BF16 ? 16 : 8);
     if (dtype == PASN_BF16) {
-        const int opts[] = {4, 6, 8, 12, 14, 16, 28};
+        const int opts[] = {2, 4, 6, 8, 12, 14, 16, 28};
         for (int o : opts)
             if (nks <= o) return o;
         return 0;
@@ -232,7 +232,7 @@ int pw_xtile_ks(const pasn_conv_desc& d, int dtype) { return xt_ks(d, dtype); }
 bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype) {
     if (const char* e = getenv("PASN_NO_XTILE"))
         if (e[0] == '1') return false;
-    if (!xt_pointwise(d) || d.Cin_p < 32) return false;  // narrower layers: pwconv.hip (weights for ALL channels in registers)
+    if (!xt_pointwise(d) || d.Cin_p < (getenv("PASN_XT_MINK") ? atoi(getenv("PASN_XT_MINK")) : 32)) return false;  // narrower layers: pwconv.hip (weights for ALL channels in registers)
     const int ch = dtype == PASN_BF16 ? 8 : 4;
     if (d.w_kc % (2 * ch) != 0 || d.w_kc < d.Cin_p || d.w_rows < ((d.Cout_p + 31) / 32) * 32) return false;
     if (2 * d.w_kc > 1024) return false;       // gate staging slots
@@ -267,6 +267,7 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
 #define PASN_XT_KS(XF_)                            \
     if (sizeof(T) == 2) {                          \
         switch (ks) {                              \
+            case 2: PASN_XT(2, XF_); break;        \
             case 4: PASN_XT(4, XF_); break;        \
             case 6: PASN_XT(6, XF_); break;        \
             case 8: PASN_XT(8, XF_); break;        \
