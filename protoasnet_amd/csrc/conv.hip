@@ -818,13 +818,120 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     return PASN_ERR_ARG;
 }
 
+// Fast path of the gate (C <= 512, Cse <= 32, Cse % 4 == 0 -- every X3D width): the kernel is three dependent round trips
+// (pool partials -> fc1 weights -> fc2 weights) of a few KB each, one block per clip.  Here BOTH weight matrices are
+// requested into registers at kernel entry, before the pool reduction, so the three trips overlap; arithmetic and
+// summation order are those of se_gate_kernel (bit-identical gates).
+__global__ __launch_bounds__(256) void se_gate_fast_kernel(const float* __restrict__ pool, int pool_blocks, float inv_positions,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           float* __restrict__ gate, int C, int Cp, int Cse) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [Cp] mean, [Cse] hidden, [4][Cp] partial sums
+    float* mean = sm;
+    float* hid = sm + Cp;
+    float* part = sm + Cp + Cse;
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int JU = 8;
+    // fc1 weights of this wave's hidden units j = wave + 4u: rows j, columns lane + 64 k (k < 8 covers C <= 512)
+    float w1r[JU][8];
+#pragma unroll
+    for (int u = 0; u < JU; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = wave + 4 * u, ch = lane + 64 * k;
+            w1r[u][k] = w1[(j < Cse && ch < C) ? (long)j * C + ch : 0];
+        }
+    // fc2 rows of this thread's channels ch = tid + 256 r (r < 2 covers C <= 512), Cse <= 32 floats each
+    f32x4 w2r[2][8];
+    float b2r[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ch = threadIdx.x + 256 * r;
+        b2r[r] = b2[ch < C ? ch : 0];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            w2r[r][u] = *reinterpret_cast<const f32x4*>(w2 + ((ch < C && 4 * u < Cse) ? (long)ch * Cse + 4 * u : 0));
+    }
+    float b1r[JU];
+#pragma unroll
+    for (int u = 0; u < JU; ++u) b1r[u] = b1[wave + 4 * u < Cse ? wave + 4 * u : 0];
+
+    // mean over positions: thread = (channel quad, parity of the partial-row index); 16-byte loads, 8 in flight, summed in
+    // index order (fixed: bitwise reproducible).  The rolled per-64-channel loop of se_gate_kernel is one round trip per
+    // iteration -- 7 on the 432-channel stage, most of that kernel's 20 us.
+    {
+        const int quad = threadIdx.x & 127, par = threadIdx.x >> 7;
+        if (quad * 4 < Cp) {
+            const float* pp = pool + (long)n * pool_blocks * Cp + quad * 4;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            int q = par;
+            for (; q + 14 < pool_blocks; q += 16) {
+                f32x4 t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(pp + (long)(q + 2 * k) * Cp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += t[k];
+            }
+            for (; q < pool_blocks; q += 2) acc += *reinterpret_cast<const f32x4*>(pp + (long)q * Cp);
+            *reinterpret_cast<f32x4*>(part + par * Cp + quad * 4) = acc;
+        }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) mean[ch] = (part[ch] + part[Cp + ch]) * inv_positions;
+    __syncthreads();
+    {
+        float s[JU];
+#pragma unroll
+        for (int u = 0; u < JU; ++u) s[u] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = lane + 64 * k;
+            const float m = ch < C ? mean[ch] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < JU; ++u) s[u] = fmaf((ch < C && wave + 4 * u < Cse) ? w1r[u][k] : 0.0f, m, s[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+            float t = s[u];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+            const int j = wave + 4 * u;
+            if (lane == 0 && j < Cse) hid[j] = fmaxf(t + b1r[u], 0.0f);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ch = threadIdx.x + 256 * r;
+        if (ch < Cp) {
+            float g = 0.0f;
+            if (ch < C) {
+                float sacc = b2r[r];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (4 * u < Cse) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sacc = fmaf(w2r[r][u][e], hid[4 * u + e], sacc);
+                    }
+                g = sigmoidf_(sacc);
+            }
+            gate[(long)n * Cp + ch] = g;
+        }
+    }
+}
+
 extern "C" int pasn_se_gate_fwd(const float* pool_partial, int pool_blocks, int positions, const float* w1, const float* b1,
                                 const float* w2, const float* b2, float* gate, int N, int C, int Cp, int Cse, void* stream) {
     PASN_REQUIRE(pool_partial && w1 && b1 && w2 && b2 && gate, "null pointer");
     PASN_REQUIRE(N > 0 && C > 0 && Cp >= C && Cse > 0 && pool_blocks > 0 && positions > 0, "bad sizes");
     const size_t lds = (size_t)(5 * Cp + Cse) * sizeof(float);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, pool_partial, pool_blocks,
-                       1.0f / (float)positions, w1, b1, w2, b2, gate, C, Cp, Cse);
+    if (Cp <= 512 && Cse <= 32 && Cse % 4 == 0)
+        hipLaunchKernelGGL(se_gate_fast_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, pool_partial, pool_blocks,
+                           1.0f / (float)positions, w1, b1, w2, b2, gate, C, Cp, Cse);
+    else
+        hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, pool_partial, pool_blocks,
+                           1.0f / (float)positions, w1, b1, w2, b2, gate, C, Cp, Cse);
     return check_launch("se_gate_kernel");
 }
 
