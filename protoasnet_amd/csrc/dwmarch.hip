@@ -250,8 +250,7 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
         if (wt == 3 && d.sw == 2) continue;  // 7 input columns: the stride-2 WT = 3 instance spills 30 registers
         const int nc = (wt - 1) * d.sw + 3;
         const double per_frame = 27.0 * wt * 4 + 3.0 * nc * 8 + 54 + 3.0 * nc * 2 + 30.0 * wt + 60;
-        for (int tc = d.To; tc >= 4; tc = (tc + 1) / 2) {
-            if (force_tc && tc != force_tc && !(force_tc > d.To && tc == d.To)) continue;
+        for (int tc = force_tc ? (force_tc < d.To ? force_tc : d.To) : d.To; tc >= 1; tc = (tc + 1) / 2) {
             const int nT = ceil_div(d.To, tc), strips = ceil_div(d.Wo, wt);
             const long blocks = (long)d.N * ceil_div((long)nT * d.Ho * strips, g.R);
             const double rounds = (double)ceil_div(blocks, 512);
@@ -262,7 +261,7 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
                 g.WT = wt;
                 g.Tc = tc;
             }
-            if (tc == 4) break;
+            if (force_tc || tc <= 4) break;  // forced: that value only; otherwise To, To/2, ... down to ~4
         }
     }
     if (g.WT == 0) return DwMarchGeom{0, 0, 0, 0, 0, 0};

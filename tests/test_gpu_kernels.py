@@ -71,6 +71,13 @@ CONV_CASES = [
     (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), (4, 8, 8), "swish", False),   # generic 3x3x3
     (432, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 5, 5), "sigmoid", False),  # many k-steps, 6 output tiles (NT=3)
     (216, 216, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 6, 6), "abs", False),    # 7 output tiles (NT=4, 2 chunks)
+    # pwconv_xtile instances (whole-K position tiles in LDS; S >= 64 positions per clip); 75 / 130 rows = ragged last tile
+    (48, 216, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 5, 5), "relu", False),    # KS = 4, two channel groups
+    (96, 216, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 13, 5), "relu", False),   # KS = 6
+    (216, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0), (5, 4, 4), "relu", True),     # KS = 14 + residual, idle 4th wave
+    (192, 432, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 7, 7), "none", False),   # KS = 12, four channel groups
+    (432, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), (4, 4, 4), "relu", True),    # KS = 28 (split weight loads) + residual
+    (108, 48, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 8), "none", True),     # KS = 8: preferred over the persistent kernel
 ]
 
 
@@ -151,6 +158,65 @@ def test_conv3d_input_gate_swish(dtype, gate):
     assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, "gate+swish conv")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(216, 96), (432, 192), (96, 48)])
+def test_pointwise_gate_swish_wide(cin, cout, dtype):
+    """Wide project conv with the fused SE gate + Swish input transform (pwconv_xtile XF instances): three clips of 72
+    positions, so a 64-row tile straddles two clips and must pick each row's own gate vector."""
+    torch.manual_seed(cin)
+    n, thw = 3, (2, 6, 6)
+    x = torch.randn(n, cin, *thw)
+    g = torch.rand(n, cin)
+    conv = nn.Conv3d(cin, cout, 1, bias=False)
+    res = torch.randn(n, cout, *thw)
+    xr = _rt(x, dtype)
+    xin = xr * g[:, :, None, None, None]
+    xin = _rt(xin * torch.sigmoid(xin), dtype)
+    ref = F.relu(F.conv3d(xin, _rt(conv.weight.data, dtype)) + _rt(res, dtype)).detach()
+
+    from protoasnet_amd.plan import round_up
+
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    ra, rs = _cl_input(pb, res, dtype)
+    gt = torch.zeros(n, round_up(cin, 8), dtype=torch.float32, device=DEV)
+    gt[:, :cin] = g.to(DEV)
+    gbuf = pb._new_buf(gt.numel() * 4, external=True)
+    y = pb.conv(xa, conv.to(DEV), None, "relu", residual=ra, in_gate=gbuf, in_swish=True)
+    plan = pb.finish(xa, y)
+    plan.ptrs[gbuf] = gt.data_ptr()
+    plan.ptrs[ra.buf] = rs.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"wide gate+swish conv {cin}->{cout}")
+
+
+def test_conv_kernel_routing():
+    """The variant query names the instance the launch will use (bench.py / profiles key on it)."""
+    from protoasnet_amd import _lib
+    from protoasnet_amd._lib import ConvDesc
+
+    lib = _lib.lib()
+
+    def desc(cin, cout, s=784, n=2, in_swish=0):
+        rup = lambda v, m: (v + m - 1) // m * m
+        return ConvDesc(N=n, Ti=1, Hi=1, Wi=s, Cin=cin, Cin_p=rup(cin, 8), To=1, Ho=1, Wo=s, Cout=cout, Cout_p=rup(cout, 8),
+                        kt=1, kh=1, kw=1, st=1, sh=1, sw=1, pt=0, ph=0, pw=0, act=0, in_swish=in_swish,
+                        w_kc=rup(rup(cin, 8), 16), w_rows=rup(cout, 128), w_frag=0)
+
+    bf16 = _lib.dtype_code(torch.bfloat16)
+    v = lambda d, gate=0: int(lib.pasn_conv3d_variant(ctypes.byref(d), bf16, gate))
+    assert v(desc(24, 54)) == 1000 + 2 * 10 + 2          # persistent: weights in registers
+    assert v(desc(54, 24)) == 1000 + 4 * 10 + 1
+    assert v(desc(216, 96)) == 2500 + 2 * 14              # x-tile, KS = 14
+    assert v(desc(216, 96, in_swish=1), 1) == 2500 + 2 * 14 + 1
+    assert v(desc(432, 192)) == 2500 + 2 * 28
+    assert v(desc(48, 108)) == 2500 + 2 * 4               # untransformed, 4 channel tiles: x-tile preferred
+    assert v(desc(108, 48, in_swish=1), 1) == 1000 + 8 * 10 + 2  # gated: persistent kernel
+    assert v(desc(216, 96, s=16)) < 2500                  # fewer than 64 positions per clip: not the x-tile kernel
+
+
 FIRST_CASES = [
     (24, (1, 3, 3), (1, 2, 2), (0, 1, 1), (3, 17, 19), "none"),   # X3D stem conv_xy
     (45, (1, 7, 7), (1, 2, 2), (0, 3, 3), (2, 20, 22), "relu"),   # R(2+1)D stem
@@ -189,7 +255,49 @@ DW_CASES = [
     (54, (3, 3, 3), (1, 2, 2), (1, 1, 1), (3, 9, 9), "none", True),     # X3D conv_b stride 2 + SE pool
     (108, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 7, 6), "swish", False),  # X3D conv_b stride 1, Swish epilogue
     (432, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 13, 13), "none", True),  # widest stage, several pool blocks
+    (520, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 5, 5), "none", True),    # > 512 channels: strip kernel + generic SE gate
 ]
+
+
+@pytest.mark.parametrize("wt", [2, 3])
+@pytest.mark.parametrize("tc", [4, 8, 16])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_dwconv3d_march_variants(stride, tc, wt, monkeypatch):
+    """T-marching stencil: every (outputs per strip, T chunk) instance on a shape with T = 9 (chunk halos, a partial last
+    chunk), ragged W for both strip widths and SE partial sums; the cost model's own choice is covered by DW_CASES."""
+    monkeypatch.setenv("PASN_DWM_WT", str(wt))
+    monkeypatch.setenv("PASN_DWM_TC", str(tc))
+    dtype = torch.bfloat16
+    torch.manual_seed(11)
+    n, c, thw = 2, 56, (9, 11, 13) if stride == 1 else (9, 14, 22)
+    x = torch.randn(n, c, *thw)
+    conv = nn.Conv3d(c, c, 3, (1, stride, stride), 1, groups=c, bias=False)
+    bn = nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    pre = bn(conv(_rt(x, dtype))).detach()
+    ref = pre * torch.sigmoid(pre)
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    y, pooled = pb.dwconv(xa, conv.to(DEV), bn.to(DEV), "swish", pool=True)
+    assert "march" in pb.meta[-1]["kernel"] or stride == 2 and wt == 3  # stride 2 has no WT = 3 instance (falls back)
+    pool_buf, pool_blocks, _ = pooled
+    pb.bufs[pool_buf].external = True
+    plan = pb.finish(xa, y)
+    part = torch.empty(n, pool_blocks, y.Cp, dtype=torch.float32, device=DEV)
+    plan.ptrs[pool_buf] = part.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"march s{stride} tc{tc} wt{wt}")
+    # SE partial sums are taken before the activation, over every output position
+    got = part.sum(dim=1)[:, :c].cpu()
+    want = pre.sum(dim=(2, 3, 4))
+    assert_close(got, want, 2e-2 * float(want.abs().max()), 0, "SE partial sums")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
