@@ -729,7 +729,9 @@ static bool conv_desc_ok(const pasn_conv_desc* d) {
 // single channel tile; with >= 2 channel tiles and no input transform the X-tile kernel is faster (measured on the X3D-S
 // stage-3 layers: 48->108 29 vs 37 us, 108->48 33 vs 36.5 us).
 static bool prefer_xtile(const pasn_conv_desc& d, int dtype, bool has_gate) {
-    return pw_xtile_applicable(d, dtype) && !has_gate && !d.in_swish && (d.Cout_p + 31) / 32 >= 2;
+    if (!pw_xtile_applicable(d, dtype) || has_gate || d.in_swish) return false;
+    if (d.st != 1 || d.sh != 1 || d.sw != 1) return true;  // strided 1x1x1 (shortcut convs): the only specialised kernel
+    return (d.Cout_p + 31) / 32 >= 2;
 }
 
 extern "C" int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,

@@ -20,6 +20,22 @@
 
 namespace pasn {
 
+// Strided 1x1x1 convs (the X3D / R(2+1)D shortcut convs): output position m reads input row rowmap(m).
+struct XtStride {
+    int on;                 // 0: rows are contiguous (stride 1)
+    int To, Ho, Wo, Ti, Hi, Wi, st, sh, sw;
+};
+__device__ __forceinline__ long xt_row(const XtStride& g, long m) {
+    if (!g.on) return m;
+    const int wo = (int)(m % g.Wo);
+    long r = m / g.Wo;
+    const int ho = (int)(r % g.Ho);
+    r /= g.Ho;
+    const int to = (int)(r % g.To);
+    const long n = r / g.To;
+    return ((n * g.Ti + (long)to * g.st) * g.Hi + (long)ho * g.sh) * g.Wi + (long)wo * g.sw;
+}
+
 constexpr int XT_BM = 64;        // positions per tile
 constexpr int XT_SROW = 36;      // fp32 row stride of the 32 x 32 epilogue image (9 slots: odd)
 constexpr int XT_MAXP = 14;      // 16-byte pieces of a tile per thread (64 rows x 448 bf16 / 224 fp32 columns)
@@ -29,7 +45,7 @@ __global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
                                                            const T* __restrict__ res, const float* __restrict__ gate,
                                                            T* __restrict__ y, long M, int S, int Cin_p, int Cout, int Cout_p,
-                                                           int w_kc, int act, int in_swish, int gy, int w_frag) {
+                                                           int w_kc, int act, int in_swish, int gy, int w_frag, XtStride geo) {
     using frag = typename Traits<T>::frag;
     constexpr int CH = Traits<T>::CH;
     constexpr int KSTEP = Traits<T>::KSTEP;
@@ -63,7 +79,7 @@ __global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__
         // hipcc wait for each load before issuing the next -- 7-14 sequential round trips, measured 8-10 us per block
         const int p = tid + 256 * u, prow = p / PPR, pcol = p - prow * PPR;  // compile-time divisor
         const bool ok = m0 + prow < M && pcol * CH < Cin_p;
-        xr[u] = *reinterpret_cast<const uint4*>(x + (ok ? (m0 + prow) * Cin_p + pcol * CH : 0));
+        xr[u] = *reinterpret_cast<const uint4*>(x + (ok ? xt_row(geo, m0 + prow) * Cin_p + pcol * CH : 0));
     }
     float gv[XF ? 4 : 1];
     if (XF && gate) {  // gate rows of the (at most two: S >= 64) clips this tile touches; 2 * w_kc <= 1024 floats
@@ -207,9 +223,10 @@ __global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__
     }
 }
 
-static bool xt_pointwise(const pasn_conv_desc& d) {
-    return d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
+static bool xt_pointwise(const pasn_conv_desc& d) {  // any stride: a strided 1x1x1 conv is a row gather
+    return d.kt == 1 && d.kh == 1 && d.kw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
 }
+static bool xt_strided(const pasn_conv_desc& d) { return d.st != 1 || d.sh != 1 || d.sw != 1; }
 
 // Template k-steps covering w_kc (the LDS tile is zero padded to exactly KS steps); 0 = too wide for the registers.
 static int xt_ks(const pasn_conv_desc& d, int dtype) {
@@ -232,7 +249,10 @@ int pw_xtile_ks(const pasn_conv_desc& d, int dtype) { return xt_ks(d, dtype); }
 bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype) {
     if (const char* e = getenv("PASN_NO_XTILE"))
         if (e[0] == '1') return false;
-    if (!xt_pointwise(d) || d.Cin_p < (getenv("PASN_XT_MINK") ? atoi(getenv("PASN_XT_MINK")) : 32)) return false;  // narrower layers: pwconv.hip (weights for ALL channels in registers)
+    // narrow stride-1 layers belong to pwconv.hip (weights for ALL channels in registers); strided ones have no such kernel
+    const int mink = xt_strided(d) ? 16 : (getenv("PASN_XT_MINK") ? atoi(getenv("PASN_XT_MINK")) : 32);
+    if (!xt_pointwise(d) || d.Cin_p < mink) return false;
+    if (xt_strided(d) && d.in_swish) return false;  // narrower layers: pwconv.hip (weights for ALL channels in registers)
     const int ch = dtype == PASN_BF16 ? 8 : 4;
     if (d.w_kc % (2 * ch) != 0 || d.w_kc < d.Cin_p || d.w_rows < ((d.Cout_p + 31) / 32) * 32) return false;
     if (2 * d.w_kc > 1024) return false;       // gate staging slots
@@ -253,6 +273,8 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
     const dim3 grid((unsigned)ntiles * gy), block(256);  // block id = position tile * gy + channel group: groups of a tile adjacent
     const bool xf = gate != nullptr || d.in_swish != 0;
     const int ks = xt_ks(d, dtype);
+    XtStride geo = {xt_strided(d) ? 1 : 0, d.To, d.Ho, d.Wo, d.Ti, d.Hi, d.Wi, d.st, d.sh, d.sw};
+    if (geo.on) PASN_REQUIRE(gate == nullptr, "the SE gate transform is only fused into stride-1 pointwise convs");
 #define PASN_XT(KS_, XF_)                                                                                                  \
     do {                                                                                                                    \
         static bool attr = false;                                                                                           \
@@ -262,7 +284,7 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
             attr = true;                                                                                                    \
         }                                                                                                                   \
         hipLaunchKernelGGL((pwconv_xtile_kernel<T, KS_, XF_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,  \
-                           (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gy, d.w_frag); \
+                           (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gy, d.w_frag, geo); \
     } while (0)
 #define PASN_XT_KS(XF_)                            \
     if (sizeof(T) == 2) {                          \
