@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
     }
 
     uint4 xr[PPT], wr[PPT];
+    bool xok[PPT];
+    // ISSUE ONLY: raw, unconditional loads from clamped addresses.  The masks (image border / K tail) are applied in
+    // stash(), after the MFMAs of the current slice: a select on the loaded value right here makes hipcc wait
+    // (vmcnt(0)) for the prefetch BEFORE the MFMAs it was meant to hide under.
     auto fetch = [&](int kt) {  // global -> registers for K slice kt
         const int k = kt * G_BK + pc * CH;          // flattened K index of this thread's piece
         int tap = 0, ci = k;
@@ -98,24 +102,26 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
                 ok = ok && ti >= 0 && ti < d.Ti && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
                 off = ((((long)rn[i] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * Cin_p + ci;
             }
-            const uint4 v = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));  // unconditional load, select after
-            xr[i].x = ok ? v.x : 0u;
-            xr[i].y = ok ? v.y : 0u;
-            xr[i].z = ok ? v.z : 0u;
-            xr[i].w = ok ? v.w : 0u;
+            xok[i] = ok;
+            xr[i] = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));
             const int n = n0 + row;  // weight rows are zero padded to a multiple of 128
-            const uint4 wv = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
-            wr[i].x = k < Ktot ? wv.x : 0u;
-            wr[i].y = k < Ktot ? wv.y : 0u;
-            wr[i].z = k < Ktot ? wv.z : 0u;
-            wr[i].w = k < Ktot ? wv.w : 0u;
+            wr[i] = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
         }
     };
     auto stash = [&](int kt, int buf) {  // registers -> LDS (applying the fused input transform to X once)
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int row = prow0 + i * RSTEP;
-            uint4 xv = xr[i];
+            uint4 xv = xr[i], wv = wr[i];
+            const bool kin = kt * G_BK + pc * CH < Ktot;
+            xv.x = xok[i] ? xv.x : 0u;
+            xv.y = xok[i] ? xv.y : 0u;
+            xv.z = xok[i] ? xv.z : 0u;
+            xv.w = xok[i] ? xv.w : 0u;
+            wv.x = kin ? wv.x : 0u;
+            wv.y = kin ? wv.y : 0u;
+            wv.z = kin ? wv.z : 0u;
+            wv.w = kin ? wv.w : 0u;
             if (PW && xform) {
                 const int k = kt * G_BK + pc * CH;
                 if (rv[i] && k < Cin_p) {
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
                 }
             }
             *reinterpret_cast<uint4*>(xs + ((size_t)buf * G_BM + row) * ROW + pc * CH) = xv;
-            *reinterpret_cast<uint4*>(ws + ((size_t)buf * G_BN + row) * ROW + pc * CH) = wr[i];
+            *reinterpret_cast<uint4*>(ws + ((size_t)buf * G_BN + row) * ROW + pc * CH) = wv;
         }
     };
 
