@@ -52,8 +52,11 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
 
     // this thread's tile rows (fixed over the K loop): row = prow0 + i * RSTEP, piece column pc
     const int pc = tid % PIECES, prow0 = tid / PIECES;
-    long rm[PPT];
-    int rn[PPT], rt[PPT], rh[PPT], rw[PPT];
+    // Per row: the window ORIGIN (first tap) in input coordinates and as a flat position; per K slice only the tap offset
+    // is added.  (The first version redid the whole (n,t,h,w) x tap decode -- integer divisions and a 64-bit offset
+    // chain, ~200 VALU instructions -- for every 32-wide slice, against 256 cycles of MFMA.)
+    long rm[PPT], rbase[PPT];
+    int rt0[PPT], rh0[PPT], rw0[PPT];
     bool rv[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -61,13 +64,27 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
         rv[i] = rm[i] < M;
         if (!PW) {
             const long mm = rv[i] ? rm[i] : 0;
-            rw[i] = (int)(mm % d.Wo);
+            const int rw = (int)(mm % d.Wo);
             long r = mm / d.Wo;
-            rh[i] = (int)(r % d.Ho);
+            const int rh = (int)(r % d.Ho);
             r /= d.Ho;
-            rt[i] = (int)(r % d.To);
-            rn[i] = (int)(r / d.To);
+            const int rt = (int)(r % d.To);
+            const int rn = (int)(r / d.To);
+            rt0[i] = rt * d.st - d.pt;
+            rh0[i] = rh * d.sh - d.ph;
+            rw0[i] = rw * d.sw - d.pw;
+            rbase[i] = (((long)rn * d.Ti + rt0[i]) * d.Hi + rh0[i]) * d.Wi + rw0[i];
         }
+    }
+    // this thread's piece of slice kt is k = kt * G_BK + pc * CH = tap * kc + ci: decoded once, then advanced per slice
+    int f_tap = 0, f_ci = pc * CH, f_da = 0, f_db = 0, f_de = 0;
+    if (!PW) {
+        f_tap = f_ci / kc;
+        f_ci -= f_tap * kc;
+        f_da = f_tap / (d.kh * d.kw);
+        const int r2 = f_tap - f_da * d.kh * d.kw;
+        f_db = r2 / d.kw;
+        f_de = r2 - f_db * d.kw;
     }
 
     uint4 xr[PPT], wr[PPT];
@@ -75,21 +92,11 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
     // ISSUE ONLY: raw, unconditional loads from clamped addresses.  The masks (image border / K tail) are applied in
     // stash(), after the MFMAs of the current slice: a select on the loaded value right here makes hipcc wait
     // (vmcnt(0)) for the prefetch BEFORE the MFMAs it was meant to hide under.
-    auto fetch = [&](int kt) {  // global -> registers for K slice kt
-        const int k = kt * G_BK + pc * CH;          // flattened K index of this thread's piece
-        int tap = 0, ci = k;
-        if (!PW) {
-            tap = k / kc;
-            ci = k - tap * kc;
-        }
-        const bool kvalid = k < Ktot && ci < Cin_p;
-        int da = 0, db = 0, de = 0;
-        if (!PW) {
-            da = tap / (d.kh * d.kw);
-            const int r2 = tap - da * d.kh * d.kw;
-            db = r2 / d.kw;
-            de = r2 - db * d.kw;
-        }
+    auto fetch = [&](int kt) {  // global -> registers for K slice kt; called with kt = 0, 1, 2, ... in order
+        const int k = kt * G_BK + pc * CH;  // flattened K index of this thread's piece
+        const int ci = PW ? k : f_ci;
+        const bool kvalid = (PW ? k < Ktot : f_tap < taps) && ci < Cin_p;
+        const long tapoff = PW ? 0 : ((long)f_da * d.Hi + f_db) * d.Wi + f_de;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int row = prow0 + i * RSTEP;
@@ -98,14 +105,28 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
             if (PW) {
                 off = rm[i] * Cin_p + ci;
             } else {
-                const int ti = rt[i] * d.st - d.pt + da, hi = rh[i] * d.sh - d.ph + db, wi = rw[i] * d.sw - d.pw + de;
-                ok = ok && ti >= 0 && ti < d.Ti && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
-                off = ((((long)rn[i] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * Cin_p + ci;
+                ok = ok && (unsigned)(rt0[i] + f_da) < (unsigned)d.Ti && (unsigned)(rh0[i] + f_db) < (unsigned)d.Hi &&
+                     (unsigned)(rw0[i] + f_de) < (unsigned)d.Wi;
+                off = (rbase[i] + tapoff) * Cin_p + ci;
             }
             xok[i] = ok;
             xr[i] = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));
             const int n = n0 + row;  // weight rows are zero padded to a multiple of 128
             wr[i] = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
+        }
+        if (!PW) {  // advance (tap, ci) by one slice
+            f_ci += G_BK;
+            while (f_ci >= kc) {
+                f_ci -= kc;
+                ++f_tap;
+                if (++f_de == d.kw) {
+                    f_de = 0;
+                    if (++f_db == d.kh) {
+                        f_db = 0;
+                        ++f_da;
+                    }
+                }
+            }
         }
     };
     auto stash = [&](int kt, int buf) {  // registers -> LDS (applying the fused input transform to X once)
