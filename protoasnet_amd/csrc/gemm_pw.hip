@@ -87,8 +87,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
         f_de = r2 - f_db * d.kw;
     }
 
-    uint4 xr[PPT], wr[PPT];
+    uint4 xr[PPT], wr[PPT];  // slice being stashed next
     bool xok[PPT];
+    uint4 xr2[PPT], wr2[PPT];  // the slice after that: TWO slices of loads are in flight under the MFMAs
+    bool xok2[PPT];
     // ISSUE ONLY: raw, unconditional loads from clamped addresses.  The masks (image border / K tail) are applied in
     // stash(), after the MFMAs of the current slice: a select on the loaded value right here makes hipcc wait
     // (vmcnt(0)) for the prefetch BEFORE the MFMAs it was meant to hide under.
@@ -109,10 +111,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
                      (unsigned)(rw0[i] + f_de) < (unsigned)d.Wi;
                 off = (rbase[i] + tapoff) * Cin_p + ci;
             }
-            xok[i] = ok;
-            xr[i] = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));
+            xok2[i] = ok;
+            xr2[i] = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));
             const int n = n0 + row;  // weight rows are zero padded to a multiple of 128
-            wr[i] = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
+            wr2[i] = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
         }
         if (!PW) {  // advance (tap, ci) by one slice
             f_ci += G_BK;
@@ -127,6 +129,14 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
                     }
                 }
             }
+        }
+    };
+    auto shift = [&]() {  // stage 2 -> stage 1 (register moves; the loads keep flying)
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            xr[i] = xr2[i];
+            wr[i] = wr2[i];
+            xok[i] = xok2[i];
         }
     };
     auto stash = [&](int kt, int buf) {  // registers -> LDS (applying the fused input transform to X once)
@@ -171,11 +181,14 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
     fetch(0);
-    stash(0, 0);
+    shift();
+    if (nk > 1) fetch(1);
+    stash(0, 0);  // waits for slice 0 only (slice 1 was issued after it)
+    shift();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) fetch(kt + 1);  // in flight under the MFMAs below
+        if (kt + 2 < nk) fetch(kt + 2);  // slices kt+1 (stage 1) and kt+2 (stage 2) are in flight under the MFMAs below
         const T* xb = xs + ((size_t)buf * G_BM + wm * 64 + c) * ROW + h * CH;
         const T* wb = ws + ((size_t)buf * G_BN + wn * 64 + c) * ROW + h * CH;
 #pragma unroll
@@ -192,6 +205,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
                 for (int j = 0; j < 2; ++j) mma32(acc[i][j], a[i], b[j]);
         }
         if (kt + 1 < nk) stash(kt + 1, buf ^ 1);  // the other buffer was last read in iteration kt-1 (barrier below)
+        shift();
         __syncthreads();
     }
 
