@@ -89,6 +89,31 @@ def test_bf16_compute_tolerance(cfg, shape):
     assert float(rel) < 0.05, f"bf16 occurrence map mean relative error {float(rel):.3g}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_x3d_production_routes_vs_oracle(dtype):
+    """16 x 160 x 160 clips: every stage has >= 64 positions per clip and T = 16, so the launches take the same kernel
+    instances as the benchmark shape (T-marching stencil with T chunks, x-tile pointwise incl. gated / strided, fused stem)
+    -- the small shapes above fall back to the generic instances in the late stages."""
+    m = _gpu(CFG_VIDEO_X3D)
+    if dtype == torch.bfloat16:
+        m.set_compute_dtype(torch.bfloat16)
+    x = synth.echo_clips((2, 3, 16, 160, 160))
+    ref = oracle.nets.xprotonet_forward({k: v.cpu() for k, v in m.state_dict().items()}, x, arch="x3d_s")
+    with torch.no_grad():
+        logits, sim, occ = m(x.to(DEV))
+        kernels = {meta["kernel"].split("<")[0] for meta in m.cnn_backbone.plan_for(x.to(DEV).to(dtype)).meta}
+    if dtype == torch.bfloat16:
+        assert {"x3d_stem_kernel", "dwconv3d_march_kernel", "pwconv_xtile_kernel", "pwconv_persist_kernel"} <= kernels, kernels
+        assert_close(sim, ref["similarity"], 2e-2, 0, "bf16 similarity")
+        assert_close(logits, ref["logits"], 0.25, 0.05, "bf16 logits")
+        rel = (occ.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()
+        assert float(rel) < 0.05, f"bf16 occurrence map mean relative error {float(rel):.3g}"
+    else:
+        assert_close(occ, ref["occurrence_map"], 1e-3 * max(1.0, float(ref["occurrence_map"].max())), 1e-3, "occurrence_map")
+        assert_close(sim, ref["similarity"], 1e-3, 0, "similarity")
+        assert_close(logits, ref["logits"], 1e-3, 0, "logits")
+
+
 def test_module_surface_and_errors():
     m = _gpu(CFG_VIDEO_X3D)
     assert m.num_prototypes == 30 and m.num_classes == 3 and tuple(m.prototype_class_identity.shape) == (30, 3)
