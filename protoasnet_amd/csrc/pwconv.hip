@@ -77,6 +77,16 @@ __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict
     const long stride = (long)gridDim.x * 4;
     long tile = (long)blockIdx.x * 4 + wave;
     const bool xform = (gate != nullptr) || (in_swish != 0);
+    // clip of this lane's row, kept incrementally (one 64-bit division here instead of one per tile: the gated layers
+    // do 4-8 MFMAs per tile, a software division is of the same order)
+    long cn = 0;   // clip index of row m = tile * 32 + c
+    long crem = 0;  // m - cn * S
+    if (gate) {
+        const long m_first = tile * 32 + c;
+        cn = m_first / S;
+        crem = m_first - cn * S;
+    }
+    const long row_step = stride * 32;
 
     frag Bc[KS], Bn[KS];
     // ISSUE ONLY: unconditional loads from clamped (existing) addresses; rows beyond M / columns beyond Cin_p are zeroed
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict
         for (int ks = 0; ks < KS; ++ks)  // zero what load_rows clamped
             if (!(mv && ks * KSTEP + h * CH < Cin_p)) Bc[ks] = zero_frag<T>();
         if (xform) {  // x' = swish(x * gate[n][ci]), rounded back to the MFMA input type
-            const long n = mv ? m / S : 0;
+            const long n = mv ? cn : 0;
             const float* gp = gate ? (gate_rows ? gl : gate) + n * Cin_p + h * CH : nullptr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -187,6 +197,13 @@ __global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict
         __builtin_amdgcn_wave_barrier();  // the image is reused by this wave's next tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) Bc[ks] = Bn[ks];
+        if (gate) {  // advance the clip index to the next tile's row
+            crem += row_step;
+            while (crem >= S) {
+                crem -= S;
+                ++cn;
+            }
+        }
     }
 }
 
