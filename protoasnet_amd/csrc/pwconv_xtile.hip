@@ -40,8 +40,11 @@ constexpr int XT_BM = 64;        // positions per tile
 constexpr int XT_SROW = 36;      // fp32 row stride of the 32 x 32 epilogue image (9 slots: odd)
 constexpr int XT_MAXP = 14;      // 16-byte pieces of a tile per thread (64 rows x 448 bf16 / 224 fp32 columns)
 
-template <typename T, int KS, bool XF>
-__global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__ x, const T* __restrict__ w,
+// minimum waves per SIMD the allocator must keep: the grid is many uniform small blocks, so resident slots decide the
+// number of "rounds" (KS = 14 with residual came out ONE register over the 3-wave limit without this)
+template <typename T, int KS, bool XF, bool RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 4 : (KS <= 14 ? 3 : 2))))
+void pwconv_xtile_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
                                                            const T* __restrict__ res, const float* __restrict__ gate,
                                                            T* __restrict__ y, long M, int S, int Cin_p, int Cout, int Cout_p,
@@ -102,8 +105,8 @@ __global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__
     const int astep = w_frag ? 64 * CH : KSTEP;
 #pragma unroll
     for (int ks = 0; ks < KA; ++ks) A[ks] = load_frag<T>(abase + (size_t)(ks < nks ? ks : nks - 1) * astep);
-    uint4 rr[2][2][sizeof(T) == 2 ? 1 : 2];
-    if (res && live) {
+    uint4 rr[RES ? 2 : 1][2][sizeof(T) == 2 ? 1 : 2];  // compile-time: expand convs (no residual) pay no registers
+    if (RES && live) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void pwconv_xtile_kernel(const T* __restrict__
             if (m < M && n < Cout_p) {
                 float v[8];
                 load8(scr + row * XT_SROW + cg * 8, v);
-                if (res) {
+                if (RES) {
                     float r[8];
                     raw_to_f8<T>(rr[j][i], r);
 #pragma unroll
@@ -275,16 +278,21 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
     const int ks = xt_ks(d, dtype);
     XtStride geo = {xt_strided(d) ? 1 : 0, d.To, d.Ho, d.Wo, d.Ti, d.Hi, d.Wi, d.st, d.sh, d.sw};
     if (geo.on) PASN_REQUIRE(gate == nullptr, "the SE gate transform is only fused into stride-1 pointwise convs");
-#define PASN_XT(KS_, XF_)                                                                                                  \
+#define PASN_XT2(KS_, XF_, RES_)                                                                                                  \
     do {                                                                                                                    \
         static bool attr = false;                                                                                           \
         if (!attr) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_xtile_kernel<T, KS_, XF_>),                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_xtile_kernel<T, KS_, XF_, RES_>),               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        hipLaunchKernelGGL((pwconv_xtile_kernel<T, KS_, XF_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,  \
+        hipLaunchKernelGGL((pwconv_xtile_kernel<T, KS_, XF_, RES_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias, \
                            (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gy, d.w_frag, geo); \
+    } while (0)
+#define PASN_XT(KS_, XF_)                  \
+    do {                                   \
+        if (res) PASN_XT2(KS_, XF_, true); \
+        else PASN_XT2(KS_, XF_, false);    \
     } while (0)
 #define PASN_XT_KS(XF_)                            \
     if (sizeof(T) == 2) {                          \
@@ -311,6 +319,7 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
     }
 #undef PASN_XT_KS
 #undef PASN_XT
+#undef PASN_XT2
     return check_launch("pwconv_xtile_kernel");
 }
 
