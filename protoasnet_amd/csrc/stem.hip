@@ -12,11 +12,16 @@
 namespace pasn {
 
 template <typename TIN, typename T, int COP>
-__global__ __launch_bounds__(256) void x3d_stem_kernel(const TIN* __restrict__ x, const float* __restrict__ wxy,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void x3d_stem_kernel(const TIN* __restrict__ x, const float* __restrict__ wxy,
                                                        const float* __restrict__ wt, const float* __restrict__ scale,
                                                        const float* __restrict__ bias, T* __restrict__ y, pasn_conv_desc d) {
-    // weights / scale / bias are wave-uniform with compile-time offsets: the compiler reads them with s_load through the
-    // scalar cache and feeds them to v_fmac as SGPR operands -- no LDS traffic, no vector registers
+    // The 27 x COP spatial weights are wave-uniform with compile-time offsets: read with s_load through the scalar cache
+    // and fed to v_pk_fma as SGPR operands -- no LDS traffic, no vector registers.  The temporal weights + scale + bias
+    // (7 x COP floats) come from LDS as broadcast reads instead: as scalars they did not fit next to the spatial ones, and
+    // hipcc spilled them through VGPR lanes (252 v_readlane/v_writelane per frame for 120 FMAs).
+    __shared__ __attribute__((aligned(16))) float tl[7 * COP];  // [5 temporal taps | scale | bias][COP]
+    for (int i = threadIdx.x; i < 7 * COP; i += 256) tl[i] = i < 5 * COP ? wt[i] : (i < 6 * COP ? scale[i - 5 * COP] : bias[i - 6 * COP]);
+    __syncthreads();
     const long P = (long)d.N * d.Ho * d.Wo;
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
@@ -51,7 +56,6 @@ __global__ __launch_bounds__(256) void x3d_stem_kernel(const TIN* __restrict__ x
         int zo = 0;
         asm volatile("" : "+s"(zo));
         const float* wq = wxy + zo;
-        const float* wk = wt + zo;
         float acc[COP];
 #pragma unroll
         for (int c = 0; c < COP; ++c) acc[c] = 0.0f;
@@ -95,21 +99,23 @@ __global__ __launch_bounds__(256) void x3d_stem_kernel(const TIN* __restrict__ x
         // ---- temporal conv: output frame to = t - 2 from frames t-4 .. t = slots 0 .. 4 ----
         const int to = t - 2;
         if (to >= 0) {
+            int zv = 0;  // opaque per-frame zero in a VGPR: keeps the LDS reads inside the loop (hoisted: 168 registers)
+            asm volatile("" : "+v"(zv));
+            const float* tw = tl + zv;
             float o[COP];
 #pragma unroll
             for (int c = 0; c < COP; ++c) o[c] = 0.0f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                float wv[COP];
 #pragma unroll
-                for (int c = 0; c < COP; ++c) wv[c] = wk[k * COP + c];
-                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < COP; c += 4) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + k * COP + c);  // wave-uniform address: a broadcast
 #pragma unroll
-                for (int c = 0; c < COP; ++c) o[c] = fmaf((float)ring[k][c >> 3][c & 7], wv[c], o[c]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < 4; ++j) o[c + j] = fmaf((float)ring[k][(c + j) >> 3][(c + j) & 7], wv[j], o[c + j]);
+                }
             }
-            const float* sc = scale + zo;
-            const float* bi = bias + zo;
+            const float* sc = tw + 5 * COP;
+            const float* bi = tw + 6 * COP;
             T* yp = y + ((((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo) * COP;
 #pragma unroll
             for (int c = 0; c < COP; c += 8) {
