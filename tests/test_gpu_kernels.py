@@ -192,6 +192,36 @@ def test_pointwise_gate_swish_wide(cin, cout, dtype):
     assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"wide gate+swish conv {cin}->{cout}")
 
 
+def test_pointwise_gate_many_clips():
+    """72 clips x 108 channels: the gate tensor (31 KB x ...) no longer fits the persistent kernel's 32 KB LDS budget, so
+    the transform reads its gate rows from global memory instead (the other gate tests use the LDS-resident path)."""
+    dtype = torch.bfloat16
+    torch.manual_seed(5)
+    n, cin, cout, thw = 80, 108, 48, (1, 3, 3)
+    x = torch.randn(n, cin, *thw)
+    g = torch.rand(n, cin)
+    conv = nn.Conv3d(cin, cout, 1, bias=False)
+    xr = _rt(x, dtype)
+    xin = _rt((xr * g[:, :, None, None, None]) * torch.sigmoid(xr * g[:, :, None, None, None]), dtype)
+    ref = F.conv3d(xin, _rt(conv.weight.data, dtype)).detach()
+    from protoasnet_amd.plan import round_up
+
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    gt = torch.zeros(n, round_up(cin, 8), dtype=torch.float32, device=DEV)
+    gt[:, :cin] = g.to(DEV)
+    assert gt.numel() * 4 > 32 * 1024
+    gbuf = pb._new_buf(gt.numel() * 4, external=True)
+    y = pb.conv(xa, conv.to(DEV), None, "none", in_gate=gbuf, in_swish=True)
+    assert "persist" in pb.meta[-1]["kernel"]
+    plan = pb.finish(xa, y)
+    plan.ptrs[gbuf] = gt.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, "gate rows from global memory")
+
+
 def test_conv_kernel_routing():
     """The variant query names the instance the launch will use (bench.py / profiles key on it)."""
     from protoasnet_amd import _lib
