@@ -135,6 +135,10 @@ int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const f
  *            that query returns 0 when the geometry is not supported (caller then uses the two unfused calls).
  */
 int pasn_x3d_expand_dw_pool_blocks(const pasn_conv_desc* d, int dtype);
+/* Which fused kernel the call will use: 0 none (use the unfused calls -- the default: neither fused kernel beats them yet),
+ * 1 x3d_front_kernel (7x7 planes, bf16: expand conv into an fp32 LDS plane tile, T-marching stencil from it; PASN_FRONT=1),
+ * 2 x3d_expand_dw_kernel (LDS ring; PASN_FUSED=1). */
+int pasn_x3d_expand_dw_variant(const pasn_conv_desc* d, int dtype);
 int pasn_x3d_expand_dw_fwd(const void* x, const void* wa, const float* sa, const float* ba, const float* wb,
                            const float* sb, const float* bb, void* y, float* pool_partial, const pasn_conv_desc* d,
                            int dtype, void* stream);

@@ -38,6 +38,7 @@ SIGNATURES = {
     "pasn_dwconv3d_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_variant": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_x3d_expand_dw_variant": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_x3d_expand_dw_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_x3d_expand_dw_fwd": (c_int, [c_void_p] * 9 + [POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_se_gate_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -44,6 +44,13 @@ int pw_xtile_ks(const pasn_conv_desc& d, int dtype);  // template k-steps of the
 template <typename T>
 int launch_pw_xtile(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                     void* y, const pasn_conv_desc& d, hipStream_t s);
+// x3d_front.hip: fused expand conv + depthwise stencil for small spatial planes (bf16).  ok = 0: not covered.
+struct XfrontGeom {
+    int ok, ks, nT, ctiles, lds;
+};
+XfrontGeom x3d_front_geom(const pasn_conv_desc& d, int dtype);
+int launch_x3d_front(const void* x, const void* wa, const float* sa, const float* ba, const float* wb, const float* sb,
+                     const float* bb, void* y, float* pool, const pasn_conv_desc& d, const XfrontGeom& g, hipStream_t s);
 // LDS-tiled MFMA GEMM for large-K pointwise convs (gemm_pw.hip)
 bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype);
 // dwmarch.hip: T-marching depthwise 3x3x3 stencil (bf16).  WT = 0: geometry / dtype not covered.

@@ -403,8 +403,20 @@ static bool xd_desc_ok(const pasn_conv_desc* d) {
            d->Cin_p >= d->Cin && d->Cout_p >= d->Cout && d->Cin_p % 8 == 0 && d->Cout_p % 8 == 0;
 }
 
+extern "C" int pasn_x3d_expand_dw_variant(const pasn_conv_desc* d, int dtype) {
+    if (!xd_desc_ok(d) || (dtype != PASN_F32 && dtype != PASN_BF16)) return 0;
+    if (x3d_front_geom(*d, dtype).ok) return 1;  // x3d_front_kernel (7x7 planes, PASN_FRONT=1)
+    const char* e = getenv("PASN_FUSED");
+    if (!e || e[0] != '1') return 0;
+    return xd_geom(*d, dtype, xd_wt()).ok ? 2 : 0;  // x3d_expand_dw_kernel (opt-in)
+}
+
 extern "C" int pasn_x3d_expand_dw_pool_blocks(const pasn_conv_desc* d, int dtype) {
     if (!xd_desc_ok(d) || (dtype != PASN_F32 && dtype != PASN_BF16)) return 0;
+    {
+        const XfrontGeom f = x3d_front_geom(*d, dtype);
+        if (f.ok) return f.nT;
+    }
     // Opt-in until it beats the unfused pair everywhere (round-1 measurements: profiles/README.md).
     const char* e = getenv("PASN_FUSED");
     if (!e || e[0] != '1') return 0;
@@ -424,6 +436,10 @@ extern "C" int pasn_x3d_expand_dw_fwd(const void* x, const void* wa, const float
     PASN_REQUIRE(dtype == PASN_F32 || dtype == PASN_BF16, "unknown dtype");
     const int kstep = dtype == PASN_BF16 ? 16 : 8;
     PASN_REQUIRE(d->w_kc >= d->Cin_p && d->w_kc % kstep == 0 && d->w_rows >= d->Cout_p, "packed expand weight does not cover the geometry");
+    {
+        const XfrontGeom f = x3d_front_geom(*d, dtype);
+        if (f.ok) return launch_x3d_front(x, wa, sa, ba, wb, sb, bb, y, pool_partial, *d, f, (hipStream_t)stream);
+    }
     const int WT = xd_wt();
     const XdGeom g = xd_geom(*d, dtype, WT);
     if (!g.ok) {

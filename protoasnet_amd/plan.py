@@ -321,7 +321,8 @@ class PlanBuilder:
         xb, yb, pb = x.buf, y.buf, pool_buf
         self._use(xb, yb, pb)
         out_pos = y.N * y.positions
-        self._note("expand_dw", f"x3d_expand_dw_kernel<{self.tname},{s[1]}>",
+        fv = int(self.lib.pasn_x3d_expand_dw_variant(dref, self.code))
+        self._note("expand_dw", f"x3d_front_kernel<{kc // 16},{x.H}>" if fv == 1 else f"x3d_expand_dw_kernel<{self.tname},{s[1]}>",
                    (x.N * x.positions * x.C + out_pos * ci + ci * x.C) * self.es + (y.N * pool_blocks * ci * 4 if pool else 0),
                    2 * x.N * x.positions * ci * x.C + 2 * out_pos * ci * taps)
         self.ops.append(

@@ -138,10 +138,10 @@ def test_plan_shapes_and_arena(cfg, shape):
                 assert a.offset + a.nbytes <= b.offset or b.offset + b.nbytes <= a.offset, "live buffers overlap"
     assert plan.arena_bytes < (0.6 if cfg["base_architecture"] == "resnet18" else 0.35) * plan.naive_bytes
     n_ops = len(plan.ops)
-    # x3d: stem 2 + 26 blocks x (expand, depthwise, project) + 4 shortcuts + 15 SE gates (the fused expand+depthwise
-    # launch is opt-in via PASN_FUSED=1 and would make it 26 x 2)
-    # (the stem's two convs are one fused T-marching launch)
-    assert n_ops == {"x3d_s": 1 + 26 * (2 if os.environ.get("PASN_FUSED") == "1" else 3) + 4 + 15,"resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
+    # x3d: fused stem 1 + 26 blocks x (expand, depthwise, project) + 4 shortcuts + 15 SE gates; opt-in fused launches:
+    # PASN_FRONT=1 fuses expand + depthwise of the 6 stride-1 blocks of the 7x7 stage, PASN_FUSED=1 of all 26
+    fused = 26 if os.environ.get("PASN_FUSED") == "1" else (6 if os.environ.get("PASN_FRONT") == "1" else 0)
+    assert n_ops == {"x3d_s": 1 + 26 * 3 - fused + 4 + 15, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
 
 
 def test_packed_weight_layout():

@@ -386,6 +386,10 @@ FUSED_CASES = [
     (96, 216, 1, (3, 14, 14), "swish", False),  # channel-chunked (216 inner channels)
     (192, 432, 1, (2, 7, 7), "none", True),     # widest stage, many chunks, T = 2 (prologue-only ring)
     (96, 432, 2, (1, 14, 14), "swish", False),  # T = 1
+    # x3d_front_kernel (7x7 planes: expand conv into an fp32 LDS plane tile, stencil from it; opt-in, bf16)
+    (192, 432, 1, (16, 7, 7), "none", True),    # benchmark stage-5 shape: two T chunks, partial last channel tile, SE sums
+    (192, 432, 1, (9, 7, 7), "swish", False),   # partial second chunk (1 frame), Swish epilogue
+    (96, 216, 1, (3, 7, 7), "swish", True),     # single short chunk, K = 96
 ]
 
 
@@ -393,7 +397,8 @@ FUSED_CASES = [
 @pytest.mark.parametrize("case", FUSED_CASES)
 def test_x3d_expand_dw_fused(case, dtype, monkeypatch):
     """Fused expand(1x1x1)+BN+ReLU -> depthwise 3x3x3+BN(+Swish)(+SE sums) == the two unfused torch ops."""
-    monkeypatch.setenv("PASN_FUSED", "1")  # the fused launch is opt-in (profiles/README.md); this test always exercises it
+    monkeypatch.setenv("PASN_FUSED", "1")  # the fused launches are opt-in (profiles/README.md); this test always exercises them
+    monkeypatch.setenv("PASN_FRONT", "1")  # 7x7 planes take x3d_front_kernel, everything else x3d_expand_dw_kernel
     cin, ci, s, thw, act, pool = case
     torch.manual_seed(13)
     n = 2
