@@ -234,14 +234,22 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const int S = d.To * d.Ho * d.Wo;
     const long ntiles = (M + 31) / 32;
-    long blocks = (ntiles + 3) / 4;
-    // persistent: as many blocks as stay resident (NT = 4 instances hold ~200 VGPRs -> 2 waves per SIMD), each wave
-    // strides over the row tiles
-    const long cap = 256L * (g.xrow <= 2 ? 4 : 2);
-    if (blocks > cap) blocks = cap;
-    const dim3 grid((unsigned)blocks, 1), block(256);
+    const long want_blocks = (ntiles + 3) / 4;
+    // persistent: exactly as many blocks as stay RESIDENT for this instance and LDS size (asked from the runtime once per
+    // instance: a fixed guess put twice the resident number on the gated NT = 2 instance, whose second half then redid the
+    // weight / gate staging in a second round); each wave strides over the row tiles
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const dim3 block(256);
 #define PASN_PW2(KS_, NT_, RES_)                                                                                                   \
     do {                                                                                                                      \
+        int per_cu = 0;                                                                                                       \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pwconv_persist_kernel<T, KS_, NT_, RES_>, 256, lds) !=      \
+                hipSuccess || per_cu < 1)                                                                                     \
+            per_cu = 2;                                                                                                       \
+        long blocks = want_blocks < (long)n_cu * per_cu ? want_blocks : (long)n_cu * per_cu;                                  \
+        const dim3 grid((unsigned)blocks, 1);                                                                                 \
         if (lds > 64 * 1024) {                                                                                                \
             static bool attr = false;                                                                                         \
             if (!attr) {                                                                                                      \
