@@ -40,7 +40,7 @@ struct RawQuad<float> {
 };
 
 template <typename T, int KS, int NT, bool RES>
-__global__ __launch_bounds__(256) void pwconv_persist_kernel(const T* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 && NT == 4 && !RES) ? 3 : 1))) void pwconv_persist_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              const T* __restrict__ res, const float* __restrict__ gate,
                                                              T* __restrict__ y, long M, int S, int Cin_p, int Cout, int Cout_p,
