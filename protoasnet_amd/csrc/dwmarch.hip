@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                         psum[j] += v[j];
                     }
                     act_vec(v, d.act);
-                    mask_tail(v, d.Cout - cg * 8);
+                    if (d.Cout - cg * 8 < 8) mask_tail(v, d.Cout - cg * 8);  // only the last channel group has padding
                     store8(yrow + (long)wo * Cp, v);
                 }
             }
