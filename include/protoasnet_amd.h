@@ -98,6 +98,18 @@ int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const 
  */
 int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
                     const float* gate, void* y, const pasn_conv_desc* d, int dtype, void* stream);
+/*
+ * Two chained 1x1x1 convs on the same positions (bf16): y1 = act1(scale1 * (w1 . x') + bias1 + residual) with the optional
+ * fused input transform x' = swish(x * gate), then y2 = act2(scale2 * (w2 . y1) + bias2) computed from y1 while it is
+ * still on chip (y1 is written too).  The X3D pattern: a block's project conv (ResBlock.conv_c + BN + residual + ReLU)
+ * and the next block's expand conv (conv_a + BN + ReLU).  Both weights fragment-major (w_frag = 1).
+ * pasn_conv3d_pair_supported() says whether the geometry is covered; otherwise call pasn_conv3d_fwd twice.
+ */
+int pasn_conv3d_pair_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype);
+int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* scale1, const float* bias1, const void* residual,
+                         const float* gate, void* y1, const pasn_conv_desc* d1, const void* w2, const float* scale2,
+                         const float* bias2, void* y2, const pasn_conv_desc* d2, int dtype, void* stream);
+
 /* Which kernel instance pasn_conv3d_fwd picks for this geometry: 1000 + KS*10 + NT = pwconv_persist_kernel<dtype, KS, NT>
  * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); 2500 + 2*KS (+1 with in_swish) = pwconv_xtile_kernel<dtype, KS, ..>
  * (1x1x1 stride-1 convs with Cin_p >= 64: whole-K position tiles in LDS); 2000 / 2001 = gemm_conv_kernel<dtype, pointwise /

@@ -250,18 +250,34 @@ class X3DFeatures(_plan.HipTrunk):
     def build_plan(self, pb, x):
         x = pb.x3d_stem(x, self.stem.conv_xy, self.stem.conv_t, self.stem.bn)  # one T-marching launch (two if unsupported)
         for stage in self.stages:
-            for blk in stage:
+            blocks = list(stage)
+            pre = None  # this block's expand-conv output when the previous block's chained launch already made it
+            for i, blk in enumerate(blocks):
                 sc = x
                 if blk.shortcut is not None:
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
-                # expand conv + depthwise conv run as one launch: the 2.25x-wide tensor between them never reaches HBM
+                act_b = "none" if blk.se is not None else "swish"  # no gate between BN and Swish: the stencil applies Swish
+                if pre is not None:
+                    r = pb.dwconv(pre, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
+                else:  # (an opt-in fused launch keeps the 2.25x-wide tensor between the two convs out of HBM)
+                    r = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
+                gate = None
                 if blk.se is not None:
-                    y, pooled = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act="none", pool=True)
+                    y, pooled = r
                     gate = pb.se_gate(pooled, blk.se.fc1, blk.se.fc2)
-                    x = pb.conv(y, blk.conv_c, blk.bn_c, act="relu", residual=sc, in_gate=gate, in_swish=True)
-                else:  # no gate between BN and Swish: the stencil's epilogue applies Swish once
-                    y = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act="swish")
-                    x = pb.conv(y, blk.conv_c, blk.bn_c, act="relu", residual=sc)
+                else:
+                    y = r
+                # project conv; where the geometry allows, chained in ONE launch with the next block's expand conv
+                nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+                pair = None
+                if nxt is not None and nxt.shortcut is None:
+                    pair = pb.conv_pair(y, blk.conv_c, blk.bn_c, "relu", sc, nxt.conv_a, nxt.bn_a, "relu",
+                                        in_gate=gate, in_swish=blk.se is not None)
+                if pair is not None:
+                    x, pre = pair
+                else:
+                    x = pb.conv(y, blk.conv_c, blk.bn_c, act="relu", residual=sc, in_gate=gate, in_swish=blk.se is not None)
+                    pre = None
         return x
 
 

@@ -51,6 +51,11 @@ struct XfrontGeom {
 XfrontGeom x3d_front_geom(const pasn_conv_desc& d, int dtype);
 int launch_x3d_front(const void* x, const void* wa, const float* sa, const float* ba, const float* wb, const float* sb,
                      const float* bb, void* y, float* pool, const pasn_conv_desc& d, const XfrontGeom& g, hipStream_t s);
+// pwconv_xpair.hip: project conv of block i chained with the expand conv of block i+1 (bf16); 0 = not covered
+int pw_xpair_ks(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, int* ks2_out);
+int launch_pw_xpair(const void* x, const void* w1, const float* s1, const float* b1, const void* res, const float* gate, void* y1,
+                    const pasn_conv_desc& d1, const void* w2, const float* s2, const float* b2, void* y2,
+                    const pasn_conv_desc& d2, hipStream_t s);
 // LDS-tiled MFMA GEMM for large-K pointwise convs (gemm_pw.hip)
 bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype);
 // dwmarch.hip: T-marching depthwise 3x3x3 stencil (bf16).  WT = 0: geometry / dtype not covered.

@@ -778,6 +778,21 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     return launch_conv3d<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
 }
 
+extern "C" int pasn_conv3d_pair_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype) {
+    if (!conv_desc_ok(d1) || !conv_desc_ok(d2)) return 0;
+    return pw_xpair_ks(*d1, *d2, dtype, nullptr) != 0;
+}
+
+extern "C" int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* scale1, const float* bias1, const void* residual,
+                                    const float* gate, void* y1, const pasn_conv_desc* d1, const void* w2, const float* scale2,
+                                    const float* bias2, void* y2, const pasn_conv_desc* d2, int dtype, void* stream) {
+    PASN_REQUIRE(x && w1 && w2 && y1 && y2 && residual, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(d1) && conv_desc_ok(d2), "bad geometry");
+    PASN_REQUIRE(dtype == PASN_BF16 && d1->w_frag == 1 && d2->w_frag == 1, "bf16 with fragment-major weights only");
+    PASN_REQUIRE(pw_xpair_ks(*d1, *d2, dtype, nullptr) != 0, "pair not covered (pasn_conv3d_pair_supported returns 0)");
+    return launch_pw_xpair(x, w1, scale1, bias1, residual, gate, y1, *d1, w2, scale2, bias2, y2, *d2, (hipStream_t)stream);
+}
+
 extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int has_gate) {
     if (!conv_desc_ok(d)) return 0;
     const PwGeom pg = prefer_xtile(*d, dtype, has_gate != 0) ? PwGeom{0, 0, 0, 0} : pw_geom(*d, dtype);

@@ -252,6 +252,51 @@ class PlanBuilder:
         )
         return y
 
+    def conv_pair(self, x: Act, conv1: nn.Module, norm1: Optional[nn.Module], act1: str, residual: Act,
+                  conv2: nn.Module, norm2: Optional[nn.Module], act2: str, in_gate: Optional[int] = None,
+                  in_swish: bool = False):
+        """Two chained 1x1x1 convs in ONE launch (X3D: a block's project conv + the next block's expand conv): returns
+        (y1, y2), or None when the chained kernel does not cover the geometry (the caller then emits the two convs)."""
+        if x.planar or self.dtype != torch.bfloat16 or conv1.groups != 1 or conv2.groups != 1:
+            return None
+        one = (1, 1, 1)
+        for cv in (conv1, conv2):
+            if _triple(cv.kernel_size, 1) != one or _triple(cv.stride, 1) != one or _triple(cv.padding, 0) != (0, 0, 0):
+                return None
+        y1 = self._out_act(x, conv1.out_channels, one, one, (0, 0, 0))
+        w1, kc1, rows1 = pack_conv_weight(conv1.weight, x.Cp, self.dtype)
+        d1 = self._desc(x, y1, one, one, (0, 0, 0), act1, in_swish, kc1, rows1)
+        mid = Act(y1.N, y1.T, y1.H, y1.W, y1.C, y1.Cp, -1)
+        y2 = self._out_act(mid, conv2.out_channels, one, one, (0, 0, 0))
+        w2, kc2, rows2 = pack_conv_weight(conv2.weight, y1.Cp, self.dtype)
+        d2 = self._desc(mid, y2, one, one, (0, 0, 0), act2, False, kc2, rows2)
+        if not int(self.lib.pasn_conv3d_pair_supported(ctypes.byref(d1), ctypes.byref(d2), self.code)):
+            self.bufs[y1.buf].nbytes = ALIGN  # never used
+            self.bufs[y2.buf].nbytes = ALIGN
+            return None
+        assert (residual.N, residual.T, residual.H, residual.W, residual.Cp) == (y1.N, y1.T, y1.H, y1.W, y1.Cp)
+        frag = lambda wp, rows, kc: wp.view(rows // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+        w1f, w2f = frag(w1, rows1, kc1), frag(w2, rows2, kc2)
+        d1.w_frag = d2.w_frag = 1
+        s1, b1 = fold_norm(norm1, conv1.bias, y1.C, rows1, self.device)
+        s2, b2 = fold_norm(norm2, conv2.bias, y2.C, rows2, self.device)
+        self.keep += [w1f, w2f, s1, b1, s2, b2]
+        fn, code = self.lib.pasn_conv3d_pair_fwd, self.code
+        a = tuple(t.data_ptr() for t in (w1f, s1, b1, w2f, s2, b2))
+        xb, rb, gb, y1b, y2b = x.buf, residual.buf, in_gate, y1.buf, y2.buf
+        r1, r2 = ctypes.byref(d1), ctypes.byref(d2)
+        self._use(xb, rb, gb, y1b, y2b)
+        pos = y1.N * y1.positions
+        self._note("conv_pair", f"pwconv_xpair_kernel<{max(8, kc1 // 16 + kc1 // 16 % 2)},{kc2 // 16 + kc2 // 16 % 2},"
+                                f"{'true' if (in_gate is not None or in_swish) else 'false'}>",
+                   (pos * (x.C + 2 * y1.C + y2.C) + y1.C * x.C + y2.C * y1.C) * self.es + (x.N * x.C * 4 if in_gate is not None else 0),
+                   2 * pos * (y1.C * x.C + y2.C * y1.C))
+        self.ops.append(
+            lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[rb], ptrs[gb] if gb is not None else 0, ptrs[y1b], r1,
+                                           a[3], a[4], a[5], ptrs[y2b], r2, code, st))
+        )
+        return y1, y2
+
     def dwconv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, pool: bool = False):
         assert not x.planar and conv.groups == conv.in_channels == conv.out_channels == x.C
         k, s, p = _triple(conv.kernel_size, 1), _triple(conv.stride, 1), _triple(conv.padding, 0)

@@ -222,6 +222,65 @@ def test_pointwise_gate_many_clips():
     assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, "gate rows from global memory")
 
 
+@pytest.mark.parametrize("gate", [False, True])
+@pytest.mark.parametrize("c0,c1,c2", [(216, 96, 216), (108, 48, 108)])
+def test_conv_pair_chained(c0, c1, c2, gate, monkeypatch):
+    """Project conv (+BN + residual + ReLU, optional SE gate + Swish on its input) chained with the next expand conv
+    (+BN + ReLU) in one launch == the two torch convs; three clips of 72 positions (a tile straddles two clips), M not a
+    multiple of 64."""
+    monkeypatch.setenv("PASN_XPAIR_ALL", "1")  # also the narrow (stage-3) instance, off by default
+    dtype = torch.bfloat16
+    torch.manual_seed(c0 + gate)
+    n, thw = 3, (2, 6, 6)
+    x = torch.randn(n, c0, *thw)
+    res = torch.randn(n, c1, *thw)
+    g = torch.rand(n, c0) if gate else None
+    conv1, conv2 = nn.Conv3d(c0, c1, 1, bias=False), nn.Conv3d(c1, c2, 1, bias=False)
+    bn1, bn2 = nn.BatchNorm3d(c1), nn.BatchNorm3d(c2)
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.5, 1.5)
+    bn1.eval(), bn2.eval()
+    xin = _rt(x, dtype)
+    if gate:
+        xin = xin * g[:, :, None, None, None]
+        xin = _rt(xin * torch.sigmoid(xin), dtype)
+    y1 = F.relu(bn1(F.conv3d(xin, _rt(conv1.weight.data, dtype))) + _rt(res, dtype)).detach()
+    y2 = F.relu(bn2(F.conv3d(_rt(y1, dtype), _rt(conv2.weight.data, dtype)))).detach()
+
+    from protoasnet_amd.plan import round_up
+
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    ra, rs = _cl_input(pb, res, dtype)
+    gbuf = gt = None
+    if gate:
+        gt = torch.zeros(n, round_up(c0, 8), dtype=torch.float32, device=DEV)
+        gt[:, :c0] = g.to(DEV)
+        gbuf = pb._new_buf(gt.numel() * 4, external=True)
+    pair = pb.conv_pair(xa, conv1.to(DEV), bn1.to(DEV), "relu", ra, conv2.to(DEV), bn2.to(DEV), "relu", in_gate=gbuf, in_swish=gate)
+    assert pair is not None and "xpair" in pb.meta[-1]["kernel"]
+    o1, o2 = pair
+    pb.bufs[o1.buf].external = True
+    plan = pb.finish(xa, o2)
+    out1 = torch.empty(n, *thw, o1.Cp, dtype=dtype, device=DEV)
+    plan.ptrs[o1.buf] = out1.data_ptr()
+    plan.ptrs[ra.buf] = rs.data_ptr()
+    if gate:
+        plan.ptrs[gbuf] = gt.data_ptr()
+    out2 = plan.run(xs)
+    torch.cuda.synchronize()
+    atol, rtol = _tols(dtype)
+    assert_close(_from_cl(out1, c1), y1, atol * max(1.0, float(y1.abs().max())), rtol, "chained pair: block output")
+    assert_close(_from_cl(out2, c2), y2, atol * max(1.0, float(y2.abs().max())), rtol, "chained pair: expand output")
+    for o, c in ((out1, c1), (out2, c2)):
+        if o.shape[-1] > c:
+            assert float(o[..., c:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
 def test_conv_kernel_routing():
     """The variant query names the instance the launch will use (bench.py / profiles key on it)."""
     from protoasnet_amd import _lib
