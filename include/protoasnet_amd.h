@@ -244,6 +244,83 @@ int pasn_push_ppnet_update(const float* dist, const void* z, const int64_t* labe
                            int class_specific, float* best_dist, int64_t* best_index, float* best_patch, int B, int P, int S,
                            int D, int Dp, int dtype, int64_t index_base, void* stream);
 
+/* =====================================================================================================================
+ * Training path (train-mode forward with batch statistics + backward).  The reference trains through the same modules
+ * (`loss.backward()` through forward / compute_occurence_map: Video_XProtoNet_e2e.py:118-141, XProtoNet_e2e.py); these
+ * entry points are what an autograd.Function under that nn.Module surface calls.  A conv + norm + activation "unit" is
+ *     y = conv(x)            (pasn_conv3d_fwd / pasn_dwconv3d_fwd / pasn_first_conv_fwd with scale = 1, bias = 0, no activation)
+ *     stat = batch statistics of y                                                        (pasn_bn_stats_fwd)
+ *     a = act((y * sc + sh + residual) * gate)                                            (pasn_affine_act_fwd)
+ * and its backward is pasn_unit_bwd_reduce (+ pasn_bn_bwd_apply), the conv's dgrad (the forward conv kernels with the
+ * transposed weight, pasn_scatter_strided for strided 1x1x1 convs, pasn_dwconv3d_dgrad) and its wgrad
+ * (pasn_conv3d_wgrad / pasn_first_conv_wgrad / pasn_dwconv3d_wgrad).  Tensors are channels-last rows [N][S][Cp] in `dtype`;
+ * statistics, reductions and parameter gradients are fp32; every reduction except the split-K of pasn_conv3d_wgrad /
+ * pasn_first_conv_wgrad (fp32 atomics) has a fixed summation order.
+ * ===================================================================================================================== */
+
+/* Row chunks per clip used by the reduction passes below: their `ws` is fp32 [N][chunks][2][Cp]. */
+int pasn_train_chunks(int N, int S, int Cp);
+
+/* torch.nn.BatchNorm{2,3}d, training=True (resnet_features.py:140,180; every norm layer of the trunks): per-channel batch
+ * mean / biased variance of y, running-estimate update (unbiased variance, `momentum`), and the affine folded to
+ *   stat : fp32 [4][Cp] = (mean, invstd, sc = gamma*invstd, sh = beta - mean*sc)        (channels >= C: zeros)
+ *   pool_u : fp32 [N][Cp] or NULL -- per-clip mean over positions of y*sc + sh (the squeeze-excite pool)
+ *   gamma / beta / running_* : fp32 [C] or NULL */
+int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* stat, float* pool_u, int N, int S, int C, int Cp, int dtype, void* stream);
+
+/* a = act((y*sc + sh + residual) * gate[n][c]);  residual (dtype [N][S][Cp]) and gate (fp32 [N][Cp]) may be NULL.
+ * A unit without a norm layer passes stat = (0, 1, 1, bias). */
+int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S, int C, int Cp,
+                        int act, int dtype, void* stream);
+
+/* One backward pass over a unit, IN PLACE on d (the gradient w.r.t. the unit's output a):
+ *   mode 0:  d <- d * act'(y*sc + sh + residual);   coef = (sum d / R, sum d*yhat / R), dgamma = sum d*yhat, dbeta = sum d
+ *   mode 1:  d <- d * act'((y*sc + sh) * gate);     ws partials of sum_s d*(y*sc + sh) per clip (gradient of the gate)
+ *   mode 2:  d <- d * gate + add[n][c];             coef / dgamma / dbeta as mode 0
+ * (yhat = (y - mean) * invstd, R = N*S; after mode 0 the buffer d is also the gradient of `residual`.) */
+int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const float* stat, const void* residual, const float* gate, const float* add,
+                         float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int act, int dtype, void* stream);
+
+/* Batch-norm input gradient: dy = sc * (d - coef[0] - yhat * coef[1]);  dy may alias d. */
+int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp, int dtype,
+                      void* stream);
+
+/* Squeeze-excite backward: from the mode-1 partials `ws` and the pooled input `pool_u`, through sigmoid / fc2 / ReLU / fc1:
+ *   add : fp32 [N][Cp] = dpool / S (the term mode 2 adds);  dw1 [Cse][C], db1 [Cse], dw2 [C][Cse], db2 [C]
+ *   pn  : workspace of pasn_se_bwd_workspace_floats(N, C, Cse) floats */
+size_t pasn_se_bwd_workspace_floats(int N, int C, int Cse);
+int pasn_se_gate_bwd(const float* ws, const float* pool_u, const float* w1, const float* b1, const float* w2, const float* b2, float* add,
+                     float* pn, float* dw1, float* db1, float* dw2, float* db2, int N, int S, int C, int Cp, int Cse, void* stream);
+
+/* dst[n][t*st][h*sh][w*sw][:] (+)= src[n][t][h][w][:] with src [N][To][Ho][Wo][Cin_p], dst [N][Ti][Hi][Wi][Cin_p]; without
+ * `accumulate` every other element of dst is zeroed (the input gradient of a strided 1x1x1 conv; zero insertion). */
+int pasn_scatter_strided(const void* src, void* dst, const pasn_conv_desc* d, int accumulate, int dtype, void* stream);
+int pasn_add_inplace(void* a, const void* b, size_t elements, int dtype, void* stream);
+
+/* Weight gradients.  dw is fp32 in the PARAMETER layout and must be zeroed by the caller for the two MFMA kernels:
+ *   pasn_conv3d_wgrad      dw [Cout][Cin][kt*kh*kw]  += sum_rows dy[row][co] * x[in(row, tap)][ci]
+ *   pasn_first_conv_wgrad  dw [Cout][3][kh*kw]       (x planar in_dtype [N][3][T][Hi][Wi])
+ *   pasn_dwconv3d_wgrad    dw [C][kt*kh*kw]          (kh*kw <= 9; ws of pasn_dwconv3d_wgrad_workspace_floats(d) floats)
+ * pasn_dwconv3d_dgrad: dx[n,ti,hi,wi,c] = sum_taps dy[n,to,ho,wo,c] * w[tap][c], w fp32 [taps][Cp] as for pasn_dwconv3d_fwd. */
+int pasn_conv3d_wgrad(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int dtype, void* stream);
+int pasn_first_conv_wgrad(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int in_dtype, int dtype, void* stream);
+size_t pasn_dwconv3d_wgrad_workspace_floats(const pasn_conv_desc* d);
+int pasn_dwconv3d_wgrad(const void* x, const void* dy, float* ws, float* dw, const pasn_conv_desc* d, int dtype, void* stream);
+int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, const pasn_conv_desc* d, int dtype, void* stream);
+
+/* Head B tail in training (Video_XProtoNet.py:82-98): z = add-on output [N][S][Dp], r = occurrence-module output BEFORE the
+ * abs [N][S][Pp] (both dtype) -> occ fp32 [N][P][S], feat fp32 [N][P][D], sim fp32 [N][P], logits fp32 [N][K].
+ * Backward: dlogits [N][K], optional dsim [N][P] and docc [N][P][S] (NULL = none) -> dz, dr (dtype), dprotos [P][D],
+ * dfc_w [K][P]; dfeat fp32 [N][P][D] is scratch.
+ * z == NULL selects the occurrence-map-only mode of compute_occurence_map (Video_XProtoNet.py:100-109): forward writes occ
+ * alone, backward is dr = sign(r) * docc (every other pointer but r / occ / docc / dr may be NULL). */
+int pasn_xproto_tail_fwd(const void* z, const void* r, const float* protos, const float* fc_w, float* occ, float* feat, float* sim,
+                         float* logits, const pasn_xproto_desc* d, int dtype, void* stream);
+int pasn_xproto_tail_bwd(const void* z, const void* r, const float* protos, const float* fc_w, const float* feat, const float* sim,
+                         const float* dlogits, const float* dsim, const float* docc, float* dfeat, void* dz, void* dr, float* dprotos,
+                         float* dfc_w, const pasn_xproto_desc* d, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,9 +18,26 @@ import torch.nn.functional as F
 BN_EPS = 1e-5  # torch.nn.BatchNorm{2,3}d default, never overridden by the reference
 
 
+BN_MOMENTUM = 0.1  # torch default
+_TRAIN = [False]
+
+
+class train_mode:
+    """``with train_mode():`` -- norm layers use batch statistics and update the running estimates in ``sd`` in place, as
+    ``model.train()`` does in the reference's training epochs (src/agents/Video_XProtoNet_e2e.py:118)."""
+
+    def __enter__(self):
+        self._old = _TRAIN[0]
+        _TRAIN[0] = True
+
+    def __exit__(self, *exc):
+        _TRAIN[0] = self._old
+
+
 def _bn(sd: Mapping[str, torch.Tensor], p: str, x: torch.Tensor) -> torch.Tensor:
     return F.batch_norm(
-        x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS
+        x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], _TRAIN[0],
+        BN_MOMENTUM if _TRAIN[0] else 0.0, BN_EPS
     )
 
 

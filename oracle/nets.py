@@ -42,3 +42,14 @@ def compute_occurence_map(sd, x, arch="resnet18", last_layer_num=-3):
     """src/models/XProtoNet.py:69-73, src/models/Video_XProtoNet.py:100-104."""
     feat = backbones.trunk(arch, sd, "cnn_backbone.", x, last_layer_num)
     return heads.occurrence_map_abs(sd, feat)
+
+
+def xprotonet_train_forward(sd, x, arch="x3d_s", last_layer_num=-3, occurrence_only=False):
+    """The same passes in TRAIN mode with autograd enabled: what ``loss.backward()`` differentiates in the reference's
+    training loop (src/agents/Video_XProtoNet_e2e.py:118-141; ``compute_occurence_map`` with gradients at src/loss/loss.py:302).
+    Running statistics in ``sd`` are updated in place."""
+    with backbones.train_mode():
+        feat = backbones.trunk(arch, sd, "cnn_backbone.", x, last_layer_num)
+    if occurrence_only:
+        return {"occurrence_map": heads.occurrence_map_abs(sd, feat)}
+    return heads.xproto_head(sd, feat, contract=True)

@@ -52,6 +52,23 @@ SIGNATURES = {
     "pasn_xproto_head_workspace_bytes": (c_size_t, [POINTER(XProtoDesc), c_int]),
     "pasn_xproto_head_fwd": (c_int, [c_void_p] * 17 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_push_xproto_update": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int64, c_void_p]),
+    # ---- training path
+    "pasn_train_chunks": (c_int, [c_int, c_int, c_int]),
+    "pasn_bn_stats_fwd": (c_int, [c_void_p] * 6 + [c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pasn_affine_act_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "pasn_unit_bwd_reduce": (c_int, [c_int] + [c_void_p] * 10 + [c_int] * 6 + [c_void_p]),
+    "pasn_bn_bwd_apply": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "pasn_se_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "pasn_se_gate_bwd": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
+    "pasn_scatter_strided": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
+    "pasn_add_inplace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "pasn_conv3d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_first_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
+    "pasn_dwconv3d_wgrad_workspace_floats": (c_size_t, [POINTER(ConvDesc)]),
+    "pasn_dwconv3d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_dwconv3d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_xproto_tail_fwd": (c_int, [c_void_p] * 8 + [POINTER(XProtoDesc), c_int, c_void_p]),
+    "pasn_xproto_tail_bwd": (c_int, [c_void_p] * 14 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_push_ppnet_update": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
 }
 

@@ -281,6 +281,19 @@ class X3DFeatures(_plan.HipTrunk):
         return x
 
 
+    def build_train(self, tb, x):
+        """Training pass (batch-statistics norm, every unit's raw conv output and activation kept for the backward)."""
+        e = tb.unit(x, self.stem.conv_xy, None, "none", kind="first")
+        x = tb.unit(e, self.stem.conv_t, self.stem.bn, "relu", kind="dw")
+        for stage in self.stages:
+            for blk in stage:
+                sc = x if blk.shortcut is None else tb.unit(x, blk.shortcut.conv, blk.shortcut.bn, "none")
+                a = tb.unit(x, blk.conv_a, blk.bn_a, "relu")
+                b = tb.unit(a, blk.conv_b, blk.bn_b, "swish", kind="dw", se=blk.se)
+                x = tb.unit(b, blk.conv_c, blk.bn_c, "relu", residual=sc)
+        return x
+
+
 def x3d_s(pretrained: bool = False, **kwargs) -> X3DFeatures:
     if pretrained:
         raise RuntimeError("no pretrained X3D weights exist for this build (no network); use pretrained=False")

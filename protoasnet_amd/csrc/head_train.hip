@@ -1,0 +1,237 @@
+// head_train.hip -- training-mode tail of head B (XProtoNet / Video_XProtoNet): occurrence-weighted pooling, cosine
+// similarity, last layer, and their backward.  The 1x1x1 conv chains in front of it run on the conv kernels; what is left
+// is small (N*P*D*S MACs) and HBM/latency-bound, so these are plain reduction kernels with a fixed summation order.
+//
+// Forward  (Video_XProtoNet.py:82-98, XProtoNet.py:51-67):
+//   occ[n][p][s] = |r[n][s][p]|,  F[n][p][d] = sum_s occ[n][p][s] * z[n][s][d],
+//   sim[n][p] = (cos(F[n][p], proto[p]) + 1) / 2   (each vector divided by max(norm, 1e-8)),  logits = sim . W^T
+// Backward: autograd's derivative of the same expressions, given dlogits, an optional extra dsim (cluster / separation
+// losses act on the similarities) and an optional extra docc (the occurrence-map losses).
+#include "common.h"
+
+namespace pasn {
+
+constexpr float COS_EPS = 1e-8f;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    // 256 threads; result broadcast to every thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xproto_pool_fwd_kernel(const T* __restrict__ z, const T* __restrict__ r, float* __restrict__ occ,
+                                                              float* __restrict__ F, int S, int D, int Dp, int P, int Pp) {
+    const int n = blockIdx.x, p0 = blockIdx.y * 8;
+    const T* zn = z + (size_t)n * S * Dp;
+    const T* rn = r + (size_t)n * S * Pp;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        float rv[8];
+        load8(rn + (size_t)s * Pp + p0, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (p0 + j < P) occ[((size_t)n * P + p0 + j) * S + s] = fabsf(rv[j]);
+    }
+    if (z == nullptr) return;  // occurrence map only (compute_occurence_map)
+    for (int dd = threadIdx.x; dd < D; dd += 256) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll 4
+        for (int s = 0; s < S; ++s) {
+            float rv[8];
+            load8(rn + (size_t)s * Pp + p0, rv);
+            const float zv = (float)zn[(size_t)s * Dp + dd];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(fabsf(rv[j]), zv, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (p0 + j < P) F[((size_t)n * P + p0 + j) * D + dd] = acc[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void xproto_tail_fwd_kernel(const float* __restrict__ F, const float* __restrict__ protos,
+                                                              const float* __restrict__ fc_w, float* __restrict__ sim, float* __restrict__ logits,
+                                                              int D, int P, int K) {
+    __shared__ float red[4];
+    __shared__ float sims[256];
+    const int n = blockIdx.x;
+    for (int p = 0; p < P; ++p) {
+        float dot = 0.0f, nf = 0.0f, np = 0.0f;
+        for (int dd = threadIdx.x; dd < D; dd += 256) {
+            const float f = F[((size_t)n * P + p) * D + dd], q = protos[(size_t)p * D + dd];
+            dot = fmaf(f, q, dot);
+            nf = fmaf(f, f, nf);
+            np = fmaf(q, q, np);
+        }
+        dot = block_sum(dot, red);
+        nf = block_sum(nf, red);
+        np = block_sum(np, red);
+        if (threadIdx.x == 0) {
+            const float c = dot / (fmaxf(sqrtf(nf), COS_EPS) * fmaxf(sqrtf(np), COS_EPS));
+            const float sv = 0.5f * (c + 1.0f);
+            sims[p] = sv;
+            sim[(size_t)n * P + p] = sv;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float a = 0.0f;
+        for (int p = 0; p < P; ++p) a = fmaf(sims[p], fc_w[(size_t)k * P + p], a);
+        logits[(size_t)n * K + k] = a;
+    }
+}
+
+// one block per prototype: dF[:, p, :], dproto[p, :], dfc_w[:, p]
+__global__ __launch_bounds__(256) void xproto_tail_bwd_kernel(const float* __restrict__ F, const float* __restrict__ protos,
+                                                              const float* __restrict__ fc_w, const float* __restrict__ sim,
+                                                              const float* __restrict__ dlogits, const float* __restrict__ dsim,
+                                                              float* __restrict__ dF, float* __restrict__ dprotos, float* __restrict__ dfc_w, int N,
+                                                              int D, int P, int K) {
+    __shared__ float red[4];
+    const int p = blockIdx.x;
+    float np = 0.0f;
+    for (int dd = threadIdx.x; dd < D; dd += 256) {
+        const float q = protos[(size_t)p * D + dd];
+        np = fmaf(q, q, np);
+    }
+    np = block_sum(np, red);
+    const float nP = fmaxf(sqrtf(np), COS_EPS);
+    const bool p_clamped = sqrtf(np) < COS_EPS;
+    float dq[2] = {0.0f, 0.0f};  // dproto accumulators for d = tid, tid + 256
+    for (int n = 0; n < N; ++n) {
+        float dot = 0.0f, nf = 0.0f;
+        for (int dd = threadIdx.x; dd < D; dd += 256) {
+            const float f = F[((size_t)n * P + p) * D + dd], q = protos[(size_t)p * D + dd];
+            dot = fmaf(f, q, dot);
+            nf = fmaf(f, f, nf);
+        }
+        dot = block_sum(dot, red);
+        nf = block_sum(nf, red);
+        const float nF = fmaxf(sqrtf(nf), COS_EPS);
+        const bool f_clamped = sqrtf(nf) < COS_EPS;
+        float ds = dsim ? dsim[(size_t)n * P + p] : 0.0f;
+        for (int k = 0; k < K; ++k) ds = fmaf(dlogits[(size_t)n * K + k], fc_w[(size_t)k * P + p], ds);
+        const float dc = 0.5f * ds;
+        const float inv = 1.0f / (nF * nP);
+        int slot = 0;
+        for (int dd = threadIdx.x; dd < D; dd += 256, ++slot) {
+            const float f = F[((size_t)n * P + p) * D + dd], q = protos[(size_t)p * D + dd];
+            // c = dot / (nF nP); a clamped norm is a constant
+            const float gf = q * inv - (f_clamped ? 0.0f : dot * f * inv / (nF * nF));
+            const float gq = f * inv - (p_clamped ? 0.0f : dot * q * inv / (nP * nP));
+            dF[((size_t)n * P + p) * D + dd] = dc * gf;
+            if (slot < 2) dq[slot] = fmaf(dc, gq, dq[slot]);
+        }
+    }
+    int slot = 0;
+    for (int dd = threadIdx.x; dd < D; dd += 256, ++slot)
+        if (slot < 2) dprotos[(size_t)p * D + dd] = dq[slot];
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float a = 0.0f;
+        for (int n = 0; n < N; ++n) a = fmaf(dlogits[(size_t)n * K + k], sim[(size_t)n * P + p], a);
+        dfc_w[(size_t)k * P + p] = a;
+    }
+}
+
+constexpr int PB_ROWS = 16;
+
+// dz[n][s][d] = sum_p dF[n][p][d] |r[n][s][p]|;   dr[n][s][p] = sign(r) (sum_d dF[n][p][d] z[n][s][d] + docc[n][p][s])
+template <typename T>
+__global__ __launch_bounds__(256) void xproto_pool_bwd_kernel(const T* __restrict__ z, const T* __restrict__ r, const float* __restrict__ dF,
+                                                              const float* __restrict__ docc, T* __restrict__ dz, T* __restrict__ dr, int S, int D,
+                                                              int Dp, int P, int Pp) {
+    extern __shared__ float sm[];
+    float* zt = sm;                   // [PB_ROWS][D]
+    float* rt = zt + PB_ROWS * D;     // [PB_ROWS][Pp]  (signed)
+    const int n = blockIdx.x, s0 = blockIdx.y * PB_ROWS;
+    const int rows = min(PB_ROWS, S - s0);
+    const bool full = z != nullptr;  // false: occurrence map only, dr = sign(r) * docc
+    if (full)
+        for (int i = threadIdx.x; i < PB_ROWS * D; i += 256) {
+            const int row = i / D, dd = i % D;
+            zt[i] = row < rows ? (float)z[((size_t)n * S + s0 + row) * Dp + dd] : 0.0f;
+        }
+    for (int i = threadIdx.x; i < PB_ROWS * Pp; i += 256) {
+        const int row = i / Pp, p = i % Pp;
+        rt[i] = (row < rows && p < P) ? (float)r[((size_t)n * S + s0 + row) * Pp + p] : 0.0f;
+    }
+    __syncthreads();
+    const float* dFn = dF + (size_t)n * P * D;
+    for (int dd = threadIdx.x; full && dd < Dp; dd += 256) {
+        float acc[PB_ROWS];
+#pragma unroll
+        for (int i = 0; i < PB_ROWS; ++i) acc[i] = 0.0f;
+        if (dd < D) {
+            for (int p = 0; p < P; ++p) {
+                const float f = dFn[(size_t)p * D + dd];
+#pragma unroll
+                for (int i = 0; i < PB_ROWS; ++i) acc[i] = fmaf(f, fabsf(rt[i * Pp + p]), acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB_ROWS; ++i)
+            if (i < rows) dz[((size_t)n * S + s0 + i) * Dp + dd] = (T)acc[i];
+    }
+    const int row = threadIdx.x >> 4, pl = threadIdx.x & 15;
+    for (int p = pl; p < Pp; p += 16) {
+        float a = 0.0f;
+        if (p < P && row < rows) {
+            const float* f = dFn + (size_t)p * D;
+            for (int dd = 0; full && dd < D; ++dd) a = fmaf(f[dd], zt[row * D + dd], a);
+            if (docc) a += docc[((size_t)n * P + p) * S + s0 + row];
+            const float rv = rt[row * Pp + p];
+            a = rv > 0.0f ? a : (rv < 0.0f ? -a : 0.0f);
+        }
+        if (row < rows) dr[((size_t)n * S + s0 + row) * Pp + p] = (T)a;
+    }
+}
+
+}  // namespace pasn
+
+using namespace pasn;
+
+extern "C" int pasn_xproto_tail_fwd(const void* z, const void* r, const float* protos, const float* fc_w, float* occ, float* feat,
+                                    float* sim, float* logits, const pasn_xproto_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(r && occ && d, "null pointer");
+    PASN_REQUIRE(z == nullptr || (protos && fc_w && feat && sim && logits), "null pointer (only the occurrence-map mode, z == NULL, may omit them)");
+    PASN_REQUIRE(d->Dp % 8 == 0 && d->Pp % 8 == 0 && d->P <= 256 && d->P <= d->Pp && d->D <= d->Dp, "bad head extents (P <= 256)");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(d->N, d->Pp / 8);
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(xproto_pool_fwd_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)z, (const __bf16*)r, occ, feat, d->S, d->D, d->Dp,
+                           d->P, d->Pp);
+    else
+        hipLaunchKernelGGL(xproto_pool_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)z, (const float*)r, occ, feat, d->S, d->D, d->Dp, d->P,
+                           d->Pp);
+    if (z) hipLaunchKernelGGL(xproto_tail_fwd_kernel, dim3(d->N), dim3(256), 0, s, feat, protos, fc_w, sim, logits, d->D, d->P, d->K);
+    return check_launch("xproto_tail_fwd");
+}
+
+extern "C" int pasn_xproto_tail_bwd(const void* z, const void* r, const float* protos, const float* fc_w, const float* feat, const float* sim,
+                                    const float* dlogits, const float* dsim, const float* docc, float* dfeat, void* dz, void* dr,
+                                    float* dprotos, float* dfc_w, const pasn_xproto_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(r && dr && d, "null pointer");
+    PASN_REQUIRE(z ? (protos && fc_w && feat && sim && dlogits && dfeat && dz && dprotos && dfc_w) : (docc != nullptr),
+                 "null pointer (the occurrence-map mode, z == NULL, needs only r, docc, dr)");
+    PASN_REQUIRE(d->Dp % 8 == 0 && d->Pp % 8 == 0 && d->P <= 256 && d->D <= 512, "bad head extents (P <= 256, D <= 512)");
+    const size_t lds = ((size_t)PB_ROWS * d->D + (size_t)PB_ROWS * d->Pp) * sizeof(float);
+    PASN_REQUIRE(lds <= 64 * 1024, "head tile above the LDS budget");
+    hipStream_t s = (hipStream_t)stream;
+    if (z)
+        hipLaunchKernelGGL(xproto_tail_bwd_kernel, dim3(d->P), dim3(256), 0, s, feat, protos, fc_w, sim, dlogits, dsim, dfeat, dprotos, dfc_w, d->N, d->D,
+                       d->P, d->K);
+    const dim3 grid(d->N, ceil_div(d->S, PB_ROWS));
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(xproto_pool_bwd_kernel<__bf16>, grid, dim3(256), lds, s, (const __bf16*)z, (const __bf16*)r, dfeat, docc, (__bf16*)dz,
+                           (__bf16*)dr, d->S, d->D, d->Dp, d->P, d->Pp);
+    else
+        hipLaunchKernelGGL(xproto_pool_bwd_kernel<float>, grid, dim3(256), lds, s, (const float*)z, (const float*)r, dfeat, docc, (float*)dz,
+                           (float*)dr, d->S, d->D, d->Dp, d->P, d->Pp);
+    return check_launch("xproto_tail_bwd");
+}

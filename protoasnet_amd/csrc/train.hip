@@ -1,0 +1,594 @@
+// train.hip -- the elementwise / reduction half of the training path: batch-statistics norm, activation forward and
+// backward, squeeze-excite backward, strided scatter.  All HBM-bound passes over channels-last rows [N][S][Cp];
+// a thread owns 8 channels of a row, a block's threads tile (row lane, channel group) so that a wave reads whole rows
+// back to back, and every reduction is two-stage with a fixed summation order (bitwise reproducible gradients).
+//
+// Reference semantics: torch.nn.BatchNorm{2,3}d in train mode (biased batch variance for normalisation, unbiased for
+// the running estimate, momentum 0.1) as instantiated at resnet_features.py:140,180 and by every trunk the reference
+// trains (agents call model.train(): Video_XProtoNet_e2e.py:118); autograd's derivative of the same expressions.
+#include "common.h"
+
+namespace pasn {
+
+struct RowGeom {
+    int CG, CGb, RL, chunks, rows_per_chunk;
+};
+
+static RowGeom row_geom(int N, int S, int Cp) {
+    RowGeom g;
+    g.CG = Cp / 8;
+    int b = 1;
+    while (b < g.CG) b <<= 1;
+    g.CGb = b;
+    g.RL = 256 / b;
+    const int want = std::max(1, 1024 / std::max(1, N));
+    const int maxc = std::max(1, S / (g.RL * 4));
+    g.chunks = std::min(want, maxc);
+    g.rows_per_chunk = ceil_div(S, g.chunks);
+    g.chunks = ceil_div(S, g.rows_per_chunk);
+    return g;
+}
+
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case PASN_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+        case PASN_ACT_SIGMOID: {
+            const float s = sigmoidf_(u);
+            return s * (1.0f - s);
+        }
+        case PASN_ACT_SWISH: {
+            const float s = sigmoidf_(u);
+            return s * (1.0f + u * (1.0f - s));
+        }
+        case PASN_ACT_ABS: return u > 0.0f ? 1.0f : (u < 0.0f ? -1.0f : 0.0f);
+        default: return 1.0f;
+    }
+}
+
+// Sum the per-thread 8-channel accumulators `acc[W][8]` over the row lanes of the block (fixed order) and store them
+// at out[w * Cp + cg*8 + j].
+template <int W>
+__device__ __forceinline__ void block_reduce_rows(float (&acc)[W][8], float* red, float* out, int Cp, int CG, int CGb) {
+    const int tid = threadIdx.x, RL = 256 / CGb;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[w][j];
+        __syncthreads();
+        for (int t = tid; t < CGb * 8; t += 256) {
+            const int cg = t >> 3, j = t & 7;
+            if (cg < CG) {
+                float s = 0.0f;
+                for (int rl = 0; rl < RL; ++rl) s += red[(rl * CGb + cg) * 8 + j];
+                out[(size_t)w * Cp + cg * 8 + j] = s;
+            }
+        }
+    }
+}
+
+// ---- batch statistics ---------------------------------------------------------------------------------------------
+// ws[n][chunk][2][Cp]: sum(y - k), sum((y - k)^2) with the shift k[c] = y[0][0][c] (keeps the variance free of
+// cancellation when |mean| >> std).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ y, float* __restrict__ ws, int S, int Cp,
+                                                               int CG, int CGb, int rows_per_chunk, int chunks) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    float acc[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.0f;
+    if (cg < CG) {
+        float k[8];
+        load8(y + cg * 8, k);
+        const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
+        const T* base = y + (size_t)n * S * Cp + cg * 8;
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += RL) {
+            float v[8];
+            load8(base + (size_t)r * Cp, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = v[j] - k[j];
+                acc[0][j] += dlt;
+                acc[1][j] = fmaf(dlt, dlt, acc[1][j]);
+            }
+        }
+    }
+    block_reduce_rows<2>(acc, red, ws + ((size_t)n * chunks + ch) * 2 * Cp, Cp, CG, CGb);
+}
+
+// One block per 16 channels; 16 "parts" share the partial sums of a clip, combined in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ y, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          float momentum, float eps, float* __restrict__ stat, float* __restrict__ pool_u,
+                                                          int N, int S, int C, int Cp, int chunks) {
+    __shared__ float red[2][16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool live = c < Cp;
+    float t1 = 0.0f, t2 = 0.0f;
+    const float k = live ? (float)y[c] : 0.0f;
+    float mean = 0.0f, sc = 0.0f, sh = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: totals; pass 1: per-clip pool (needs sc / sh)
+        if (pass == 1 && pool_u == nullptr) break;
+        for (int n = 0; n < N; ++n) {
+            float a1 = 0.0f, a2 = 0.0f;
+            if (live)
+                for (int ch = part; ch < chunks; ch += 16) {
+                    const float* p = ws + ((size_t)n * chunks + ch) * 2 * Cp + c;
+                    a1 += p[0];
+                    a2 += p[Cp];
+                }
+            __syncthreads();
+            red[0][part][cl] = a1;
+            red[1][part][cl] = a2;
+            __syncthreads();
+            if (part == 0) {
+                float b1 = 0.0f, b2 = 0.0f;
+                for (int q = 0; q < 16; ++q) {
+                    b1 += red[0][q][cl];
+                    b2 += red[1][q][cl];
+                }
+                if (pass == 0) {
+                    t1 += b1;
+                    t2 += b2;
+                } else if (live) {
+                    pool_u[(size_t)n * Cp + c] = sc * (k + b1 / (float)S) + sh;
+                }
+            }
+        }
+        if (pass == 0 && part == 0 && live) {
+            const float R = (float)N * (float)S;
+            const float m = t1 / R;
+            float var = fmaxf(t2 / R - m * m, 0.0f);
+            mean = k + m;
+            float invstd = 1.0f / sqrtf(var + eps);
+            if (c < C) {
+                const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+                sc = g * invstd;
+                sh = b - mean * sc;
+                if (rmean) {
+                    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (R / fmaxf(R - 1.0f, 1.0f));
+                }
+            } else {
+                mean = 0.0f;
+                invstd = 0.0f;
+            }
+            stat[c] = mean;
+            stat[Cp + c] = invstd;
+            stat[2 * Cp + c] = sc;
+            stat[3 * Cp + c] = sh;
+        }
+    }
+}
+
+// ---- a = act((y*sc + sh + residual) * gate) ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ stat, const T* __restrict__ res,
+                                                             const float* __restrict__ gate, T* __restrict__ a, int S, int Cp, int CG,
+                                                             int CGb, int rows_per_chunk, int act) {
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    if (cg >= CG) return;
+    float sc[8], sh[8], g[8];
+    load8(stat + 2 * Cp + cg * 8, sc);
+    load8(stat + 3 * Cp + cg * 8, sh);
+    if (gate) load8(gate + (size_t)n * Cp + cg * 8, g);
+    const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
+    const size_t base = (size_t)n * S * Cp + cg * 8;
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const size_t o = base + (size_t)r * Cp;
+        float v[8];
+        load8(y + o, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+        if (res) {
+            float q[8];
+            load8(res + o, q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += q[j];
+        }
+        if (gate) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= g[j];
+        }
+        act_vec(v, act);
+        store8(a + o, v);
+    }
+}
+
+// ---- backward pass over one unit (in place on d) --------------------------------------------------------------------
+// mode 0:  d' = d * act'(y*sc + sh + residual)                 partials: sum d', sum d' * yhat      (yhat = (y-mean)*invstd)
+// mode 1:  d' = d * act'((y*sc + sh) * gate)                   partials: sum d' * (y*sc + sh)       (per clip: grad of the gate)
+// mode 2:  d' = d * gate + add[n][c]                           partials: sum d', sum d' * yhat
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
+                                                        const T* __restrict__ res, const float* __restrict__ gate, const float* __restrict__ add,
+                                                        float* __restrict__ ws, int S, int Cp, int CG, int CGb, int rows_per_chunk,
+                                                        int chunks, int act) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    float acc[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.0f;
+    if (cg < CG) {
+        float mean[8], invstd[8], sc[8], sh[8], g[8], ad[8];
+        load8(stat + cg * 8, mean);
+        load8(stat + Cp + cg * 8, invstd);
+        load8(stat + 2 * Cp + cg * 8, sc);
+        load8(stat + 3 * Cp + cg * 8, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            g[j] = 1.0f;
+            ad[j] = 0.0f;
+        }
+        if (gate) load8(gate + (size_t)n * Cp + cg * 8, g);
+        if (add) load8(add + (size_t)n * Cp + cg * 8, ad);
+        const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
+        const size_t base = (size_t)n * S * Cp + cg * 8;
+#pragma unroll 2
+        for (int r = r0 + rl; r < r1; r += RL) {
+            const size_t o = base + (size_t)r * Cp;
+            float v[8], dv[8];
+            load8(y + o, v);
+            load8(d + o, dv);
+            if (MODE == 0) {
+                float u[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u[j] = fmaf(v[j], sc[j], sh[j]);
+                if (res) {
+                    float q[8];
+                    load8(res + o, q);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) u[j] += q[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dv[j] *= act_grad(u[j], act);
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float u = fmaf(v[j], sc[j], sh[j]);
+                    dv[j] *= act_grad(u * g[j], act);
+                    acc[0][j] = fmaf(dv[j], u, acc[0][j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dv[j] = fmaf(dv[j], g[j], ad[j]);
+            }
+            if (MODE != 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[0][j] += dv[j];
+                    acc[1][j] = fmaf(dv[j], (v[j] - mean[j]) * invstd[j], acc[1][j]);
+                }
+            }
+            store8(d + o, dv);
+        }
+    }
+    block_reduce_rows<2>(acc, red, ws + ((size_t)n * chunks + ch) * 2 * Cp, Cp, CG, CGb);
+}
+
+// totals of the mode 0 / 2 partials -> coef[2][Cp] = (sum d'/R, sum d' yhat / R), dgamma, dbeta (either may be NULL)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ coef, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int N, int S, int C, int Cp, int chunks) {
+    __shared__ float red[2][16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool live = c < Cp;
+    float a1 = 0.0f, a2 = 0.0f;
+    if (live)
+        for (int i = part; i < N * chunks; i += 16) {
+            const float* p = ws + (size_t)i * 2 * Cp + c;
+            a1 += p[0];
+            a2 += p[Cp];
+        }
+    red[0][part][cl] = a1;
+    red[1][part][cl] = a2;
+    __syncthreads();
+    if (part == 0 && live) {
+        float b1 = 0.0f, b2 = 0.0f;
+        for (int q = 0; q < 16; ++q) {
+            b1 += red[0][q][cl];
+            b2 += red[1][q][cl];
+        }
+        const float R = (float)N * (float)S;
+        coef[c] = b1 / R;
+        coef[Cp + c] = b2 / R;
+        if (c < C) {
+            if (dgamma) dgamma[c] = b2;
+            if (dbeta) dbeta[c] = b1;
+        }
+    }
+}
+
+// dy = sc * (d - m1 - yhat * m2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
+                                                           const float* __restrict__ coef, T* __restrict__ dy, int S, int Cp, int CG, int CGb,
+                                                           int rows_per_chunk) {
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    if (cg >= CG) return;
+    float mean[8], invstd[8], sc[8], m1[8], m2[8];
+    load8(stat + cg * 8, mean);
+    load8(stat + Cp + cg * 8, invstd);
+    load8(stat + 2 * Cp + cg * 8, sc);
+    load8(coef + cg * 8, m1);
+    load8(coef + Cp + cg * 8, m2);
+    const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
+    const size_t base = (size_t)n * S * Cp + cg * 8;
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const size_t o = base + (size_t)r * Cp;
+        float v[8], dv[8];
+        load8(y + o, v);
+        load8(d + o, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (dv[j] - m1[j] - (v[j] - mean[j]) * invstd[j] * m2[j]);
+        store8(dy + o, dv);
+    }
+}
+
+// ---- squeeze-excite backward (one block per clip) ---------------------------------------------------------------------
+// gate = sigmoid(w2 . relu(w1 . pool + b1) + b2).  In: dgate partials (mode 1), pool_u.  Out: add[n][c] = dpool[c] / S and
+// this clip's parameter-gradient contributions pn[n][...] = (dw1 [Cse][C], db1 [Cse], dw2 [C][Cse], db2 [C]).
+__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ ws, int chunks, const float* __restrict__ pool_u,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, float* __restrict__ add, float* __restrict__ pn, int S, int C,
+                                                         int Cp, int Cse) {
+    extern __shared__ float sm[];
+    float* pool = sm;             // [C]
+    float* ds = pool + C;         // [C]
+    float* h = ds + C;            // [Cse]
+    float* dh = h + Cse;          // [Cse]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) pool[c] = pool_u[(size_t)n * Cp + c];
+    __syncthreads();
+    for (int j = tid; j < Cse; j += 256) {
+        float a = b1[j];
+        for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)j * C + c], pool[c], a);
+        h[j] = fmaxf(a, 0.0f);
+    }
+    __syncthreads();
+    float* p = pn + (size_t)n * (2 * (size_t)C * Cse + Cse + C);
+    float* p_w1 = p;
+    float* p_b1 = p_w1 + (size_t)Cse * C;
+    float* p_w2 = p_b1 + Cse;
+    float* p_b2 = p_w2 + (size_t)C * Cse;
+    for (int c = tid; c < C; c += 256) {
+        float dg = 0.0f;
+        for (int ch = 0; ch < chunks; ++ch) dg += ws[((size_t)n * chunks + ch) * 2 * Cp + c];
+        float a = b2[c];
+        for (int j = 0; j < Cse; ++j) a = fmaf(w2[(size_t)c * Cse + j], h[j], a);
+        const float g = 1.0f / (1.0f + expf(-a));
+        const float d = dg * g * (1.0f - g);
+        ds[c] = d;
+        p_b2[c] = d;
+        for (int j = 0; j < Cse; ++j) p_w2[(size_t)c * Cse + j] = d * h[j];
+    }
+    __syncthreads();
+    for (int j = tid; j < Cse; j += 256) {
+        float a = 0.0f;
+        for (int c = 0; c < C; ++c) a = fmaf(w2[(size_t)c * Cse + j], ds[c], a);
+        a = h[j] > 0.0f ? a : 0.0f;
+        dh[j] = a;
+        p_b1[j] = a;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.0f;
+        for (int j = 0; j < Cse; ++j) {
+            a = fmaf(w1[(size_t)j * C + c], dh[j], a);
+            p_w1[(size_t)j * C + c] = dh[j] * pool[c];
+        }
+        add[(size_t)n * Cp + c] = a / (float)S;
+    }
+    for (int c = C + tid; c < Cp; c += 256) add[(size_t)n * Cp + c] = 0.0f;
+}
+
+// out[i] = sum_n pn[n * stride + i], i < len   (fixed order)
+__global__ __launch_bounds__(256) void sum_over_clips_kernel(const float* __restrict__ pn, float* __restrict__ out, int N, size_t stride,
+                                                             size_t len) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    float s = 0.0f;
+    for (int n = 0; n < N; ++n) s += pn[(size_t)n * stride + i];
+    out[i] = s;
+}
+
+// ---- strided scatter: dst[n][t*st][h*sh][w*sw][:] (+)= src[n][t][h][w][:], every other element 0 (or kept) -------------
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_strided_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int To, int Ho, int Wo,
+                                                              int Ti, int Hi, int Wi, int st, int sh, int sw, int Cp, int accumulate) {
+    const int CG = Cp / 8;
+    const size_t total = (size_t)N * Ti * Hi * Wi * CG;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        size_t row = i / CG;
+        const int w = (int)(row % Wi);
+        size_t q = row / Wi;
+        const int h = (int)(q % Hi);
+        q /= Hi;
+        const int t = (int)(q % Ti), n = (int)(q / Ti);
+        const bool on = (t % st == 0) && (h % sh == 0) && (w % sw == 0) && (t / st < To) && (h / sh < Ho) && (w / sw < Wo);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+        T* o = dst + row * Cp + cg * 8;
+        if (on) {
+            load8(src + ((((size_t)n * To + t / st) * Ho + h / sh) * Wo + w / sw) * Cp + cg * 8, v);
+            if (accumulate) {
+                float e[8];
+                load8(o, e);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += e[j];
+            }
+            store8(o, v);
+        } else if (!accumulate) {
+            store8(o, v);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ a, const T* __restrict__ b, size_t groups) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < groups; i += (size_t)gridDim.x * 256) {
+        float x[8], y[8];
+        load8(a + i * 8, x);
+        load8(b + i * 8, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        store8(a + i * 8, x);
+    }
+}
+
+}  // namespace pasn
+
+using namespace pasn;
+
+#define ROWS_ARGS_OK(N, S, C, Cp)                                                                         \
+    PASN_REQUIRE((N) > 0 && (S) > 0 && (C) > 0 && (Cp) >= (C) && (Cp) % 8 == 0, "bad tensor extents");   \
+    PASN_REQUIRE((Cp) <= 2048, "channel stride above 2048 is not covered")
+
+extern "C" int pasn_train_chunks(int N, int S, int Cp) {
+    if (N <= 0 || S <= 0 || Cp <= 0 || Cp % 8 || Cp > 2048) return 0;
+    return row_geom(N, S, Cp).chunks;
+}
+
+extern "C" int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float momentum, float eps, float* stat, float* pool_u, int N, int S, int C,
+                                 int Cp, int dtype, void* stream) {
+    ROWS_ARGS_OK(N, S, C, Cp);
+    PASN_REQUIRE(y && ws && stat, "null pointer");
+    PASN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean / running_var go together");
+    const RowGeom g = row_geom(N, S, Cp);
+    const dim3 grid(g.chunks, N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16) {
+        hipLaunchKernelGGL(bn_stats_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, ws, S, Cp, g.CG, g.CGb, g.rows_per_chunk, g.chunks);
+        hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)y, gamma, beta, running_mean,
+                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks);
+    } else {
+        hipLaunchKernelGGL(bn_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)y, ws, S, Cp, g.CG, g.CGb, g.rows_per_chunk, g.chunks);
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const float*)y, gamma, beta, running_mean,
+                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks);
+    }
+    return check_launch("bn_stats_fwd");
+}
+
+extern "C" int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S,
+                                   int C, int Cp, int act, int dtype, void* stream) {
+    ROWS_ARGS_OK(N, S, C, Cp);
+    PASN_REQUIRE(y && stat && a, "null pointer");
+    const RowGeom g = row_geom(N, S, Cp);
+    const dim3 grid(g.chunks, N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(affine_act_fwd_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, stat, (const __bf16*)residual, gate, (__bf16*)a,
+                           S, Cp, g.CG, g.CGb, g.rows_per_chunk, act);
+    else
+        hipLaunchKernelGGL(affine_act_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)y, stat, (const float*)residual, gate, (float*)a, S,
+                           Cp, g.CG, g.CGb, g.rows_per_chunk, act);
+    return check_launch("affine_act_fwd");
+}
+
+template <typename T>
+static void launch_grad_pass(int mode, void* d, const void* y, const float* stat, const void* res, const float* gate, const float* add,
+                             float* ws, int N, int S, int Cp, const RowGeom& g, int act, hipStream_t s) {
+    const dim3 grid(g.chunks, N);
+#define GP(M)                                                                                                                      \
+    hipLaunchKernelGGL((grad_pass_kernel<T, M>), grid, dim3(256), 0, s, (T*)d, (const T*)y, stat, (const T*)res, gate, add, ws, S, Cp, g.CG, \
+                       g.CGb, g.rows_per_chunk, g.chunks, act)
+    if (mode == 0) GP(0);
+    else if (mode == 1) GP(1);
+    else GP(2);
+#undef GP
+}
+
+extern "C" int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const float* stat, const void* residual, const float* gate,
+                                    const float* add, float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp,
+                                    int act, int dtype, void* stream) {
+    ROWS_ARGS_OK(N, S, C, Cp);
+    PASN_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+    PASN_REQUIRE(d && y && stat && ws, "null pointer");
+    PASN_REQUIRE(mode == 1 || coef, "coef is required for modes 0 and 2");
+    PASN_REQUIRE(mode == 0 || gate, "modes 1 and 2 need the gate");
+    const RowGeom g = row_geom(N, S, Cp);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16) launch_grad_pass<__bf16>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s);
+    else launch_grad_pass<float>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s);
+    if (mode != 1)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, coef, dgamma, dbeta, N, S, C, Cp, g.chunks);
+    return check_launch("unit_bwd_reduce");
+}
+
+extern "C" int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp,
+                                 int dtype, void* stream) {
+    ROWS_ARGS_OK(N, S, C, Cp);
+    PASN_REQUIRE(d && y && stat && coef && dy, "null pointer");
+    const RowGeom g = row_geom(N, S, Cp);
+    const dim3 grid(g.chunks, N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)d, (const __bf16*)y, stat, coef, (__bf16*)dy, S, Cp,
+                           g.CG, g.CGb, g.rows_per_chunk);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)d, (const float*)y, stat, coef, (float*)dy, S, Cp, g.CG,
+                           g.CGb, g.rows_per_chunk);
+    return check_launch("bn_bwd_apply");
+}
+
+extern "C" size_t pasn_se_bwd_workspace_floats(int N, int C, int Cse) { return (size_t)N * (2 * (size_t)C * Cse + Cse + C); }
+
+extern "C" int pasn_se_gate_bwd(const float* ws, const float* pool_u, const float* w1, const float* b1, const float* w2, const float* b2,
+                                float* add, float* pn, float* dw1, float* db1, float* dw2, float* db2, int N, int S, int C, int Cp, int Cse,
+                                void* stream) {
+    ROWS_ARGS_OK(N, S, C, Cp);
+    PASN_REQUIRE(Cse > 0 && ws && pool_u && w1 && b1 && w2 && b2 && add && pn && dw1 && db1 && dw2 && db2, "null pointer");
+    const size_t lds = (2 * (size_t)C + 2 * Cse) * sizeof(float);
+    PASN_REQUIRE(lds <= 64 * 1024, "squeeze-excite width above the LDS budget");
+    const RowGeom g = row_geom(N, S, Cp);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), lds, s, ws, g.chunks, pool_u, w1, b1, w2, b2, add, pn, S, C, Cp, Cse);
+    // the per-clip contributions are laid out (dw1, db1, dw2, db2): sum each segment into its own gradient tensor
+    const size_t len = 2 * (size_t)C * Cse + Cse + C;
+    const size_t o_b1 = (size_t)Cse * C, o_w2 = o_b1 + Cse, o_b2 = o_w2 + (size_t)C * Cse;
+    struct Seg { float* out; size_t off, n; } segs[4] = {{dw1, 0, o_b1}, {db1, o_b1, (size_t)Cse}, {dw2, o_w2, (size_t)C * Cse}, {db2, o_b2, (size_t)C}};
+    for (const Seg& sg : segs) {
+        hipLaunchKernelGGL(sum_over_clips_kernel, dim3(ceil_div((long)sg.n, 256)), dim3(256), 0, s, pn + sg.off, sg.out, N, len, sg.n);
+    }
+    return check_launch("se_gate_bwd");
+}
+
+extern "C" int pasn_scatter_strided(const void* src, void* dst, const pasn_conv_desc* d, int accumulate, int dtype, void* stream) {
+    PASN_REQUIRE(src && dst && d, "null pointer");
+    // src: [N][To][Ho][Wo][Cin_p] (compact), dst: [N][Ti][Hi][Wi][Cin_p]; element (t,h,w) of src lands on (t*st, h*sh, w*sw)
+    PASN_REQUIRE(d->Cin_p % 8 == 0 && d->st > 0 && d->sh > 0 && d->sw > 0, "bad descriptor");
+    PASN_REQUIRE((d->To - 1) * d->st < d->Ti && (d->Ho - 1) * d->sh < d->Hi && (d->Wo - 1) * d->sw < d->Wi, "source does not fit the target");
+    const size_t total = (size_t)d->N * d->Ti * d->Hi * d->Wi * (d->Cin_p / 8);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(scatter_strided_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)src, (__bf16*)dst, d->N, d->To, d->Ho, d->Wo,
+                           d->Ti, d->Hi, d->Wi, d->st, d->sh, d->sw, d->Cin_p, accumulate);
+    else
+        hipLaunchKernelGGL(scatter_strided_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, (float*)dst, d->N, d->To, d->Ho, d->Wo,
+                           d->Ti, d->Hi, d->Wi, d->st, d->sh, d->sw, d->Cin_p, accumulate);
+    return check_launch("scatter_strided");
+}
+
+extern "C" int pasn_add_inplace(void* a, const void* b, size_t elements, int dtype, void* stream) {
+    PASN_REQUIRE(a && b && elements % 8 == 0, "element count must be a multiple of 8");
+    const size_t groups = elements / 8;
+    const int blocks = (int)std::min<size_t>((groups + 255) / 256, 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16) hipLaunchKernelGGL(add_inplace_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (__bf16*)a, (const __bf16*)b, groups);
+    else hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)a, (const float*)b, groups);
+    return check_launch("add_inplace");
+}

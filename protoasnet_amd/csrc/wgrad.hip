@@ -1,0 +1,357 @@
+// wgrad.hip -- weight gradients of the dense / first / depthwise convs and the depthwise input gradient.
+//
+// Dense weight gradient dW[co][ci][tap] = sum_rows dy[row][co] * x[in(row, tap)][ci] is a GEMM whose contraction runs
+// over the ROWS of two channels-last tensors.  v_mfma_f32_32x32x2_f32 wants, per lane, ONE A element (row m = lane & 31,
+// k = lane >> 5) and ONE B element (column n = lane & 31, same k): with k = activation row and m / n = channel, a lane's
+// operand is a single element of a channels-last row and a wave's load is two coalesced 128-byte row segments -- no
+// transposition through LDS.  bf16 activations are widened on load; accumulation and the gradient are fp32.
+// Row chunks are spread over the grid (split-K) and combined with fp32 atomics into the zero-initialised gradient.
+//
+// The input gradients of the dense convs need no kernel of their own: a 1x1x1 conv's dgrad is pasn_conv3d_fwd with the
+// transposed weight (strided ones followed by pasn_scatter_strided).
+#include "common.h"
+
+namespace pasn {
+
+constexpr int WG_U = 8;  // row pairs in flight per wave
+
+template <typename T>
+__device__ __forceinline__ float ld_f(const T* p) {
+    return (float)*p;
+}
+
+// x: [N][Ti][Hi][Wi][Cin_p], dy: [N][To][Ho][Wo][Cout_p], dw: fp32 [Cout][Cin][taps]
+template <typename T, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
+                                                         pasn_conv_desc d, int ci_tiles, int rows_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, k = lane >> 5;
+    const int taps = d.kt * d.kh * d.kw;
+    int tile = blockIdx.y;
+    const int tap = tile % taps;
+    tile /= taps;
+    const int ci_t = tile % ci_tiles, co_t = tile / ci_tiles;
+    const int co = co_t * 32 + m, ci = ci_t * 32 + m;
+    const bool a_ok = co < d.Cout_p, b_ok = ci < d.Cin_p;
+    const int coc = a_ok ? co : 0, cic = b_ok ? ci : 0;
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * rows_per_wave;
+    const long r1 = min(R, r0 + rows_per_wave);
+    const int tt = tap / (d.kh * d.kw), th = (tap / d.kw) % d.kh, tw = tap % d.kw;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (long rb = r0; rb < r1; rb += 2 * WG_U) {
+        T ra[WG_U], rx[WG_U];
+        float ma[WG_U], mx[WG_U];
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const long r = rb + 2 * u + k;
+            const bool rok = r < r1;
+            const long rc = rok ? r : r0;
+            long in_row = rc;
+            bool vok = rok;
+            if (!PW) {
+                const int wo = (int)(rc % d.Wo);
+                long q = rc / d.Wo;
+                const int ho = (int)(q % d.Ho);
+                q /= d.Ho;
+                const int to = (int)(q % d.To), n = (int)(q / d.To);
+                const int ti = to * d.st - d.pt + tt, hi = ho * d.sh - d.ph + th, wi = wo * d.sw - d.pw + tw;
+                const bool in = ti >= 0 && ti < d.Ti && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
+                vok = rok && in;
+                in_row = in ? (((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi : 0;
+            }
+            ra[u] = dy[rc * d.Cout_p + coc];
+            rx[u] = x[in_row * d.Cin_p + cic];
+            ma[u] = (rok && a_ok) ? 1.0f : 0.0f;
+            mx[u] = (vok && b_ok) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ra[u] * ma[u], (float)rx[u] * mx[u], acc, 0, 0, 0);
+    }
+    // acc element `reg` of this lane: row (= co offset) acc_row(reg, k), column (= ci offset) m
+    const int cig = ci_t * 32 + m;
+    if (cig < d.Cin) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int cog = co_t * 32 + acc_row(reg, k);
+            if (cog < d.Cout) unsafeAtomicAdd(dw + ((size_t)cog * d.Cin + cig) * taps + tap, acc[reg]);
+        }
+    }
+}
+
+// First conv (planar input x [N][3][T][Hi][Wi], window (1,kh,kw)): dw fp32 [Cout][3*kh*kw]
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const TIN* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
+                                                               pasn_conv_desc d, int col_tiles, int rows_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, k = lane >> 5;
+    const int cols = 3 * d.kh * d.kw;
+    const int col_t = blockIdx.y % col_tiles, co_t = blockIdx.y / col_tiles;
+    const int co = co_t * 32 + m, col = col_t * 32 + m;
+    const bool a_ok = co < d.Cout_p, b_ok = col < cols;
+    const int coc = a_ok ? co : 0;
+    const int ci = b_ok ? col / (d.kh * d.kw) : 0, th = b_ok ? (col / d.kw) % d.kh : 0, tw = b_ok ? col % d.kw : 0;
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * rows_per_wave;
+    const long r1 = min(R, r0 + rows_per_wave);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (long rb = r0; rb < r1; rb += 2 * WG_U) {
+        T ra[WG_U];
+        TIN rx[WG_U];
+        float ma[WG_U], mx[WG_U];
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const long r = rb + 2 * u + k;
+            const bool rok = r < r1;
+            const long rc = rok ? r : r0;
+            const int wo = (int)(rc % d.Wo);
+            long q = rc / d.Wo;
+            const int ho = (int)(q % d.Ho);
+            q /= d.Ho;
+            const int to = (int)(q % d.To), n = (int)(q / d.To);
+            const int hi = ho * d.sh - d.ph + th, wi = wo * d.sw - d.pw + tw;
+            const bool in = hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
+            const long off = in ? ((((long)n * 3 + ci) * d.Ti + to) * d.Hi + hi) * d.Wi + wi : 0;
+            ra[u] = dy[rc * d.Cout_p + coc];
+            rx[u] = x[off];
+            ma[u] = (rok && a_ok) ? 1.0f : 0.0f;
+            mx[u] = (rok && in && b_ok) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ra[u] * ma[u], (float)rx[u] * mx[u], acc, 0, 0, 0);
+    }
+    if (col < cols) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int cog = co_t * 32 + acc_row(reg, k);
+            if (cog < d.Cout) unsafeAtomicAdd(dw + (size_t)cog * cols + col, acc[reg]);
+        }
+    }
+}
+
+// ---- depthwise input gradient (any window / stride): dx[n,ti,hi,wi,c] = sum_taps dy[n,to,ho,wo,c] * w[tap][c] -----------
+template <typename T>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
+                                                       pasn_conv_desc d) {
+    const int CG = d.Cin_p / 8;
+    const size_t total = (size_t)d.N * d.Ti * d.Hi * d.Wi * CG;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        const size_t row = i / CG;
+        const int wi = (int)(row % d.Wi);
+        size_t q = row / d.Wi;
+        const int hi = (int)(q % d.Hi);
+        q /= d.Hi;
+        const int ti = (int)(q % d.Ti), n = (int)(q / d.Ti);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int a = 0; a < d.kt; ++a) {
+            const int tn = ti + d.pt - a;
+            if (tn < 0 || tn % d.st) continue;
+            const int to = tn / d.st;
+            if (to >= d.To) continue;
+            for (int b = 0; b < d.kh; ++b) {
+                const int hn = hi + d.ph - b;
+                if (hn < 0 || hn % d.sh) continue;
+                const int ho = hn / d.sh;
+                if (ho >= d.Ho) continue;
+                for (int c = 0; c < d.kw; ++c) {
+                    const int wn = wi + d.pw - c;
+                    if (wn < 0 || wn % d.sw) continue;
+                    const int wo = wn / d.sw;
+                    if (wo >= d.Wo) continue;
+                    float g[8], wv[8];
+                    load8(dy + ((((size_t)n * d.To + to) * d.Ho + ho) * d.Wo + wo) * d.Cout_p + cg * 8, g);
+                    load8(w + (size_t)((a * d.kh + b) * d.kw + c) * d.Cout_p + cg * 8, wv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(g[j], wv[j], acc[j]);
+                }
+            }
+        }
+        store8(dx + row * d.Cin_p + cg * 8, acc);
+    }
+}
+
+// ---- depthwise weight gradient: partial[chunk][tap][Cp] over output-row chunks, one temporal tap plane per blockIdx.z ----
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
+                                                               pasn_conv_desc d, int CG, int CGb, long rows_per_chunk) {
+    __shared__ float red[256 * 8];
+    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    const int a = blockIdx.z;  // temporal tap
+    const int KP = d.kh * d.kw;  // <= 9
+    float acc[9][8];
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[p][j] = 0.0f;
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    if (cg < CG) {
+        for (long r = r0 + rl; r < r1; r += RL) {
+            const int wo = (int)(r % d.Wo);
+            long q = r / d.Wo;
+            const int ho = (int)(q % d.Ho);
+            q /= d.Ho;
+            const int to = (int)(q % d.To), n = (int)(q / d.To);
+            const int ti = to * d.st - d.pt + a;
+            if (ti < 0 || ti >= d.Ti) continue;
+            float g[8];
+            load8(dy + r * d.Cout_p + cg * 8, g);
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                if (p < KP) {
+                    const int hi = ho * d.sh - d.ph + p / d.kw, wi = wo * d.sw - d.pw + p % d.kw;
+                    if (hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) {
+                        float v[8];
+                        load8(x + ((((size_t)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.Cin_p + cg * 8, v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(g[j], v[j], acc[p][j]);
+                    }
+                }
+            }
+        }
+    }
+    const int taps = d.kt * KP;
+    float* out = partial + ((size_t)blockIdx.x * taps + (size_t)a * KP) * d.Cout_p;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        if (p < KP) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[p][j];
+            __syncthreads();
+            for (int t = threadIdx.x; t < CGb * 8; t += 256) {
+                const int g2 = t >> 3, j = t & 7;
+                if (g2 < CG) {
+                    float s = 0.0f;
+                    for (int q = 0; q < RL; ++q) s += red[(q * CGb + g2) * 8 + j];
+                    out[(size_t)p * d.Cout_p + g2 * 8 + j] = s;
+                }
+            }
+        }
+    }
+}
+
+// dw[c][tap] = sum_chunks partial[chunk][tap][c]
+__global__ __launch_bounds__(256) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int taps,
+                                                                int C, int Cp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= taps * Cp) return;
+    const int tap = i / Cp, c = i % Cp;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int ch = 0; ch < chunks; ++ch) s += partial[((size_t)ch * taps + tap) * Cp + c];
+    dw[(size_t)c * taps + tap] = s;
+}
+
+static int wgrad_rows_per_wave(long R, int tiles) {
+    long waves_per_tile = std::max<long>(1, std::min<long>(8192 / std::max(1, tiles), R / 128));
+    waves_per_tile = (waves_per_tile + 3) / 4 * 4;
+    long rpw = (R + waves_per_tile - 1) / waves_per_tile;
+    rpw = (rpw + 2 * WG_U - 1) / (2 * WG_U) * (2 * WG_U);
+    return (int)rpw;
+}
+
+static long dw_wgrad_rows_per_chunk(const pasn_conv_desc& d) {
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    int CG = d.Cout_p / 8, b = 1;
+    while (b < CG) b <<= 1;
+    const int RL = 256 / b;
+    const long chunks = std::max<long>(1, std::min<long>(512, R / ((long)RL * 8)));
+    return (R + chunks - 1) / chunks;
+}
+
+}  // namespace pasn
+
+using namespace pasn;
+
+extern "C" int pasn_conv3d_wgrad(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && dy && dw && d, "null pointer");
+    PASN_REQUIRE(d->Cin_p % 8 == 0 && d->Cout_p % 8 == 0 && d->Cin <= d->Cin_p && d->Cout <= d->Cout_p, "bad channel extents");
+    const int taps = d->kt * d->kh * d->kw;
+    const int co_tiles = ceil_div(d->Cout, 32), ci_tiles = ceil_div(d->Cin, 32);
+    const long tiles = (long)co_tiles * ci_tiles * taps;
+    PASN_REQUIRE(tiles <= 65535, "too many weight tiles for one launch");
+    const long R = (long)d->N * d->To * d->Ho * d->Wo;
+    const int rpw = wgrad_rows_per_wave(R, (int)tiles);
+    const dim3 grid(ceil_div(R, (long)rpw * 4), (unsigned)tiles);
+    const bool pw = taps == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0;
+    hipStream_t s = (hipStream_t)stream;
+#define WG(T, P) hipLaunchKernelGGL((conv_wgrad_kernel<T, P>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, dw, *d, ci_tiles, rpw)
+    if (dtype == PASN_BF16) {
+        if (pw) WG(__bf16, true);
+        else WG(__bf16, false);
+    } else {
+        if (pw) WG(float, true);
+        else WG(float, false);
+    }
+#undef WG
+    return check_launch("conv3d_wgrad");
+}
+
+extern "C" int pasn_first_conv_wgrad(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int in_dtype, int dtype,
+                                     void* stream) {
+    PASN_REQUIRE(x && dy && dw && d, "null pointer");
+    PASN_REQUIRE(d->kt == 1 && d->st == 1 && d->pt == 0 && d->Cin == 3, "first conv is (1,kh,kw) over 3 planar channels");
+    const int cols = 3 * d->kh * d->kw;
+    const int co_tiles = ceil_div(d->Cout, 32), col_tiles = ceil_div(cols, 32);
+    const long R = (long)d->N * d->To * d->Ho * d->Wo;
+    const int rpw = wgrad_rows_per_wave(R, co_tiles * col_tiles);
+    const dim3 grid(ceil_div(R, (long)rpw * 4), co_tiles * col_tiles);
+    hipStream_t s = (hipStream_t)stream;
+#define FW(TI, T) hipLaunchKernelGGL((first_conv_wgrad_kernel<TI, T>), grid, dim3(256), 0, s, (const TI*)x, (const T*)dy, dw, *d, col_tiles, rpw)
+    if (in_dtype == PASN_BF16 && dtype == PASN_BF16) FW(__bf16, __bf16);
+    else if (in_dtype == PASN_F32 && dtype == PASN_BF16) FW(float, __bf16);
+    else if (in_dtype == PASN_BF16) FW(__bf16, float);
+    else FW(float, float);
+#undef FW
+    return check_launch("first_conv_wgrad");
+}
+
+extern "C" int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(dy && w && dx && d, "null pointer");
+    PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0, "depthwise conv keeps the channel stride");
+    const size_t total = (size_t)d->N * d->Ti * d->Hi * d->Wi * (d->Cin_p / 8);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16) hipLaunchKernelGGL(dw_dgrad_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)dy, w, (__bf16*)dx, *d);
+    else hipLaunchKernelGGL(dw_dgrad_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dy, w, (float*)dx, *d);
+    return check_launch("dwconv3d_dgrad");
+}
+
+extern "C" size_t pasn_dwconv3d_wgrad_workspace_floats(const pasn_conv_desc* d) {
+    if (!d || d->Cout_p <= 0 || d->Cout_p % 8 || d->Cout_p > 2048) return 0;
+    const long R = (long)d->N * d->To * d->Ho * d->Wo;
+    const long rpc = dw_wgrad_rows_per_chunk(*d);
+    const long chunks = (R + rpc - 1) / rpc;
+    return (size_t)chunks * d->kt * d->kh * d->kw * d->Cout_p;
+}
+
+extern "C" int pasn_dwconv3d_wgrad(const void* x, const void* dy, float* ws, float* dw, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && dy && ws && dw && d, "null pointer");
+    PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0 && d->Cout_p <= 2048, "depthwise conv keeps the channel stride (<= 2048)");
+    PASN_REQUIRE(d->kh * d->kw <= 9, "spatial window above 3x3 is not covered");
+    const long R = (long)d->N * d->To * d->Ho * d->Wo;
+    const long rpc = dw_wgrad_rows_per_chunk(*d);
+    const int chunks = (int)((R + rpc - 1) / rpc);
+    int CG = d->Cout_p / 8, CGb = 1;
+    while (CGb < CG) CGb <<= 1;
+    const int taps = d->kt * d->kh * d->kw;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(chunks, 1, d->kt);
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(dw_wgrad_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, ws, *d, CG, CGb, rpc);
+    else
+        hipLaunchKernelGGL(dw_wgrad_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dy, ws, *d, CG, CGb, rpc);
+    hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3(ceil_div((long)taps * d->Cout_p, 256)), dim3(256), 0, s, ws, dw, chunks, taps, d->Cout,
+                       d->Cout_p);
+    return check_launch("dwconv3d_wgrad");
+}

@@ -4,8 +4,9 @@ Same constructor kwargs, attributes, method names, return tuples and ``state_dic
 ``/root/reference/src/models/{ProtoPNet,XProtoNet,Video_XProtoNet}.py``, so the
 reference's agents / push / explain code can sit on top.  What differs is underneath: the trunk runs as
 a compiled list of fused HIP launches (``plan.py``), and everything after the trunk is one C-ABI call
-(``pasn_l2_head_fwd`` / ``pasn_xproto_head_fwd``).  The modules are forward-only in this round: they
-serve ``model.eval()`` inference, ``push_forward`` and ``compute_occurence_map`` under ``torch.no_grad()``.
+(``pasn_l2_head_fwd`` / ``pasn_xproto_head_fwd``).  Eval mode serves inference, ``push_forward`` and
+``compute_occurence_map`` under ``torch.no_grad()``; train mode (``model.train()``) of the head-B models on the X3D trunks runs
+the compiled forward + backward launch lists of ``train.py`` under autograd.
 """
 from __future__ import annotations
 
@@ -291,7 +292,30 @@ def _occurrence_module(conv, cin: int, depth: int, num_prototypes: int) -> Point
 class _XProtoHeadMixin:
     """Head B shared by the image and video models: one ``pasn_xproto_head_fwd`` call after the trunk."""
 
+    def _train_pass(self, x: torch.Tensor, mode: int):
+        """Train-mode pass (batch-statistics norm, differentiable): one compiled forward + backward launch list per input
+        shape (``train.TrainRunner``), driven by autograd -- the path ``loss.backward()`` of the reference's agents takes
+        (Video_XProtoNet_e2e.py:118-141; ``compute_occurence_map`` is called with gradients by loss.py:302)."""
+        from .train import TrainRunner
+
+        if not x.is_cuda:
+            raise RuntimeError("protoasnet_amd models run on the GPU only; there is no CPU fallback")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        runners = self.__dict__.setdefault("_train_runners", {})
+        key = (tuple(x.shape), x.dtype, self._dtype(), mode, id(self.prototype_vectors), tuple(self.prototype_shape))
+        runner = runners.get(key)
+        if runner is None:
+            if len(self.add_on_layers.convs()) != 2 or len(self.occurrence_module.convs()) != 3:
+                raise NotImplementedError("the training path supports the 2-conv add-on and 3-conv occurrence module of the shipped configs")
+            runner = runners[key] = TrainRunner(self, x, mode)
+        return runner(x)
+
     def _xproto(self, x: torch.Tensor, mode: int):
+        if self.training:
+            out = self._train_pass(x, mode)
+            return (out[0], out[1], out[2], None) if mode == 0 else (None, None, out[0], None)
         self._guard(x)
         feat = self.cnn_backbone(x)
         dtype = self._dtype()
@@ -338,6 +362,8 @@ class _XProtoHeadMixin:
         return self._xproto(x, 1)[2]
 
     def push_forward(self, x: torch.Tensor):
+        if self.training:
+            raise RuntimeError("push_forward runs in eval mode (the reference pushes under model.eval(): push_abs_revision.py:210)")
         logits, sim, occ, feats = self._xproto(x, 0)
         return feats, 1 - sim, occ, logits
 

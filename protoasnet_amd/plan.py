@@ -509,6 +509,12 @@ class HipTrunk(nn.Module):
     def build_plan(self, pb: PlanBuilder, x: Act) -> Act:  # pragma: no cover - overridden
         raise NotImplementedError
 
+    def build_train(self, tb, x: Act) -> Act:
+        raise NotImplementedError(
+            f"{type(self).__name__}: the training path (batch-statistics norm + backward) covers the X3D trunks; "
+            "this trunk runs eval / push / forward-throughput only so far"
+        )
+
     def _signature(self) -> tuple:
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 

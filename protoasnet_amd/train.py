@@ -1,0 +1,470 @@
+"""Training path: train-mode forward (batch-statistics norm) and backward as ONE replayable list of HIP launches.
+
+The reference trains by ``loss.backward()`` through ``model(x)`` / ``model.compute_occurence_map(x)``
+(src/agents/Video_XProtoNet_e2e.py:118-141, src/loss/loss.py:302).  Here the whole model (trunk + head) is compiled, for
+one input shape, into a forward launch list and a backward launch list by a small tape: every conv + norm + activation
+*unit* emits its forward launches immediately and registers an emitter for its backward launches, which are generated in
+reverse order once the forward graph is complete.  Both lists share one arena whose offsets come from the same live-range
+analysis as the inference plan -- an activation stays resident exactly until the last backward launch that reads it.
+
+Parameters stay fp32 ``nn.Parameter``s (the optimizer and the RCCL gradient all-reduce see ordinary ``.grad`` tensors);
+activations and activation gradients are fp32 or bf16 (``set_compute_dtype``); statistics, reductions and parameter
+gradients are fp32.  ``TrainPlan`` is driven by ``_TrainFn`` (a ``torch.autograd.Function``), so the reference's losses
+and optimizers sit on top unchanged.  Kernels: ``csrc/train.hip``, ``csrc/wgrad.hip``, ``csrc/head_train.hip`` plus the
+inference conv kernels (a 1x1x1 conv's input gradient is the same kernel with the transposed weight).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ConvDesc, XProtoDesc
+from .plan import ALIGN, Act, PlanBuilder, _triple, round_up
+
+
+def _need_fp32_param(p: torch.Tensor, what: str) -> None:
+    if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+        raise RuntimeError(
+            f"training keeps fp32 master parameters on the GPU ({what} is {p.dtype} on {p.device}); "
+            "use model.set_compute_dtype(torch.bfloat16) for bf16 activations instead of casting the model"
+        )
+
+
+class TrainBuilder(PlanBuilder):
+    def __init__(self, device, dtype, in_dtype):
+        super().__init__(device, dtype, in_dtype)
+        self.tape: List[Callable[[], None]] = []
+        self.grads: Dict[int, Act] = {}        # activation buffer id -> Act holding its gradient
+        self.refresh: List[Callable[[], None]] = []
+        self.pslots: List[Tuple[torch.Tensor, int, int]] = []
+        self._slot_of: Dict[int, int] = {}
+        self.gsize = 0
+        self.gbuf = self._new_buf(0, external=True)
+        self._const: Dict[tuple, torch.Tensor] = {}
+        self.nbt: List[torch.Tensor] = []      # num_batches_tracked counters bumped once per forward
+        self.n_fwd = -1
+
+    # ---- small helpers -------------------------------------------------------------------------------------------
+    def const(self, rows: int, value: float) -> torch.Tensor:
+        key = (rows, value)
+        if key not in self._const:
+            self._const[key] = torch.full((rows,), value, dtype=torch.float32, device=self.device)
+        return self._const[key]
+
+    def slot(self, p: torch.Tensor) -> int:
+        """Offset (in floats) of ``p``'s gradient inside the flat fp32 gradient buffer of one backward pass."""
+        if id(p) not in self._slot_of:
+            _need_fp32_param(p, "a parameter")
+            self._slot_of[id(p)] = self.gsize
+            self.pslots.append((p, self.gsize, p.numel()))
+            self.gsize += round_up(p.numel(), 64)
+        return self._slot_of[id(p)]
+
+    def like(self, a: Act) -> Act:
+        return Act(a.N, a.T, a.H, a.W, a.C, a.Cp, self._new_buf(a.N * a.positions * a.Cp * self.es))
+
+    # ---- launch recording -----------------------------------------------------------------------------------------
+    def _op(self, fn, *args) -> None:
+        """Record one C-ABI call.  Each argument is a constant, or a callable of the per-run pointer table (``B`` / ``Pm`` /
+        ``Gp`` below); everything is bound HERE, so later re-use of a local name cannot change a recorded launch."""
+        bound = tuple(args)
+
+        def run(ptrs, st, fn=fn, bound=bound):
+            _lib.check(fn(*[a(ptrs) if callable(a) else a for a in bound], st))
+
+        self.ops.append(run)
+
+    @staticmethod
+    def B(buf: Optional[int]):
+        """Arena / external buffer id -> its address in this run (None -> NULL)."""
+        return 0 if buf is None else (lambda ptrs, b=buf: ptrs[b])
+
+    @staticmethod
+    def Pm(t: Optional[torch.Tensor]):
+        """Live fp32 parameter / buffer -> its address at launch time (the optimizer updates it in place)."""
+        return 0 if t is None else (lambda ptrs, t=t: t.data_ptr())
+
+    def Gp(self, off: int):
+        """Address of a parameter-gradient slot inside this backward pass's flat gradient buffer."""
+        return lambda ptrs, g=self.gbuf, o=4 * off: ptrs[g] + o
+
+    def add_grad(self, a: Act, g: Act) -> None:
+        have = self.grads.get(a.buf)
+        if have is None:
+            self.grads[a.buf] = g
+            return
+        self._use(have.buf, g.buf)
+        self._op(self.lib.pasn_add_inplace, self.B(have.buf), self.B(g.buf), a.N * a.positions * a.Cp, self.code)
+
+    # ---- dense conv launch with a weight that is re-packed from the live parameter every step --------------------------
+    def _dense(self, x: Act, y: Act, k, s, p, cout: int, cin: int, weight_fn: Callable[[], torch.Tensor],
+               residual: Optional[Act] = None) -> ConvDesc:
+        taps = k[0] * k[1] * k[2]
+        kstep, ch = (16, 8) if self.dtype == torch.bfloat16 else (8, 4)
+        kc, rows = round_up(x.Cp, kstep), round_up(round_up(cout, 8), 128)
+        wp = torch.zeros(rows, taps, kc, dtype=self.dtype, device=self.device)
+        d = self._desc(x, y, k, s, p, "none", False, kc, rows)
+        dref = ctypes.byref(d)
+        frag = int(self.lib.pasn_conv3d_variant(dref, self.code, 0)) >= 2500
+        wf = torch.empty_like(wp) if frag else None
+        if frag:
+            d.w_frag = 1
+
+        def refresh():
+            wp[:cout, :, :cin] = weight_fn().reshape(cout, cin, taps).permute(0, 2, 1)
+            if frag:
+                wf.view(rows // 32, kc // kstep, 2, 32, ch).copy_(wp.view(rows // 32, 32, kc // kstep, 2, ch).permute(0, 2, 3, 1, 4))
+
+        self.refresh.append(refresh)
+        one, zero = self.const(rows, 1.0), self.const(rows, 0.0)
+        self.keep += [wp, wf, one, zero]
+        rb = residual.buf if residual is not None else None
+        self._use(x.buf, y.buf, rb)
+        self._op(self.lib.pasn_conv3d_fwd, self.B(x.buf), (wf if frag else wp).data_ptr(), one.data_ptr(), zero.data_ptr(), self.B(rb), 0,
+                 self.B(y.buf), dref, self.code)
+        return d
+
+    # ---- one conv (+ norm) (+ squeeze-excite) (+ residual) + activation unit ---------------------------------------------
+    def unit(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, kind: str = "conv",
+             residual: Optional[Act] = None, se: Optional[nn.Module] = None) -> Act:
+        k, s, p = _triple(conv.kernel_size, 1), _triple(conv.stride, 1), _triple(conv.padding, 0)
+        cout, cin = conv.out_channels, conv.in_channels
+        _need_fp32_param(conv.weight, "a conv weight")
+        taps = k[0] * k[1] * k[2]
+        y = self._out_act(x, cout, k, s, p)
+        N, S, C, Cp = y.N, y.positions, y.C, y.Cp
+        code, lib, B, Pm = self.code, self.lib, self.B, self.Pm
+        actc = _lib.ACT[act]
+        dw_w = None
+        # ---------------- forward conv (raw output) ----------------
+        if kind == "first":
+            assert x.planar and x.C == 3 and k[0] == 1 and s[0] == 1 and p[0] == 0
+            wfirst = torch.zeros(3 * k[1] * k[2], Cp, dtype=torch.float32, device=self.device)
+            d = self._desc(x, y, k, s, p, "none")
+            self.refresh.append(lambda: wfirst[:, :C].copy_(conv.weight.detach().reshape(C, 3, k[1], k[2]).permute(1, 2, 3, 0).reshape(3 * k[1] * k[2], C)))
+            one, zero = self.const(Cp, 1.0), self.const(Cp, 0.0)
+            self.keep += [wfirst, one, zero]
+            self._use(x.buf, y.buf)
+            self._op(lib.pasn_first_conv_fwd, B(x.buf), wfirst.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), ctypes.byref(d),
+                     _lib.dtype_code(self.in_dtype), code)
+        elif kind == "dw":
+            assert conv.groups == cin == cout == x.C and not x.planar
+            dw_w = torch.zeros(taps, Cp, dtype=torch.float32, device=self.device)
+            d = self._desc(x, y, k, s, p, "none")
+            self.refresh.append(lambda: dw_w[:, :C].copy_(conv.weight.detach().reshape(C, taps).t()))
+            one, zero = self.const(Cp, 1.0), self.const(Cp, 0.0)
+            self.keep += [dw_w, one, zero]
+            self._use(x.buf, y.buf)
+            self._op(lib.pasn_dwconv3d_fwd, B(x.buf), dw_w.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), 0, ctypes.byref(d), code)
+        else:
+            assert conv.groups == 1 and not x.planar
+            d = self._dense(x, y, k, s, p, cout, cin, lambda: conv.weight.detach())
+        dref = ctypes.byref(d)
+        # ---------------- statistics / affine ----------------
+        plain = norm is None and conv.bias is None and act == "none" and residual is None and se is None
+        stat_buf = pool_buf = gate_buf = None
+        stat = 0  # address source of the unit's (mean, invstd, sc, sh) table
+        if norm is not None:
+            assert conv.bias is None, "a conv followed by a norm layer carries no bias in the trunks built here"
+            for t in (norm.weight, norm.bias):
+                _need_fp32_param(t, "a norm parameter")
+            if norm.momentum is None:
+                raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not built")
+            chunks = int(lib.pasn_train_chunks(N, S, Cp))
+            ws = self._new_buf(N * chunks * 2 * Cp * 4)
+            stat_buf = self._new_buf(4 * Cp * 4)
+            pool_buf = self._new_buf(N * Cp * 4) if se is not None else None
+            track = bool(norm.track_running_stats and norm.running_mean is not None)
+            if track:
+                self.nbt.append(norm.num_batches_tracked)
+            self._use(y.buf, ws, stat_buf, pool_buf)
+            self._op(lib.pasn_bn_stats_fwd, B(y.buf), B(ws), Pm(norm.weight), Pm(norm.bias), Pm(norm.running_mean if track else None),
+                     Pm(norm.running_var if track else None), float(norm.momentum), float(norm.eps), B(stat_buf), B(pool_buf), N, S, C, Cp, code)
+            stat = B(stat_buf)
+        elif not plain:
+            stat_t = torch.zeros(4, Cp, dtype=torch.float32, device=self.device)  # (mean 0, invstd 1, sc 1, sh = bias)
+            stat_t[1, :C] = 1.0
+            stat_t[2, :C] = 1.0
+            if conv.bias is not None:
+                _need_fp32_param(conv.bias, "a conv bias")
+                self.refresh.append(lambda: stat_t[3, :C].copy_(conv.bias.detach()))
+            self.keep.append(stat_t)
+            stat = stat_t.data_ptr()
+        if se is not None:
+            assert norm is not None
+            cse = se.fc1.out_channels
+            for t in (se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias):
+                _need_fp32_param(t, "a squeeze-excite parameter")
+            gate_buf = self._new_buf(N * Cp * 4)
+            self._use(pool_buf, gate_buf)
+            self._op(lib.pasn_se_gate_fwd, B(pool_buf), 1, 1, Pm(se.fc1.weight), Pm(se.fc1.bias), Pm(se.fc2.weight), Pm(se.fc2.bias), B(gate_buf),
+                     N, C, Cp, cse)
+        if plain:
+            out = y
+        else:
+            out = self.like(y)
+            if residual is not None:
+                assert (residual.N, residual.positions, residual.Cp) == (N, S, Cp)
+            rb = residual.buf if residual is not None else None
+            self._use(y.buf, out.buf, rb, stat_buf, gate_buf)
+            self._op(lib.pasn_affine_act_fwd, B(y.buf), stat, B(rb), B(gate_buf), B(out.buf), N, S, C, Cp, actc, code)
+
+        # ---------------- backward emitter ----------------
+        def backward() -> None:
+            g = self.grads.get(out.buf)
+            if g is None:
+                return  # nothing downstream needs this unit's gradient
+            dy = g
+            if not plain:
+                chunks = int(lib.pasn_train_chunks(N, S, Cp))
+                ws = self._new_buf(N * chunks * 2 * Cp * 4)
+                coef = self._new_buf(2 * Cp * 4)
+                rb = residual.buf if residual is not None else None
+                red = lib.pasn_unit_bwd_reduce
+                if norm is not None:
+                    dg, db = self.Gp(self.slot(norm.weight)), self.Gp(self.slot(norm.bias))
+                elif conv.bias is not None:
+                    dg, db = 0, self.Gp(self.slot(conv.bias))
+                else:
+                    dg = db = 0
+                if se is None:
+                    self._use(g.buf, y.buf, rb, stat_buf, ws, coef)
+                    self._op(red, 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
+                else:
+                    cse = se.fc1.out_channels
+                    addb = self._new_buf(N * Cp * 4)
+                    pn = self._new_buf(int(lib.pasn_se_bwd_workspace_floats(N, C, cse)) * 4)
+                    o = [self.Gp(self.slot(t)) for t in (se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)]
+                    self._use(g.buf, y.buf, stat_buf, gate_buf, ws)
+                    self._op(red, 1, B(g.buf), B(y.buf), stat, 0, B(gate_buf), 0, B(ws), 0, 0, 0, N, S, C, Cp, actc, code)
+                    self._use(ws, pool_buf, addb, pn)
+                    self._op(lib.pasn_se_gate_bwd, B(ws), B(pool_buf), Pm(se.fc1.weight), Pm(se.fc1.bias), Pm(se.fc2.weight), Pm(se.fc2.bias),
+                             B(addb), B(pn), o[0], o[1], o[2], o[3], N, S, C, Cp, cse)
+                    self._use(g.buf, y.buf, stat_buf, gate_buf, addb, ws, coef)
+                    self._op(red, 2, B(g.buf), B(y.buf), stat, 0, B(gate_buf), B(addb), B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
+                if residual is not None:
+                    self.add_grad(residual, g)  # after mode 0, g is the gradient of the pre-activation sum
+                if norm is not None:
+                    dy = self.like(y) if residual is not None else g
+                    self._use(g.buf, y.buf, stat_buf, coef, dy.buf)
+                    self._op(lib.pasn_bn_bwd_apply, B(g.buf), B(y.buf), stat, B(coef), B(dy.buf), N, S, C, Cp, code)
+            # ---- weight gradient
+            dW = self.Gp(self.slot(conv.weight))
+            if kind == "first":
+                self._use(x.buf, dy.buf)
+                self._op(lib.pasn_first_conv_wgrad, B(x.buf), B(dy.buf), dW, dref, _lib.dtype_code(self.in_dtype), code)
+                return
+            if kind == "dw":
+                wsb = self._new_buf(int(lib.pasn_dwconv3d_wgrad_workspace_floats(dref)) * 4)
+                self._use(x.buf, dy.buf, wsb)
+                self._op(lib.pasn_dwconv3d_wgrad, B(x.buf), B(dy.buf), B(wsb), dW, dref, code)
+                dx = self.like(x)
+                self._use(dy.buf, dx.buf)
+                self._op(lib.pasn_dwconv3d_dgrad, B(dy.buf), dw_w.data_ptr(), B(dx.buf), dref, code)
+                self.add_grad(x, dx)
+                return
+            self._use(x.buf, dy.buf)
+            self._op(lib.pasn_conv3d_wgrad, B(x.buf), B(dy.buf), dW, dref, code)
+            # ---- input gradient of the dense conv
+            if taps != 1 or p != (0, 0, 0):
+                raise NotImplementedError("training covers 1x1x1 dense convs, depthwise convs and the first conv (the X3D trunks and head B)")
+            one = (1, 1, 1)
+            wt = lambda: conv.weight.detach().reshape(cout, cin).t()
+            have = self.grads.get(x.buf)
+            if s == one:
+                dx = self.like(x)
+                self._dense(dy, dx, one, one, (0, 0, 0), cin, cout, wt, residual=have)
+                self.grads[x.buf] = dx
+            else:
+                compact = Act(y.N, y.T, y.H, y.W, cin, x.Cp, self._new_buf(y.N * y.positions * x.Cp * self.es))
+                self._dense(dy, compact, one, one, (0, 0, 0), cin, cout, wt)
+                dst = have if have is not None else self.like(x)
+                self._use(compact.buf, dst.buf)
+                self._op(lib.pasn_scatter_strided, B(compact.buf), B(dst.buf), dref, int(have is not None), code)
+                self.grads[x.buf] = dst
+
+        self.tape.append(backward)
+        return out
+
+    # ---- head B tail ----------------------------------------------------------------------------------------------
+    def xproto_tail(self, z: Optional[Act], r: Act, model, ext: Dict[str, int]) -> None:
+        """z: add-on output (None = occurrence map only), r: occurrence-module output before the abs.  ``ext`` maps the names of
+        the external tensors (occ, feat, sim, logits, dlogits, dsim, docc) to buffer ids filled in per run."""
+        P, K = model.num_prototypes, model.num_classes
+        D = model.prototype_shape[1]
+        pv, fw = model.prototype_vectors, model.last_layer.weight
+        for t in (pv, fw):
+            _need_fp32_param(t, "a head parameter")
+        d = XProtoDesc(N=r.N, S=r.positions, Cb=0, Cbp=0, D=D, Dp=(z.Cp if z is not None else round_up(D, 8)), Hd=D // 2,
+                       Hp=round_up(D // 2, 8), P=P, Pp=r.Cp, K=K, mode=0 if z is not None else 1)
+        self.keep.append(d)
+        dref, code, lib, B, Pm = ctypes.byref(d), self.code, self.lib, self.B, self.Pm
+        zb = z.buf if z is not None else None
+        e = ext
+        self._use(zb, r.buf)
+        self._op(lib.pasn_xproto_tail_fwd, B(zb), B(r.buf), Pm(pv), Pm(fw), B(e["occ"]), B(e["feat"]), B(e["sim"]), B(e["logits"]), dref, code)
+
+        def backward() -> None:
+            dz = self.like(z) if z is not None else None
+            dr = self.like(r)
+            dfeat = self._new_buf(r.N * P * D * 4) if z is not None else None
+            gp, gf = (self.Gp(self.slot(pv)), self.Gp(self.slot(fw))) if z is not None else (0, 0)
+            dzb = dz.buf if dz is not None else None
+            self._use(zb, r.buf, dzb, dr.buf, dfeat)
+            self._op(lib.pasn_xproto_tail_bwd, B(zb), B(r.buf), Pm(pv), Pm(fw), B(e["feat"]), B(e["sim"]), B(e["dlogits"]), B(e["dsim"]),
+                     B(e["docc"]), B(dfeat), B(dzb), B(dr.buf), gp, gf, dref, code)
+            if z is not None:
+                self.add_grad(z, dz)
+            self.add_grad(r, dr)
+
+        self.tape.append(backward)
+
+    # ---- finish: generate the backward list, then place every buffer ----------------------------------------------------
+    def finish_train(self, x_in: Act, ext: Dict[str, int]) -> "TrainPlan":
+        self.n_fwd = len(self.ops)
+        for emit in reversed(self.tape):
+            emit()
+        live: List[Tuple[int, int, int]] = []
+        total = 0
+        for b in self.bufs:
+            if b.external:
+                continue
+            live = [a for a in live if a[2] >= b.first]
+            live.sort()
+            off = 0
+            for (o, sz, _) in live:
+                if off + b.nbytes <= o:
+                    break
+                off = max(off, o + sz)
+            b.offset = off
+            live.append((off, b.nbytes, b.last))
+            total = max(total, off + b.nbytes)
+        return TrainPlan(self, x_in, ext, total)
+
+
+class TrainPlan:
+    def __init__(self, tb: TrainBuilder, x_in: Act, ext: Dict[str, int], arena_bytes: int):
+        self.ops, self.n_fwd, self.keep, self.refresh = tb.ops, tb.n_fwd, tb.keep, tb.refresh
+        self.offsets = [None if b.external else b.offset for b in tb.bufs]
+        self.in_buf, self.ext, self.gbuf = x_in.buf, ext, tb.gbuf
+        self.pslots, self.gsize, self.nbt = tb.pslots, tb.gsize, tb.nbt
+        self.arena_bytes = arena_bytes
+        self.naive_bytes = sum(b.nbytes for b in tb.bufs if not b.external)
+        self.device, self.dtype = tb.device, tb.dtype
+
+    def _ptrs(self, arena: torch.Tensor) -> List[int]:
+        base = round_up(arena.data_ptr(), ALIGN)
+        return [0 if o is None else base + o for o in self.offsets]
+
+    def forward(self, x: torch.Tensor, outs: Dict[str, torch.Tensor]):
+        with torch.no_grad():
+            for r in self.refresh:
+                r()
+            if self.nbt:
+                torch._foreach_add_(self.nbt, 1)
+        arena = torch.empty(self.arena_bytes + ALIGN, dtype=torch.uint8, device=x.device)
+        ptrs = self._ptrs(arena)
+        ptrs[self.in_buf] = x.data_ptr()
+        for name, t in outs.items():
+            ptrs[self.ext[name]] = 0 if t is None else t.data_ptr()
+        st = _lib.current_stream()
+        for op in self.ops[: self.n_fwd]:
+            op(ptrs, st)
+        return arena
+
+    def backward(self, arena: torch.Tensor, x: torch.Tensor, tensors: Dict[str, Optional[torch.Tensor]]) -> List[torch.Tensor]:
+        """``tensors``: the forward outputs plus dlogits / dsim / docc (None = no gradient).  Returns one gradient per
+        ``self.pslots`` entry (views of one flat fp32 buffer -- the bucket a data-parallel all-reduce can send as is)."""
+        G = torch.zeros(max(self.gsize, 1), dtype=torch.float32, device=x.device)
+        ptrs = self._ptrs(arena)
+        ptrs[self.in_buf] = x.data_ptr()
+        ptrs[self.gbuf] = G.data_ptr()
+        for name, t in tensors.items():
+            ptrs[self.ext[name]] = 0 if t is None else t.data_ptr()
+        st = _lib.current_stream()
+        for op in self.ops[self.n_fwd:]:
+            op(ptrs, st)
+        return [G[o: o + n].view_as(p) for (p, o, n) in self.pslots]
+
+
+class _TrainFn(torch.autograd.Function):
+    """Autograd node of one training-mode pass: forward replays the forward launch list, backward the backward list."""
+
+    @staticmethod
+    def forward(ctx, runner, x, *params):
+        outs = runner.alloc_outputs(x)
+        arena = runner.plan.forward(x, outs)
+        ctx.runner, ctx.names = runner, tuple(outs)
+        ctx.save_for_backward(x, arena, *outs.values())
+        ctx.set_materialize_grads(False)
+        return tuple(outs[n] for n in runner.out_names)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        runner = ctx.runner
+        x, arena, *saved = ctx.saved_tensors
+        outs = dict(zip(ctx.names, saved))
+        tensors: Dict[str, Optional[torch.Tensor]] = dict(outs)
+        for name, g in zip(runner.grad_names, grads):
+            tensors[name] = None if g is None else g.contiguous().float()
+        tensors = runner.fix_grads(tensors, outs)
+        pg = runner.plan.backward(arena, x, tensors)
+        by_id = {id(p): g for (p, _, _), g in zip(runner.plan.pslots, pg)}
+        return (None, None) + tuple(by_id.get(id(p)) for p in runner.params)
+
+
+class TrainRunner:
+    """One compiled training pass of a head-B model for one input shape: mode 0 = forward(), 1 = compute_occurence_map()."""
+
+    def __init__(self, model, x: torch.Tensor, mode: int):
+        dtype = model._dtype()
+        tb = TrainBuilder(x.device, dtype, x.dtype)
+        x_in = tb.input(tuple(x.shape))
+        feat = model.cnn_backbone.build_train(tb, x_in)
+        ext = {n: tb._new_buf(0, external=True) for n in ("occ", "feat", "sim", "logits", "dlogits", "dsim", "docc")}
+        a_convs, o_convs = model.add_on_layers._steps(), model.occurrence_module._steps()
+        z = None
+        if mode == 0:
+            z = feat
+            for conv, act in a_convs:
+                z = tb.unit(z, conv, None, act)
+        r = feat
+        for conv, act in o_convs:
+            r = tb.unit(r, conv, None, act)
+        tb.xproto_tail(z, r, model, ext)
+        self.plan = tb.finish_train(x_in, ext)
+        self.mode, self.model = mode, model
+        self.N, self.S = feat.N, feat.positions
+        self.spatial = (feat.T, feat.H, feat.W) if x.dim() == 5 else (feat.H, feat.W)
+        self.out_names = ("logits", "sim", "occ") if mode == 0 else ("occ",)
+        self.grad_names = ("dlogits", "dsim", "docc") if mode == 0 else ("docc",)
+        self.params = [p for p in model.parameters()]
+
+    def alloc_outputs(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        m, dev, f32 = self.model, x.device, torch.float32
+        P, D, K = m.num_prototypes, m.prototype_shape[1], m.num_classes
+        outs = {"occ": torch.empty((self.N, P, 1) + self.spatial, dtype=f32, device=dev)}
+        if self.mode == 0:
+            outs["feat"] = torch.empty((self.N, P, D), dtype=f32, device=dev)
+            outs["sim"] = torch.empty((self.N, P), dtype=f32, device=dev)
+            outs["logits"] = torch.empty((self.N, K), dtype=f32, device=dev)
+        else:
+            outs["feat"] = outs["sim"] = outs["logits"] = None
+        return {k: v for k, v in outs.items()}
+
+    def fix_grads(self, tensors, outs):
+        if self.mode == 0 and tensors.get("dlogits") is None:
+            tensors["dlogits"] = torch.zeros_like(outs["logits"])
+        if self.mode == 1:
+            tensors.setdefault("dlogits", None)
+            tensors.setdefault("dsim", None)
+            if tensors.get("docc") is None:
+                tensors["docc"] = torch.zeros_like(outs["occ"])
+        return tensors
+
+    def __call__(self, x: torch.Tensor):
+        return _TrainFn.apply(self, x, *self.params)
