@@ -45,11 +45,20 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU-baseline sample after this much CPU work")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--per-op", default="", help="write a per-launch timing table to this file")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="forward = the BASELINE.json headline metric (default); train = config 3's training step (tools/train_bench.py)")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    if args.mode == "train":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import train_bench
+
+        return train_bench.main(["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
+                                 "--frames", str(args.frames), "--size", str(args.size), "--arch", args.arch, "--dtype", args.dtype]
+                                + (["--per-op", args.per_op] if args.per_op else []))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

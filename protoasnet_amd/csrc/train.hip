@@ -99,70 +99,72 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restri
     block_reduce_rows<2>(acc, red, ws + ((size_t)n * chunks + ch) * 2 * Cp, Cp, CG, CGb);
 }
 
-// One block per 16 channels; 16 "parts" share the partial sums of a clip, combined in a fixed order.
+// One block per 16 channels.  Totals: each of the 16 "parts" sums every 16th partial (independent loads, one LDS combine in a
+// fixed order).  Per-clip pool (squeeze-excite only): a part owns whole clips, no cross-thread combine at all.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ y, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                                           float momentum, float eps, float* __restrict__ stat, float* __restrict__ pool_u,
                                                           int N, int S, int C, int Cp, int chunks) {
     __shared__ float red[2][16][16];
+    __shared__ float scsh[2][16];
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool live = c < Cp;
-    float t1 = 0.0f, t2 = 0.0f;
     const float k = live ? (float)y[c] : 0.0f;
-    float mean = 0.0f, sc = 0.0f, sh = 0.0f;
-    for (int pass = 0; pass < 2; ++pass) {  // pass 0: totals; pass 1: per-clip pool (needs sc / sh)
-        if (pass == 1 && pool_u == nullptr) break;
-        for (int n = 0; n < N; ++n) {
-            float a1 = 0.0f, a2 = 0.0f;
-            if (live)
-                for (int ch = part; ch < chunks; ch += 16) {
-                    const float* p = ws + ((size_t)n * chunks + ch) * 2 * Cp + c;
-                    a1 += p[0];
-                    a2 += p[Cp];
-                }
-            __syncthreads();
-            red[0][part][cl] = a1;
-            red[1][part][cl] = a2;
-            __syncthreads();
-            if (part == 0) {
-                float b1 = 0.0f, b2 = 0.0f;
-                for (int q = 0; q < 16; ++q) {
-                    b1 += red[0][q][cl];
-                    b2 += red[1][q][cl];
-                }
-                if (pass == 0) {
-                    t1 += b1;
-                    t2 += b2;
-                } else if (live) {
-                    pool_u[(size_t)n * Cp + c] = sc * (k + b1 / (float)S) + sh;
-                }
-            }
+    float a1 = 0.0f, a2 = 0.0f;
+    if (live) {
+        const int total = N * chunks;
+#pragma unroll 4
+        for (int i = part; i < total; i += 16) {
+            const float* p = ws + (size_t)i * 2 * Cp + c;
+            a1 += p[0];
+            a2 += p[Cp];
         }
-        if (pass == 0 && part == 0 && live) {
+    }
+    red[0][part][cl] = a1;
+    red[1][part][cl] = a2;
+    __syncthreads();
+    if (part == 0) {
+        float t1 = 0.0f, t2 = 0.0f;
+        for (int q = 0; q < 16; ++q) {
+            t1 += red[0][q][cl];
+            t2 += red[1][q][cl];
+        }
+        float mean = 0.0f, invstd = 0.0f, sc = 0.0f, sh = 0.0f;
+        if (live && c < C) {
             const float R = (float)N * (float)S;
             const float m = t1 / R;
-            float var = fmaxf(t2 / R - m * m, 0.0f);
+            const float var = fmaxf(t2 / R - m * m, 0.0f);
             mean = k + m;
-            float invstd = 1.0f / sqrtf(var + eps);
-            if (c < C) {
-                const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-                sc = g * invstd;
-                sh = b - mean * sc;
-                if (rmean) {
-                    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
-                    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (R / fmaxf(R - 1.0f, 1.0f));
-                }
-            } else {
-                mean = 0.0f;
-                invstd = 0.0f;
+            invstd = 1.0f / sqrtf(var + eps);
+            const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+            sc = g * invstd;
+            sh = b - mean * sc;
+            if (rmean) {
+                rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (R / fmaxf(R - 1.0f, 1.0f));
             }
+        }
+        if (live) {
             stat[c] = mean;
             stat[Cp + c] = invstd;
             stat[2 * Cp + c] = sc;
             stat[3 * Cp + c] = sh;
         }
+        scsh[0][cl] = sc;
+        scsh[1][cl] = sh;
+    }
+    if (pool_u == nullptr) return;
+    __syncthreads();
+    if (!live) return;
+    const float sc = scsh[0][cl], sh = scsh[1][cl];
+    for (int n = part; n < N; n += 16) {
+        float b1 = 0.0f;
+        const float* p = ws + (size_t)n * chunks * 2 * Cp + c;
+#pragma unroll 4
+        for (int ch = 0; ch < chunks; ++ch) b1 += p[(size_t)ch * 2 * Cp];
+        pool_u[(size_t)n * Cp + c] = sc * (k + b1 / (float)S) + sh;
     }
 }
 

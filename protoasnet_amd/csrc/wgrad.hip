@@ -252,8 +252,12 @@ __global__ __launch_bounds__(256) void dw_wgrad_finalize_kernel(const float* __r
     dw[(size_t)c * taps + tap] = s;
 }
 
+bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s);
+size_t dw_wgrad_strip_floats(const pasn_conv_desc& d);
+bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const pasn_conv_desc& d, int dtype, hipStream_t s);
+
 static int wgrad_rows_per_wave(long R, int tiles) {
-    long waves_per_tile = std::max<long>(1, std::min<long>(8192 / std::max(1, tiles), R / 128));
+    long waves_per_tile = std::max<long>(1, std::min<long>(std::min(8192, 2048 + 65536 / std::max(1, tiles)) / std::max(1, tiles), R / 128));
     waves_per_tile = (waves_per_tile + 3) / 4 * 4;
     long rpw = (R + waves_per_tile - 1) / waves_per_tile;
     rpw = (rpw + 2 * WG_U - 1) / (2 * WG_U) * (2 * WG_U);
@@ -277,6 +281,8 @@ extern "C" int pasn_conv3d_wgrad(const void* x, const void* dy, float* dw, const
     PASN_REQUIRE(x && dy && dw && d, "null pointer");
     PASN_REQUIRE(d->Cin_p % 8 == 0 && d->Cout_p % 8 == 0 && d->Cin <= d->Cin_p && d->Cout <= d->Cout_p, "bad channel extents");
     const int taps = d->kt * d->kh * d->kw;
+    if (dtype == PASN_BF16 && !getenv("PASN_NO_WGRAD_LDS") && pw_wgrad_bf16(x, dy, dw, *d, (hipStream_t)stream))
+        return check_launch("conv3d_wgrad");
     const int co_tiles = ceil_div(d->Cout, 32), ci_tiles = ceil_div(d->Cin, 32);
     const long tiles = (long)co_tiles * ci_tiles * taps;
     PASN_REQUIRE(tiles <= 65535, "too many weight tiles for one launch");
@@ -329,6 +335,8 @@ extern "C" int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, con
 
 extern "C" size_t pasn_dwconv3d_wgrad_workspace_floats(const pasn_conv_desc* d) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 || d->Cout_p > 2048) return 0;
+    const size_t fast = getenv("PASN_NO_DWWG_STRIP") ? 0 : dw_wgrad_strip_floats(*d);
+    if (fast) return fast;
     const long R = (long)d->N * d->To * d->Ho * d->Wo;
     const long rpc = dw_wgrad_rows_per_chunk(*d);
     const long chunks = (R + rpc - 1) / rpc;
@@ -339,6 +347,7 @@ extern "C" int pasn_dwconv3d_wgrad(const void* x, const void* dy, float* ws, flo
     PASN_REQUIRE(x && dy && ws && dw && d, "null pointer");
     PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0 && d->Cout_p <= 2048, "depthwise conv keeps the channel stride (<= 2048)");
     PASN_REQUIRE(d->kh * d->kw <= 9, "spatial window above 3x3 is not covered");
+    if (!getenv("PASN_NO_DWWG_STRIP") && dw_wgrad_strip(x, dy, ws, dw, *d, dtype, (hipStream_t)stream)) return check_launch("dwconv3d_wgrad");
     const long R = (long)d->N * d->To * d->Ho * d->Wo;
     const long rpc = dw_wgrad_rows_per_chunk(*d);
     const int chunks = (int)((R + rpc - 1) / rpc);
@@ -355,3 +364,341 @@ extern "C" int pasn_dwconv3d_wgrad(const void* x, const void* dy, float* ws, flo
                        d->Cout_p);
     return check_launch("dwconv3d_wgrad");
 }
+
+// =====================================================================================================================
+// bf16 fast paths
+// =====================================================================================================================
+namespace pasn {
+
+// ---- pointwise (1x1x1, any stride) weight gradient on v_mfma_f32_32x32x16_bf16 ------------------------------------------
+// The contraction index (the activation ROW) is the slow index of both operands, the MFMA wants 8 consecutive k per lane.
+// A thread therefore loads an 8-row x 8-channel patch (eight 16-byte loads), transposes it in registers (32 v_perm_b32) and
+// stores, per channel, the 8 consecutive rows as ONE 16-byte LDS write: LDS holds At[channel][KT rows] / Bt[channel][KT rows],
+// and a fragment read is a conflict-free ds_read_b128 (row pitch KT*2 + 16 bytes).  Four waves share the staged rows; each
+// owns up to TPW 32x32 (co, ci) tiles.  Split-K over the grid, fp32 atomics into the zeroed gradient.
+template <int KT>
+struct WgLds {
+    static constexpr int PITCH = KT * 2 + 16;  // bytes per channel row
+};
+
+__device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&out)[8]) {
+    // in[r] = 8 channels of row r (2 per dword); out[c] = 8 rows of channel c (2 per dword)
+    const unsigned* I = reinterpret_cast<const unsigned*>(in);
+    unsigned* O = reinterpret_cast<unsigned*>(out);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)        // channel pair (2q, 2q+1)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {  // row pair (2p, 2p+1)
+            const unsigned lo = I[(2 * p) * 4 + q], hi = I[(2 * p + 1) * 4 + q];
+            O[(2 * q) * 4 + p] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);      // low halves  -> channel 2q
+            O[(2 * q + 1) * 4 + p] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);  // high halves -> channel 2q+1
+        }
+}
+
+template <int KT, int TPW>
+__global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, float* __restrict__ dw,
+                                                            pasn_conv_desc d, int co_tiles, int ci_tiles, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int PITCH = WgLds<KT>::PITCH;
+    const int CGo = d.Cout_p / 8, CGi = d.Cin_p / 8;
+    unsigned char* At = lds;                                   // [co_tiles*32][PITCH]
+    unsigned char* Bt = lds + (size_t)co_tiles * 32 * PITCH;   // [ci_tiles*32][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    const bool strided = d.st != 1 || d.sh != 1 || d.sw != 1;
+    const int ntiles = co_tiles * ci_tiles;
+    // this wave's tiles: (blockIdx.y * 4 + wave) * TPW + j; out-of-range ones alias tile 0 and are dropped at the end
+    int t_co[TPW], t_ci[TPW];
+    bool t_ok[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = (blockIdx.y * 4 + wave) * TPW + j;
+        t_ok[j] = t < ntiles;
+        const int tc = t_ok[j] ? t : 0;
+        t_co[j] = tc / ci_tiles;
+        t_ci[j] = tc % ci_tiles;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    // zero the LDS rows of padded channels once (channels >= C*_p of the last tile are never written by the staging)
+    for (int i = tid * 16; i < (co_tiles + ci_tiles) * 32 * PITCH; i += 256 * 16) *reinterpret_cast<uint4*>(lds + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int units = (KT / 8) * (CGo + CGi);  // 8-row x 8-channel patches per staged K tile
+    for (long rb = r0; rb < r1; rb += KT) {
+        for (int u = tid; u < units; u += 256) {
+            const int g = u % (CGo + CGi), r8 = u / (CGo + CGi);
+            const bool is_a = g < CGo;
+            const int cg = is_a ? g : g - CGo;
+            const int cp = is_a ? d.Cout_p : d.Cin_p;
+            const __bf16* src = is_a ? dy : x;
+            uint4 in[8], out[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long r = rb + r8 * 8 + i;
+                const bool ok = r < r1;
+                long row = ok ? r : r0;
+                if (!is_a && strided) {
+                    const int wo = (int)(row % d.Wo);
+                    long q = row / d.Wo;
+                    const int ho = (int)(q % d.Ho);
+                    q /= d.Ho;
+                    const int to = (int)(q % d.To), n = (int)(q / d.To);
+                    row = (((long)n * d.Ti + to * d.st) * d.Hi + ho * d.sh) * d.Wi + wo * d.sw;
+                }
+                in[i] = *reinterpret_cast<const uint4*>(src + row * cp + cg * 8);
+                if (!ok) in[i] = make_uint4(0, 0, 0, 0);
+            }
+            transpose8x8_bf16(in, out);
+            unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * PITCH + r8 * 16;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst + c * PITCH) = out[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KT / 16; ++kk) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (size_t)(t_co[j] * 32 + m) * PITCH + (kk * 2 + h) * 16);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (size_t)(t_ci[j] * 32 + m) * PITCH + (kk * 2 + h) * 16);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int cig = t_ci[j] * 32 + m;
+        if (t_ok[j] && cig < d.Cin) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int cog = t_co[j] * 32 + acc_row(reg, h);
+                if (cog < d.Cout) unsafeAtomicAdd(dw + (size_t)cog * d.Cin + cig, acc[j][reg]);
+            }
+        }
+    }
+}
+
+template <int KT, int TPW>
+static void launch_pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, int co_tiles, int ci_tiles, int gy,
+                                 hipStream_t s) {
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    // split-K partitions: enough blocks to fill the chip, but every partition ends in ntiles*1024 atomics on the same addresses
+    const long ntiles = (long)co_tiles * ci_tiles;
+    const long want_blocks = std::max<long>(1, std::min<long>(2048 / gy, std::max<long>(16, 3000 / ntiles)));
+    long rpb = std::max<long>(KT, (R + want_blocks - 1) / want_blocks);
+    rpb = (rpb + KT - 1) / KT * KT;
+    const dim3 grid(ceil_div(R, rpb), gy);
+    const size_t lds = (size_t)(co_tiles + ci_tiles) * 32 * WgLds<KT>::PITCH;
+    hipLaunchKernelGGL((pw_wgrad_bf16_kernel<KT, TPW>), grid, dim3(256), lds, s, (const __bf16*)x, (const __bf16*)dy, dw, d, co_tiles, ci_tiles,
+                       (int)rpb);
+}
+
+// returns false when the geometry is outside the fast path
+bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s) {
+    if (d.kt * d.kh * d.kw != 1 || d.pt || d.ph || d.pw) return false;
+    const int co_tiles = ceil_div(d.Cout_p, 32), ci_tiles = ceil_div(d.Cin_p, 32);
+    const int ntiles = co_tiles * ci_tiles;
+    const bool small = (co_tiles + ci_tiles) <= 6;  // few channels: stage more rows per step so every thread has a patch to move
+    const int KT = small ? 128 : 32;
+    if ((size_t)(co_tiles + ci_tiles) * 32 * (KT * 2 + 16) > 64 * 1024) return false;
+    int tpw = ceil_div(ntiles, 4);
+    tpw = tpw <= 1 ? 1 : tpw <= 2 ? 2 : tpw <= 4 ? 4 : 8;
+    const int gy = ceil_div(ntiles, 4 * tpw);
+#define PW(K, T) launch_pw_wgrad_bf16<K, T>(x, dy, dw, d, co_tiles, ci_tiles, gy, s)
+    if (small) {
+        if (tpw == 1) PW(128, 1);
+        else if (tpw == 2) PW(128, 2);
+        else PW(128, 4);
+    } else {
+        if (tpw == 1) PW(32, 1);
+        else if (tpw == 2) PW(32, 2);
+        else if (tpw == 4) PW(32, 4);
+        else PW(32, 8);
+    }
+#undef PW
+    return true;
+}
+
+}  // namespace pasn
+
+// ---- depthwise 3x3 (spatial) weight gradient, strip form -------------------------------------------------------------------
+// item = (channel group, strip of WT outputs along w, HR consecutive output rows of one (n, to) plane); one temporal tap per
+// blockIdx.z.  Per output row a thread loads the WT gradients and the three (WT-1)*SW+3 wide input rows once and feeds all nine
+// spatial taps from registers (the row-per-thread kernel above re-loads every input pixel nine times and pays an integer
+// division per row); the item decomposition is done once.  Partials per block, fixed-order combine by dw_wgrad_reduce_kernel.
+namespace pasn {
+
+template <int CH, typename T>
+__device__ __forceinline__ void loadc(const T* p, float (&v)[CH]) {
+    if constexpr (CH == 8) load8(p, v);
+    else load4(p, v);
+}
+
+// CH channels per thread (4: half the registers of 8, twice the resident waves -- the kernel is bound by load latency, not by
+// bytes per load instruction); CGb = lanes per position (power of two >= Cp / CH)
+template <typename T, int SW, int WT, int CH>
+__global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
+                                                             pasn_conv_desc d, int CG, int CGb, int strips, int HR, int hgroups, long items) {
+    __shared__ float red[256 * CH];
+    constexpr int IW = (WT - 1) * SW + 3;
+    const int cg = threadIdx.x % CGb, pl = threadIdx.x / CGb, PL = 256 / CGb;
+    const int a = blockIdx.z;
+    float acc[9][CH];
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[p][j] = 0.0f;
+    const long item = (long)blockIdx.x * PL + pl;  // over (n, to, hgroup, strip)
+    if (cg < CG && item < items) {
+        const int strip = (int)(item % strips);
+        long q = item / strips;
+        const int hg = (int)(q % hgroups);
+        q /= hgroups;
+        const int to = (int)(q % d.To), n = (int)(q / d.To);
+        const int ti = to * d.st - d.pt + a;
+        if (ti >= 0 && ti < d.Ti) {
+            const int wo0 = strip * WT, wi0 = wo0 * SW - 1;
+            const T* xp = x + (((size_t)n * d.Ti + ti) * d.Hi) * d.Wi * d.Cin_p + cg * CH;
+            const T* gp = dy + (((size_t)n * d.To + to) * d.Ho) * d.Wo * d.Cout_p + cg * CH;
+            const int h1 = min(d.Ho, (hg + 1) * HR);
+            for (int ho = hg * HR; ho < h1; ++ho) {
+                float g[WT][CH];
+#pragma unroll
+                for (int j = 0; j < WT; ++j) {
+                    const int wo = wo0 + j;
+                    const bool ok = wo < d.Wo;
+                    loadc<CH>(gp + ((size_t)ho * d.Wo + (ok ? wo : 0)) * d.Cout_p, g[j]);
+                    if (!ok) {
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) g[j][e] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+                    const int hi = ho * SW - 1 + dh;
+                    const bool hok = hi >= 0 && hi < d.Hi;
+                    float xr[IW][CH];
+#pragma unroll
+                    for (int i = 0; i < IW; ++i) {
+                        const int wi = wi0 + i;
+                        const bool ok = hok && wi >= 0 && wi < d.Wi;
+                        loadc<CH>(xp + ((size_t)(hok ? hi : 0) * d.Wi + (ok ? wi : 0)) * d.Cin_p, xr[i]);
+                        if (!ok) {
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) xr[i][e] = 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int dw_ = 0; dw_ < 3; ++dw_)
+#pragma unroll
+                        for (int j = 0; j < WT; ++j)
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) acc[dh * 3 + dw_][e] = fmaf(g[j][e], xr[j * SW + dw_][e], acc[dh * 3 + dw_][e]);
+                }
+            }
+        }
+    }
+    const int taps = d.kt * 9;
+    float* out = partial + ((size_t)blockIdx.x * taps + (size_t)a * 9) * d.Cout_p;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CH; ++j) red[threadIdx.x * CH + j] = acc[p][j];
+        __syncthreads();
+        for (int t = threadIdx.x; t < CGb * CH; t += 256) {
+            const int g2 = t / CH, j = t % CH;
+            if (g2 < CG) {
+                float s = 0.0f;
+                for (int q2 = 0; q2 < PL; ++q2) s += red[(q2 * CGb + g2) * CH + j];
+                out[(size_t)p * d.Cout_p + g2 * CH + j] = s;
+            }
+        }
+    }
+}
+
+// dw[c][tap] = sum_chunks partial[chunk][tap*Cp + c]: 64 columns x 4 parts per block, parts combined in a fixed order
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int taps, int C,
+                                                              int Cp) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int L = taps * Cp;
+    float s = 0.0f;
+    if (col < L) {
+#pragma unroll 8
+        for (int ch = part; ch < chunks; ch += 4) s += partial[(size_t)ch * L + col];
+    }
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && col < L) {
+        const float tsum = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const int tap = col / Cp, c = col % Cp;
+        if (c < C) dw[(size_t)c * taps + tap] = tsum;
+    }
+}
+
+struct DwWgGeom {
+    int ok, SW, WT, strips, HR, hgroups, CG, CGb, PL;
+    long items, blocks;
+};
+
+static DwWgGeom dw_wgrad_strip_geom(const pasn_conv_desc& d) {
+    DwWgGeom g{};
+    if (d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sh != d.sw || (d.sh != 1 && d.sh != 2)) return g;
+    if (d.Cout_p % 8 || d.Cout_p > 2048) return g;
+    g.SW = d.sh;
+    g.WT = g.SW == 1 ? 3 : 2;
+    g.strips = ceil_div(d.Wo, g.WT);
+    g.CG = d.Cout_p / 4;  // 4 channels per thread
+    if (g.CG > 256) return g;
+    g.CGb = 1;
+    while (g.CGb < g.CG) g.CGb <<= 1;
+    g.PL = 256 / g.CGb;
+    // rows per item: enough items to fill the chip a few times over, few enough partial blocks to keep the combine small
+    const long planes = (long)d.N * d.To;
+    int HR = d.Ho;
+    while (HR > 1 && planes * ceil_div(d.Ho, HR) * g.strips * g.CG < 400000) HR = (HR + 1) / 2;
+    g.HR = HR;
+    g.hgroups = ceil_div(d.Ho, HR);
+    g.items = planes * g.hgroups * g.strips;
+    g.blocks = (g.items + g.PL - 1) / g.PL;
+    g.ok = g.blocks <= 2147483647L;
+    return g;
+}
+
+}  // namespace pasn
+
+namespace pasn {
+
+size_t dw_wgrad_strip_floats(const pasn_conv_desc& d) {
+    const DwWgGeom g = dw_wgrad_strip_geom(d);
+    return g.ok ? (size_t)g.blocks * d.kt * 9 * d.Cout_p : 0;
+}
+
+bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const pasn_conv_desc& d, int dtype, hipStream_t s) {
+    const DwWgGeom g = dw_wgrad_strip_geom(d);
+    if (!g.ok) return false;
+    const dim3 grid((unsigned)g.blocks, 1, d.kt);
+#define DWS(T, SWv, WTv)                                                                                                              \
+    hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, SWv, WTv, 4>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, ws, d, g.CG, g.CGb, g.strips, \
+                       g.HR, g.hgroups, g.items)
+    if (dtype == PASN_BF16) {
+        if (g.SW == 1) DWS(__bf16, 1, 3);
+        else DWS(__bf16, 2, 2);
+    } else {
+        if (g.SW == 1) DWS(float, 1, 3);
+        else DWS(float, 2, 2);
+    }
+#undef DWS
+    const int taps = d.kt * 9;
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div((long)taps * d.Cout_p, 64)), dim3(256), 0, s, ws, dw, (int)g.blocks, taps, d.Cout,
+                       d.Cout_p);
+    return true;
+}
+
+}  // namespace pasn

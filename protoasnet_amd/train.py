@@ -47,6 +47,7 @@ class TrainBuilder(PlanBuilder):
         self._const: Dict[tuple, torch.Tensor] = {}
         self.nbt: List[torch.Tensor] = []      # num_batches_tracked counters bumped once per forward
         self.n_fwd = -1
+        self.op_names: List[str] = []
 
     # ---- small helpers -------------------------------------------------------------------------------------------
     def const(self, rows: int, value: float) -> torch.Tensor:
@@ -77,6 +78,7 @@ class TrainBuilder(PlanBuilder):
             _lib.check(fn(*[a(ptrs) if callable(a) else a for a in bound], st))
 
         self.ops.append(run)
+        self.op_names.append(getattr(fn, "__name__", "?"))
 
     @staticmethod
     def B(buf: Optional[int]):
@@ -263,8 +265,21 @@ class TrainBuilder(PlanBuilder):
                 self._use(x.buf, dy.buf, wsb)
                 self._op(lib.pasn_dwconv3d_wgrad, B(x.buf), B(dy.buf), B(wsb), dW, dref, code)
                 dx = self.like(x)
-                self._use(dy.buf, dx.buf)
-                self._op(lib.pasn_dwconv3d_dgrad, B(dy.buf), dw_w.data_ptr(), B(dx.buf), dref, code)
+                same = s == (1, 1, 1) and all(kk % 2 == 1 and pp == kk // 2 for kk, pp in zip(k, p))
+                if same:
+                    # stride-1 "same" depthwise conv: its input gradient is the forward stencil with the taps reversed
+                    # (the T-marching forward kernel, not the generic gather)
+                    wflip = torch.zeros(taps, Cp, dtype=torch.float32, device=self.device)
+                    self.refresh.append(lambda: wflip[:, :C].copy_(conv.weight.detach().reshape(C, taps).flip(1).t()))
+                    one_, zero_ = self.const(Cp, 1.0), self.const(Cp, 0.0)
+                    dflip = self._desc(dy, dx, k, s, p, "none")
+                    self.keep += [wflip]
+                    self._use(dy.buf, dx.buf)
+                    self._op(lib.pasn_dwconv3d_fwd, B(dy.buf), wflip.data_ptr(), one_.data_ptr(), zero_.data_ptr(), B(dx.buf), 0,
+                             ctypes.byref(dflip), code)
+                else:
+                    self._use(dy.buf, dx.buf)
+                    self._op(lib.pasn_dwconv3d_dgrad, B(dy.buf), dw_w.data_ptr(), B(dx.buf), dref, code)
                 self.add_grad(x, dx)
                 return
             self._use(x.buf, dy.buf)
@@ -348,7 +363,7 @@ class TrainBuilder(PlanBuilder):
 
 class TrainPlan:
     def __init__(self, tb: TrainBuilder, x_in: Act, ext: Dict[str, int], arena_bytes: int):
-        self.ops, self.n_fwd, self.keep, self.refresh = tb.ops, tb.n_fwd, tb.keep, tb.refresh
+        self.ops, self.n_fwd, self.keep, self.refresh, self.op_names = tb.ops, tb.n_fwd, tb.keep, tb.refresh, tb.op_names
         self.offsets = [None if b.external else b.offset for b in tb.bufs]
         self.in_buf, self.ext, self.gbuf = x_in.buf, ext, tb.gbuf
         self.pslots, self.gsize, self.nbt = tb.pslots, tb.gsize, tb.nbt

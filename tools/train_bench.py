@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Training-step benchmark (BASELINE.json config 3): clips/sec of forward + loss + backward + gradient all-reduce + Adam step
+of Video ProtoASNet (X3D-S trunk, head B) on synthetic echo batches, one process per GPU.
+
+    python tools/train_bench.py --steps 10 --warmup 3 [--dtype bf16|f32] [--batch 32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/train_bench.py --gpus N
+
+Loss: cross-entropy on the logits + the L1 norm of the occurrence maps + a cluster-style term on the similarities (plain torch
+ops on the tiny head outputs; the reference's loss stack is SURVEY.md section 8f row 1, not built).  The optimizer is
+torch.optim.Adam (lr 1e-4, weight_decay 1e-3) as in the reference's agents (Video_XProtoNet_e2e.py:36-62)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--arch", default="x3d_s")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--per-op", default="", help="write per-launch device times of one step to this file")
+    args = ap.parse_args(argv)
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        backend = os.environ.get("PASN_BENCH_BACKEND", "nccl")
+        dist.init_process_group("nccl", device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
+
+    from protoasnet_amd import dp, model_builder, synth
+
+    cfg = dict(checkpoint_path="", name="Video_XProtoNet", base_architecture=args.arch, backbone_last_layer_num=-3, pretrained=False,
+               prototype_shape="(30, 256, 1, 1, 1)", num_classes=3, img_size=args.size)
+    model = model_builder.build(cfg)
+    synth.load_synth(model)
+    model = model.to(dev).train()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.set_compute_dtype(dtype)
+    x = synth.echo_clips((args.batch, 3, args.frames, args.size, args.size), seed=synth.DEFAULT_SEED + rank).to(dev).to(dtype)
+    labels = torch.randint(0, 3, (args.batch,), generator=torch.Generator().manual_seed(rank)).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-3)
+    ident = model.prototype_class_identity.to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits, sim, occ = model(x)
+        own = ident[:, labels].t()  # (N, P): prototypes of the clip's class
+        loss = F.cross_entropy(logits, labels) + 1e-3 * occ.abs().mean() + 0.1 * ((1 - sim) * own).sum(1).mean()
+        loss.backward()
+        dp.allreduce_gradients(params)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss), "non-finite loss"
+    runner = next(iter(model._train_runners.values()))
+    if args.per_op and rank == 0:
+        plan = runner.plan
+        evs = []
+        orig = list(plan.ops)
+        def wrap(i, op):
+            def run(ptrs, st):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); op(ptrs, st); b.record(); evs.append((i, a, b))
+            return run
+        plan.ops[:] = [wrap(i, op) for i, op in enumerate(orig)]
+        step(); torch.cuda.synchronize()
+        plan.ops[:] = orig
+        with open(args.per_op, "w") as fh:
+            tot = 0.0
+            for i, a, b in evs:
+                ms = a.elapsed_time(b); tot += ms
+                fh.write(f"{i:4d} {'fwd' if i < plan.n_fwd else 'bwd'} {plan.op_names[i]:32s} {ms * 1e3:9.1f} us\n")
+            fh.write(f"total {tot:.3f} ms over {len(evs)} launches (event-bracketed, includes launch gaps)\n")
+            agg = {}
+            for i, a, b in evs:
+                k = ('fwd ' if i < plan.n_fwd else 'bwd ') + plan.op_names[i]
+                agg.setdefault(k, [0.0, 0])
+                agg[k][0] += a.elapsed_time(b); agg[k][1] += 1
+            for k, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                fh.write(f"SUM {k:40s} {n:4d} launches {ms:9.3f} ms\n")
+    if rank == 0:
+        plan = runner.plan
+        print(json.dumps({
+            "metric": "clips/sec train step", "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Video ProtoASNet train step (fwd + loss + bwd + grad all-reduce + Adam), {args.arch} + head B, "
+                                   f"{args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world} (one flat fp32 gradient bucket all-reduced per step)"},
+            "launches": {"forward": plan.n_fwd, "backward": len(plan.ops) - plan.n_fwd}, "arena_bytes": plan.arena_bytes,
+            "naive_bytes": plan.naive_bytes, "grad_bucket_bytes": plan.gsize * 4, "loss": round(float(loss), 5),
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
