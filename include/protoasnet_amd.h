@@ -297,6 +297,9 @@ int pasn_se_gate_bwd(const float* ws, const float* pool_u, const float* w1, cons
  * `accumulate` every other element of dst is zeroed (the input gradient of a strided 1x1x1 conv; zero insertion). */
 int pasn_scatter_strided(const void* src, void* dst, const pasn_conv_desc* d, int accumulate, int dtype, void* stream);
 int pasn_add_inplace(void* a, const void* b, size_t elements, int dtype, void* stream);
+/* Max-pool backward (resnet_features.py:206 in training): dx receives dy of every window whose first maximum (scan order t, h, w:
+ * the index torch records) the element is; x is the pooling INPUT, d the forward descriptor. */
+int pasn_maxpool3d_bwd(const void* x, const void* dy, void* dx, const pasn_conv_desc* d, int dtype, void* stream);
 
 /* Weight gradients.  dw is fp32 in the PARAMETER layout and must be zeroed by the caller for the two MFMA kernels:
  *   pasn_conv3d_wgrad      dw [Cout][Cin][kt*kh*kw]  += sum_rows dy[row][co] * x[in(row, tap)][ci]

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pasn_se_gate_bwd": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "pasn_scatter_strided": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
     "pasn_add_inplace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "pasn_maxpool3d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_first_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
     "pasn_dwconv3d_wgrad_workspace_floats": (c_size_t, [POINTER(ConvDesc)]),

@@ -82,6 +82,17 @@ class ResNet18Features(_plan.HipTrunk):
         return x
 
 
+    def build_train(self, tb, x):
+        x = tb.unit(x, self.conv1, self.bn1, "relu", kind="first")
+        x = tb.maxpool_unit(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}"):
+                identity = x if blk.downsample is None else tb.unit(x, blk.downsample[0], blk.downsample[1], "none")
+                y = tb.unit(x, blk.conv1, blk.bn1, "relu")
+                x = tb.unit(y, blk.conv2, blk.bn2, "relu", residual=identity)
+        return x
+
+
 def resnet18_features(pretrained: bool = False, **kwargs) -> ResNet18Features:
     if pretrained:
         raise RuntimeError(
@@ -165,6 +176,22 @@ class resnet2p1d_18(_plan.HipTrunk):  # noqa: N801 -- name is part of the refere
                 c = blk.conv2[0]
                 y = pb.conv(y, c[0], c[1], act="relu")
                 x = pb.conv(y, c[3], blk.conv2[1], act="relu", residual=identity)
+        return x
+
+
+    def build_train(self, tb, x):
+        stem = self.backbone[0]
+        x = tb.unit(x, stem[0], stem[1], "relu", kind="first")
+        x = tb.unit(x, stem[3], stem[4], "relu")
+        for layer in list(self.backbone)[1:]:
+            for blk in layer:
+                identity = x if blk.downsample is None else tb.unit(x, blk.downsample[0], blk.downsample[1], "none")
+                c = blk.conv1[0]
+                y = tb.unit(x, c[0], c[1], "relu")
+                y = tb.unit(y, c[3], blk.conv1[1], "relu")
+                c = blk.conv2[0]
+                y = tb.unit(y, c[0], c[1], "relu")
+                x = tb.unit(y, c[3], blk.conv2[1], "relu", residual=identity)
         return x
 
 

@@ -450,6 +450,60 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ a, con
     }
 }
 
+// ---- max-pool backward (gather form, no atomics): an input element receives dy of every window whose FIRST maximum (scan
+// order t, h, w -- the index torch's forward records) it is ------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, pasn_conv_desc d) {
+    const int CG = d.Cin_p / 8;
+    const size_t total = (size_t)d.N * d.Ti * d.Hi * d.Wi * CG;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        const size_t row = i / CG;
+        const int wi = (int)(row % d.Wi);
+        size_t q = row / d.Wi;
+        const int hi = (int)(q % d.Hi);
+        q /= d.Hi;
+        const int ti = (int)(q % d.Ti), n = (int)(q / d.Ti);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        const T* xn = x + (size_t)n * d.Ti * d.Hi * d.Wi * d.Cin_p + cg * 8;
+        for (int to = max(0, (ti + d.pt - d.kt + d.st) / d.st); to <= min(d.To - 1, (ti + d.pt) / d.st); ++to)
+            for (int ho = max(0, (hi + d.ph - d.kh + d.sh) / d.sh); ho <= min(d.Ho - 1, (hi + d.ph) / d.sh); ++ho)
+                for (int wo = max(0, (wi + d.pw - d.kw + d.sw) / d.sw); wo <= min(d.Wo - 1, (wi + d.pw) / d.sw); ++wo) {
+                    float best[8];
+                    int bidx[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        best[j] = -INFINITY;
+                        bidx[j] = -1;
+                    }
+                    for (int a = 0; a < d.kt; ++a)
+                        for (int b = 0; b < d.kh; ++b)
+                            for (int c = 0; c < d.kw; ++c) {
+                                const int t2 = to * d.st - d.pt + a, h2 = ho * d.sh - d.ph + b, w2 = wo * d.sw - d.pw + c;
+                                if (t2 < 0 || t2 >= d.Ti || h2 < 0 || h2 >= d.Hi || w2 < 0 || w2 >= d.Wi) continue;
+                                const int lin = (t2 * d.Hi + h2) * d.Wi + w2;
+                                float v[8];
+                                load8(xn + (size_t)lin * d.Cin_p, v);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    if (v[j] > best[j] || (v[j] != v[j] && bidx[j] < 0)) {
+                                        best[j] = v[j];
+                                        bidx[j] = lin;
+                                    }
+                            }
+                    const int me = (ti * d.Hi + hi) * d.Wi + wi;
+                    float g[8];
+                    load8(dy + ((((size_t)n * d.To + to) * d.Ho + ho) * d.Wo + wo) * d.Cout_p + cg * 8, g);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (bidx[j] == me) acc[j] += g[j];
+                }
+        store8(dx + row * d.Cin_p + cg * 8, acc);
+    }
+}
+
 }  // namespace pasn
 
 using namespace pasn;
@@ -593,4 +647,17 @@ extern "C" int pasn_add_inplace(void* a, const void* b, size_t elements, int dty
     if (dtype == PASN_BF16) hipLaunchKernelGGL(add_inplace_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (__bf16*)a, (const __bf16*)b, groups);
     else hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)a, (const float*)b, groups);
     return check_launch("add_inplace");
+}
+
+extern "C" int pasn_maxpool3d_bwd(const void* x, const void* dy, void* dx, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && dy && dx && d, "null pointer");
+    PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0, "pooling keeps the channel stride");
+    const size_t total = (size_t)d->N * d->Ti * d->Hi * d->Wi * (d->Cin_p / 8);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx, *d);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, *d);
+    return check_launch("maxpool3d_bwd");
 }

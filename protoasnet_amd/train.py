@@ -285,25 +285,65 @@ class TrainBuilder(PlanBuilder):
             self._use(x.buf, dy.buf)
             self._op(lib.pasn_conv3d_wgrad, B(x.buf), B(dy.buf), dW, dref, code)
             # ---- input gradient of the dense conv
-            if taps != 1 or p != (0, 0, 0):
-                raise NotImplementedError("training covers 1x1x1 dense convs, depthwise convs and the first conv (the X3D trunks and head B)")
             one = (1, 1, 1)
-            wt = lambda: conv.weight.detach().reshape(cout, cin).t()
             have = self.grads.get(x.buf)
-            if s == one:
-                dx = self.like(x)
-                self._dense(dy, dx, one, one, (0, 0, 0), cin, cout, wt, residual=have)
-                self.grads[x.buf] = dx
+            if taps == 1 and p == (0, 0, 0):
+                # 1x1x1: the same pointwise kernel with the transposed weight; strided ones on the compact grid, then scattered
+                wt = lambda: conv.weight.detach().reshape(cout, cin).t()
+                if s == one:
+                    dx = self.like(x)
+                    self._dense(dy, dx, one, one, (0, 0, 0), cin, cout, wt, residual=have)
+                    self.grads[x.buf] = dx
+                else:
+                    compact = Act(y.N, y.T, y.H, y.W, cin, x.Cp, self._new_buf(y.N * y.positions * x.Cp * self.es))
+                    self._dense(dy, compact, one, one, (0, 0, 0), cin, cout, wt)
+                    dst = have if have is not None else self.like(x)
+                    self._use(compact.buf, dst.buf)
+                    self._op(lib.pasn_scatter_strided, B(compact.buf), B(dst.buf), dref, int(have is not None), code)
+                    self.grads[x.buf] = dst
+                return
+            # windowed conv: correlate the (zero-inserted, for strides > 1) output gradient with the reversed, transposed weight,
+            # padding k-1-p -- the forward implicit-GEMM kernel again.  Extent Z = Ti + 2p - k + 1 covers output_padding.
+            wtf = lambda: (conv.weight.detach() if conv.weight.dim() == 5 else conv.weight.detach().unsqueeze(2)).transpose(0, 1).flip(2, 3, 4)
+            padb = tuple(kk - 1 - pp for kk, pp in zip(k, p))
+            Z = (x.T + 2 * p[0] - k[0] + 1, x.H + 2 * p[1] - k[1] + 1, x.W + 2 * p[2] - k[2] + 1)
+            src = dy
+            if s != one:
+                zi = Act(y.N, Z[0], Z[1], Z[2], cout, y.Cp, self._new_buf(y.N * Z[0] * Z[1] * Z[2] * y.Cp * self.es))
+                zd = ConvDesc(N=y.N, Ti=Z[0], Hi=Z[1], Wi=Z[2], Cin=cout, Cin_p=y.Cp, To=y.T, Ho=y.H, Wo=y.W, Cout=cout, Cout_p=y.Cp,
+                              kt=1, kh=1, kw=1, st=s[0], sh=s[1], sw=s[2])
+                self.keep.append(zd)
+                self._use(dy.buf, zi.buf)
+                self._op(lib.pasn_scatter_strided, B(dy.buf), B(zi.buf), ctypes.byref(zd), 0, code)
+                src = zi
             else:
-                compact = Act(y.N, y.T, y.H, y.W, cin, x.Cp, self._new_buf(y.N * y.positions * x.Cp * self.es))
-                self._dense(dy, compact, one, one, (0, 0, 0), cin, cout, wt)
-                dst = have if have is not None else self.like(x)
-                self._use(compact.buf, dst.buf)
-                self._op(lib.pasn_scatter_strided, B(compact.buf), B(dst.buf), dref, int(have is not None), code)
-                self.grads[x.buf] = dst
+                assert (y.T, y.H, y.W) == Z
+            dx = self.like(x)
+            self._dense(src, dx, k, one, padb, cin, cout, wtf, residual=have)
+            self.grads[x.buf] = dx
 
         self.tape.append(backward)
         return out
+
+    # ---- max pooling (ResNet-18 stem) ----------------------------------------------------------------------------------
+    def maxpool_unit(self, x: Act, k, s, p) -> Act:
+        y = self._out_act(x, x.C, k, s, p)
+        d = self._desc(x, y, k, s, p, "none")
+        dref, code, lib, B = ctypes.byref(d), self.code, self.lib, self.B
+        self._use(x.buf, y.buf)
+        self._op(lib.pasn_maxpool3d_fwd, B(x.buf), B(y.buf), dref, code)
+
+        def backward() -> None:
+            g = self.grads.get(y.buf)
+            if g is None:
+                return
+            dx = self.like(x)
+            self._use(x.buf, g.buf, dx.buf)
+            self._op(lib.pasn_maxpool3d_bwd, B(x.buf), B(g.buf), B(dx.buf), dref, code)
+            self.add_grad(x, dx)
+
+        self.tape.append(backward)
+        return y
 
     # ---- head B tail ----------------------------------------------------------------------------------------------
     def xproto_tail(self, z: Optional[Act], r: Act, model, ext: Dict[str, int]) -> None:

@@ -65,3 +65,41 @@ def test_sharded_push_merge_world2(tmp_path):
         assert torch.equal(o["vec"], torch.stack([torch.from_numpy(v) for v in full_f]))
         assert np.array_equal(o["dist"].numpy(), full_d.astype(np.float32))
         assert o["pindex"].tolist() == [[2, 7], [9, 0]] and o["pvec"].tolist() == [[1.0, 1.0], [0.0, 0.0]]
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from protoasnet_amd.dp import allreduce_gradients
+
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((7, 3, 1, 1, 1), (5,), (2, 9), (4,))]
+    g = torch.Generator().manual_seed(100 + rank)
+    for i, p in enumerate(params):
+        if i != 3:  # a parameter without a gradient (frozen / unused) is skipped on every rank alike
+            p.grad = torch.randn(p.shape, generator=g)
+    nbytes = allreduce_gradients(params)
+    torch.save({"grads": [None if p.grad is None else p.grad.clone() for p in params], "nbytes": nbytes}, os.path.join(out_dir, f"dp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gradient_bucket_allreduce_world2(tmp_path):
+    """The data-parallel training exchange (one flat fp32 bucket, averaged): every rank ends with the mean of the ranks' gradients."""
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    shapes = ((7, 3, 1, 1, 1), (5,), (2, 9))
+    want = []
+    for s in shapes:
+        want.append(torch.zeros(s))
+    per_rank = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        per_rank.append([torch.randn(s, generator=g) for s in shapes])
+    mean = [(per_rank[0][i] + per_rank[1][i]) / 2 for i in range(len(shapes))]
+    for r in range(world):
+        o = torch.load(os.path.join(tmp_path, f"dp{r}.pt"))
+        assert o["grads"][3] is None and o["nbytes"] == sum(t.numel() for t in mean) * 4
+        for got, ref in zip(o["grads"][:3], mean):
+            assert torch.allclose(got, ref, atol=1e-6)

@@ -15,7 +15,7 @@ import oracle
 from conftest import assert_close
 from protoasnet_amd import _lib, synth
 from protoasnet_amd._lib import ConvDesc, XProtoDesc
-from util import CFG_VIDEO_X3D, synth_model
+from util import CFG_VIDEO_R2P1D, CFG_VIDEO_X3D, CFG_XPROTO, synth_model
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -284,12 +284,14 @@ def test_xproto_tail_forward_backward(occ_only):
 # kernel, the tape order, residual / shortcut accumulation, SE, Swish, the head and the parameter slots; the ReLU derivative
 # itself is pinned by the kernel-level tests above.  The unmodified model is then checked with bounds a mask flip cannot
 # break but a wiring error would (strict forward outputs, global gradient direction).
-def _train_model(kink_free):
-    m = synth_model(CFG_VIDEO_X3D).to(DEV)
+def _train_model(kink_free, cfg=CFG_VIDEO_X3D):
+    m = synth_model(cfg).to(DEV)
     if kink_free:
+        relu_fed = {n + ".bias" for n, mod in m.named_modules() if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))
+                    and not any(t in n for t in ("downsample", "shortcut", "bn_b"))}  # norms whose output (or residual sum) feeds a ReLU
         with torch.no_grad():
             for name, p in m.named_parameters():
-                if name.endswith(("stem.bn.bias", "bn_a.bias", "bn_c.bias")):
+                if name in relu_fed:
                     p += 2.5
     return m.train()
 
@@ -299,9 +301,9 @@ def _loss_weights(n, p, k, spatial, seed=5):
     return torch.randn(n, k, generator=g), torch.randn(n, p, generator=g), torch.randn((n, p, 1) + spatial, generator=g) * 0.1
 
 
-def _oracle_step(sd, x, wl, ws, wo, occurrence_only=False):
+def _oracle_step(sd, x, wl, ws, wo, occurrence_only=False, arch="x3d_s"):
     sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
-    out = oracle.nets.xprotonet_train_forward(sd, x, arch="x3d_s", occurrence_only=occurrence_only)
+    out = oracle.nets.xprotonet_train_forward(sd, x, arch=arch, occurrence_only=occurrence_only)
     if occurrence_only:
         loss = (out["occurrence_map"] * wo).sum()
     else:
@@ -395,6 +397,30 @@ def test_video_x3d_compute_occurence_map_train_and_second_step():
     ref, sd_ref2, _ = _oracle_step(sd2, x, wl, ws, wo)
     _rel(logits, ref["logits"], 1e-3, "logits after the step")
     _check_grads(m, sd_ref2, 1e-3)
+
+
+@pytest.mark.parametrize("cfg,shape,spatial", [(CFG_XPROTO, (3, 3, 96, 96), (3, 3)), (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4))],
+                         ids=["xprotonet_resnet18", "video_r2plus1d"])
+def test_reference_trunks_train_step_fp32_vs_oracle_autograd(cfg, shape, spatial):
+    """The reference's own trunks (2-D ResNet-18 with max-pool, R(2+1)D-18[:-3]: windowed dense convs, strided in space and time)
+    through the same training path: outputs, every parameter gradient, running statistics."""
+    m = _train_model(kink_free=True, cfg=cfg)
+    arch, n = cfg["base_architecture"], shape[0]
+    P, K = m.num_prototypes, m.num_classes
+    x = synth.echo_clips(shape)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    wl, ws, wo = _loss_weights(n, P, K, spatial)
+    logits, sim, occ = m(x.to(DEV))
+    ((logits * wl.to(DEV)).sum() + (sim * ws.to(DEV)).sum() + (occ * wo.to(DEV)).sum()).backward()
+    ref, sd_ref, _ = _oracle_step(sd0, x, wl, ws, wo, arch=arch)
+    _rel(logits, ref["logits"], 1e-3, "logits")
+    _rel(sim, ref["similarity"], 1e-3, "similarity")
+    _rel(occ, ref["occurrence_map"], 1e-3, "occurrence_map")
+    _check_grads(m, sd_ref, 1e-3)
+    sd1 = m.state_dict()
+    for k_, v in sd_ref.items():
+        if "running_" in k_:
+            _rel(sd1[k_], v, 1e-4, k_)
 
 
 def test_video_x3d_train_unmodified_model_vs_oracle():
