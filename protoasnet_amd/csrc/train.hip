@@ -22,7 +22,7 @@ static RowGeom row_geom(int N, int S, int Cp) {
     g.CGb = b;
     g.RL = 256 / b;
     const int want = std::max(1, 1024 / std::max(1, N));
-    const int maxc = std::max(1, S / (g.RL * 4));
+    const int maxc = std::max(1, S / (g.RL * 16));  // small tensors: fewer partials, the finalize pass is pure latency
     g.chunks = std::min(want, maxc);
     g.rows_per_chunk = ceil_div(S, g.chunks);
     g.chunks = ceil_div(S, g.rows_per_chunk);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     float a1 = 0.0f, a2 = 0.0f;
     if (live) {
         const int total = N * chunks;
-#pragma unroll 4
+#pragma unroll 8
         for (int i = part; i < total; i += 16) {
             const float* p = ws + (size_t)i * 2 * Cp + c;
             a1 += p[0];
@@ -284,12 +284,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int c = blockIdx.x * 16 + cl;
     const bool live = c < Cp;
     float a1 = 0.0f, a2 = 0.0f;
-    if (live)
-        for (int i = part; i < N * chunks; i += 16) {
+    if (live) {
+        const int total = N * chunks;
+#pragma unroll 8
+        for (int i = part; i < total; i += 16) {
             const float* p = ws + (size_t)i * 2 * Cp + c;
             a1 += p[0];
             a2 += p[Cp];
         }
+    }
     red[0][part][cl] = a1;
     red[1][part][cl] = a2;
     __syncthreads();

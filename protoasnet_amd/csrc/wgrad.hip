@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_finalize_kernel(const float* __r
     dw[(size_t)c * taps + tap] = s;
 }
 
+__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int taps, int C, int Cp);
 bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s);
 size_t dw_wgrad_strip_floats(const pasn_conv_desc& d);
 bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const pasn_conv_desc& d, int dtype, hipStream_t s);
@@ -269,7 +270,7 @@ static long dw_wgrad_rows_per_chunk(const pasn_conv_desc& d) {
     int CG = d.Cout_p / 8, b = 1;
     while (b < CG) b <<= 1;
     const int RL = 256 / b;
-    const long chunks = std::max<long>(1, std::min<long>(512, R / ((long)RL * 8)));
+    const long chunks = std::max<long>(1, std::min<long>(2048, R / ((long)RL * 8)));
     return (R + chunks - 1) / chunks;
 }
 
@@ -322,9 +323,82 @@ extern "C" int pasn_first_conv_wgrad(const void* x, const void* dy, float* dw, c
     return check_launch("first_conv_wgrad");
 }
 
+// 3x3x3, stride (1,2,2), pad 1 (the first block of every X3D stage): a thread owns a 2x2 input patch.  Even rows / columns
+// see only the centre tap, odd ones the two outer taps, so the four pixels need dy[to][i..i+1][j..j+1] for the three temporal
+// taps -- 12 loads and 27 FMAs per channel for 4 outputs, no divergent tap loop.
+template <typename T>
+__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
+                                                          pasn_conv_desc d) {
+    const int CG = d.Cin_p / 8, Hh = (d.Hi + 1) / 2, Wh = (d.Wi + 1) / 2;
+    const size_t total = (size_t)d.N * d.Ti * Hh * Wh * CG;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cg = (int)(idx % CG);
+        size_t q = idx / CG;
+        const int j = (int)(q % Wh);
+        q /= Wh;
+        const int i = (int)(q % Hh);
+        q /= Hh;
+        const int ti = (int)(q % d.Ti), n = (int)(q / d.Ti);
+        float o[2][2][8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[a][b][e] = 0.0f;
+        for (int kt = 0; kt < 3; ++kt) {
+            const int to = ti + 1 - kt;
+            if (to < 0 || to >= d.To) continue;
+            float g[2][2][8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int ho = i + a, wo = j + b;
+                    const bool ok = ho < d.Ho && wo < d.Wo;
+                    load8(dy + ((((size_t)n * d.To + to) * d.Ho + (ok ? ho : 0)) * d.Wo + (ok ? wo : 0)) * d.Cout_p + cg * 8, g[a][b]);
+                    if (!ok) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) g[a][b][e] = 0.0f;
+                    }
+                }
+            const float* wk = w + (size_t)kt * 9 * d.Cout_p + cg * 8;
+            float wv[9][8];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) load8(wk + (size_t)tp * d.Cout_p, wv[tp]);
+            // input (2i+a, 2j+b) <- output (ho, wo) through tap (kh, kw) with 2*ho - 1 + kh = 2i + a
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[0][0][e] = fmaf(g[0][0][e], wv[4][e], o[0][0][e]);                                             // (1,1)
+                o[0][1][e] = fmaf(g[0][0][e], wv[5][e], fmaf(g[0][1][e], wv[3][e], o[0][1][e]));                  // (1,2) from j, (1,0) from j+1
+                o[1][0][e] = fmaf(g[0][0][e], wv[7][e], fmaf(g[1][0][e], wv[1][e], o[1][0][e]));                  // (2,1) from i, (0,1) from i+1
+                o[1][1][e] = fmaf(g[0][0][e], wv[8][e], fmaf(g[0][1][e], wv[6][e],
+                             fmaf(g[1][0][e], wv[2][e], fmaf(g[1][1][e], wv[0][e], o[1][1][e]))));
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int hi = 2 * i + a, wi = 2 * j + b;
+                if (hi < d.Hi && wi < d.Wi) store8(dx + ((((size_t)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.Cin_p + cg * 8, o[a][b]);
+            }
+    }
+}
+
 extern "C" int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, const pasn_conv_desc* d, int dtype, void* stream) {
     PASN_REQUIRE(dy && w && dx && d, "null pointer");
     PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0, "depthwise conv keeps the channel stride");
+    if (d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 1 && d->ph == 1 && d->pw == 1 &&
+        !getenv("PASN_NO_DGRAD_S2")) {
+        const size_t items = (size_t)d->N * d->Ti * ((d->Hi + 1) / 2) * ((d->Wi + 1) / 2) * (d->Cin_p / 8);
+        const int nb = (int)std::min<size_t>((items + 255) / 256, 1 << 20);
+        if (dtype == PASN_BF16)
+            hipLaunchKernelGGL(dw_dgrad_s2_kernel<__bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, w, (__bf16*)dx, *d);
+        else
+            hipLaunchKernelGGL(dw_dgrad_s2_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, *d);
+        return check_launch("dwconv3d_dgrad");
+    }
     const size_t total = (size_t)d->N * d->Ti * d->Hi * d->Wi * (d->Cin_p / 8);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
     hipStream_t s = (hipStream_t)stream;
@@ -360,7 +434,7 @@ extern "C" int pasn_dwconv3d_wgrad(const void* x, const void* dy, float* ws, flo
         hipLaunchKernelGGL(dw_wgrad_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, ws, *d, CG, CGb, rpc);
     else
         hipLaunchKernelGGL(dw_wgrad_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dy, ws, *d, CG, CGb, rpc);
-    hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3(ceil_div((long)taps * d->Cout_p, 256)), dim3(256), 0, s, ws, dw, chunks, taps, d->Cout,
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div((long)taps * d->Cout_p, 64)), dim3(256), 0, s, ws, dw, chunks, taps, d->Cout,
                        d->Cout_p);
     return check_launch("dwconv3d_wgrad");
 }
@@ -553,8 +627,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
     for (int p = 0; p < 9; ++p)
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[p][j] = 0.0f;
-    const long item = (long)blockIdx.x * PL + pl;  // over (n, to, hgroup, strip)
-    if (cg < CG && item < items) {
+    // over (n, to, hgroup, strip); a block keeps accumulating over several item groups before its one partial is written
+    for (long item = (long)blockIdx.x * PL + pl; cg < CG && item < items; item += (long)gridDim.x * PL) {
         const int strip = (int)(item % strips);
         long q = item / strips;
         const int hg = (int)(q % hgroups);
@@ -666,8 +740,10 @@ static DwWgGeom dw_wgrad_strip_geom(const pasn_conv_desc& d) {
     g.HR = HR;
     g.hgroups = ceil_div(d.Ho, HR);
     g.items = planes * g.hgroups * g.strips;
-    g.blocks = (g.items + g.PL - 1) / g.PL;
-    g.ok = g.blocks <= 2147483647L;
+    // at most 768 blocks per temporal tap: each block loops over its item groups, so the partial buffer (and the combine
+    // pass over it) stays small however many items there are
+    g.blocks = std::min<long>((g.items + g.PL - 1) / g.PL, 768);
+    g.ok = 1;
     return g;
 }
 

@@ -191,9 +191,11 @@ class PPNet(nn.Module):
 
     def _guard(self, x: torch.Tensor) -> None:
         if self.training:
-            raise NotImplementedError("train-mode forward / backward is not built yet: call .eval() (see DESIGN.md)")
+            raise NotImplementedError("train-mode forward / backward of the ProtoPNet head (head A) is not built yet: call .eval(); "
+                                      "the XProtoNet / Video_XProtoNet models train (see DESIGN.md)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP forward has no autograd backward yet: run it under torch.no_grad()")
+            raise NotImplementedError("the eval-mode HIP forward records no autograd graph: run it under torch.no_grad(), "
+                                      "or call .train() for the differentiable (batch-statistics) pass")
         if not x.is_cuda:
             raise RuntimeError("protoasnet_amd models run on the GPU only; there is no CPU fallback")
 

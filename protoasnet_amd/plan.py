@@ -511,8 +511,7 @@ class HipTrunk(nn.Module):
 
     def build_train(self, tb, x: Act) -> Act:
         raise NotImplementedError(
-            f"{type(self).__name__}: the training path (batch-statistics norm + backward) covers the X3D trunks; "
-            "this trunk runs eval / push / forward-throughput only so far"
+            f"{type(self).__name__}: no training launch list is defined for this trunk"
         )
 
     def _signature(self) -> tuple:
@@ -538,12 +537,12 @@ class HipTrunk(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
             raise NotImplementedError(
-                f"{type(self).__name__}: train-mode forward (batch-statistics norm + backward) is not built yet; "
-                "call .eval() -- the HIP path implements the reference's eval / push / clips-per-second forward"
+                f"{type(self).__name__}: a trunk on its own runs eval-mode inference only -- call .eval(); training compiles trunk + "
+                "head of a XProtoNet / Video_XProtoNet model into one forward + backward launch list (model.train(); train.py)"
             )
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
-                f"{type(self).__name__}: the HIP forward has no autograd backward yet; run it under torch.no_grad()"
+                f"{type(self).__name__}: the eval-mode HIP forward records no autograd graph; run it under torch.no_grad()"
             )
         if not x.is_cuda:
             raise RuntimeError("protoasnet_amd trunks run on the GPU only (input is on %s); there is no CPU fallback" % x.device)

@@ -121,9 +121,11 @@ def test_module_surface_and_errors():
     x = synth.echo_clips((1, 3, 4, 64, 64)).to(DEV)
     with pytest.raises(NotImplementedError, match="no_grad"):
         m(x)  # grad enabled + trainable parameters: refuse instead of silently returning graph-less tensors
-    m.train()
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="eval"):
-        m(x)
+    m.train()  # train mode is the differentiable path (batch-statistics norm; tests/test_gpu_train.py)
+    logits, sim, occ = m(x)
+    assert logits.requires_grad and sim.requires_grad and occ.requires_grad
+    with pytest.raises(NotImplementedError, match="eval"):
+        m.cnn_backbone(x)  # a trunk on its own has no training pass: the model compiles trunk + head as one launch list
     m.eval()
     with torch.no_grad(), pytest.raises(RuntimeError, match="GPU only"):
         m(x.cpu())
