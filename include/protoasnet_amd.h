@@ -324,6 +324,13 @@ int pasn_xproto_tail_bwd(const void* z, const void* r, const float* protos, cons
                          const float* dlogits, const float* dsim, const float* docc, float* dfeat, void* dz, void* dr, float* dprotos,
                          float* dfc_w, const pasn_xproto_desc* d, int dtype, void* stream);
 
+/* Head A (ProtoPNet) backward of pasn_l2_head_fwd (ProtoPNet.py:189-243 under autograd): only the arg-min position of each
+ * (image, prototype) carries gradient.  dlogits [N][K], dmin [N][P] or NULL (the cluster / separation costs act on
+ * min_distances) -> dz dtype [N][S][Dp] (fully written), dprotos [P][D], dfc_w [K][P]; coef fp32 [N][P] is scratch. */
+int pasn_l2_head_bwd(const void* z, const float* protos, const float* fc_w, const float* min_dist, const int32_t* argmin,
+                     const float* dlogits, const float* dmin, void* dz, float* coef, float* dprotos, float* dfc_w, int N, int S, int D,
+                     int Dp, int P, int K, int dtype, int activation, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

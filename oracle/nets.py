@@ -53,3 +53,11 @@ def xprotonet_train_forward(sd, x, arch="x3d_s", last_layer_num=-3, occurrence_o
     if occurrence_only:
         return {"occurrence_map": heads.occurrence_map_abs(sd, feat)}
     return heads.xproto_head(sd, feat, contract=True)
+
+
+def ppnet_train_forward(sd, x, arch="resnet18", activation="log", epsilon=1e-4):
+    """``PPNet.forward`` (src/models/ProtoPNet.py:225-243) in TRAIN mode with autograd enabled (ProtoPNet_Base.py trains through it)."""
+    with backbones.train_mode():
+        feat = backbones.trunk(arch, sd, "features.", x)
+    conv_features = heads.add_on_layers(sd, feat, final_sigmoid=True)
+    return heads.ppnet_head(sd, conv_features, activation, epsilon)

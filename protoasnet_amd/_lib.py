@@ -70,6 +70,7 @@ SIGNATURES = {
     "pasn_dwconv3d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_xproto_tail_fwd": (c_int, [c_void_p] * 8 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_xproto_tail_bwd": (c_int, [c_void_p] * 14 + [POINTER(XProtoDesc), c_int, c_void_p]),
+    "pasn_l2_head_bwd": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_void_p]),
     "pasn_push_ppnet_update": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
 }
 

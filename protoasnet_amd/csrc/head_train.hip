@@ -235,3 +235,85 @@ extern "C" int pasn_xproto_tail_bwd(const void* z, const void* r, const float* p
                            (float*)dr, d->S, d->D, d->Dp, d->P, d->Pp);
     return check_launch("xproto_tail_bwd");
 }
+
+// ---- head A (ProtoPNet) backward ------------------------------------------------------------------------------------------
+// Forward (pasn_l2_head_fwd; ProtoPNet.py:189-243): dist = relu(|z|^2 - 2 z.p + |p|^2), min over positions (argmin s*),
+// sim = log((d+1)/(d+eps)) or -d, logits = sim . W^T.  Only the arg-min position of each (clip, prototype) carries gradient:
+//   g[n][p] = dmin[n][p] + (sum_k dlogits[n][k] W[k][p]) * sim'(d),   dz[n][s*][:] += 2 g (z - p),   dp[p][:] += 2 g (p - z)
+namespace pasn {
+
+__device__ __forceinline__ float l2_sim(float d, int activation, float eps) { return activation == 0 ? logf((d + 1.0f) / (d + eps)) : -d; }
+__device__ __forceinline__ float l2_dsim(float d, int activation, float eps) { return activation == 0 ? 1.0f / (d + 1.0f) - 1.0f / (d + eps) : -1.0f; }
+
+// one block per clip: zero dz[n], then walk the prototypes in order (a thread owns its channels, so two prototypes sharing an
+// arg-min position accumulate without a race and in a fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void l2_head_bwd_z_kernel(const T* __restrict__ z, const float* __restrict__ protos, const float* __restrict__ fc_w,
+                                                            const float* __restrict__ min_dist, const int32_t* __restrict__ argmin,
+                                                            const float* __restrict__ dlogits, const float* __restrict__ dmin, T* __restrict__ dz,
+                                                            float* __restrict__ coef, int S, int D, int Dp, int P, int K, int activation,
+                                                            float eps) {
+    const int n = blockIdx.x;
+    T* dzn = dz + (size_t)n * S * Dp;
+    const T* zn = z + (size_t)n * S * Dp;
+    for (size_t i = threadIdx.x; i < (size_t)S * Dp; i += 256) dzn[i] = (T)0.0f;
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {
+        const float d = min_dist[(size_t)n * P + p];
+        float ds = 0.0f;
+        for (int k = 0; k < K; ++k) ds = fmaf(dlogits[(size_t)n * K + k], fc_w[(size_t)k * P + p], ds);
+        const float g = (dmin ? dmin[(size_t)n * P + p] : 0.0f) + ds * l2_dsim(d, activation, eps);
+        if (threadIdx.x == 0) coef[(size_t)n * P + p] = g;
+        const int s = argmin[(size_t)n * P + p];
+        for (int dd = threadIdx.x; dd < D; dd += 256) {
+            const size_t o = (size_t)s * Dp + dd;
+            dzn[o] = (T)((float)dzn[o] + 2.0f * g * ((float)zn[o] - protos[(size_t)p * D + dd]));
+        }
+    }
+}
+
+// one block per prototype: dprotos[p][:], dfc_w[:][p]  (fixed order over the clips)
+template <typename T>
+__global__ __launch_bounds__(256) void l2_head_bwd_p_kernel(const T* __restrict__ z, const float* __restrict__ protos, const float* __restrict__ min_dist,
+                                                            const int32_t* __restrict__ argmin, const float* __restrict__ dlogits,
+                                                            const float* __restrict__ coef, float* __restrict__ dprotos, float* __restrict__ dfc_w,
+                                                            int N, int S, int D, int Dp, int P, int K, int activation, float eps) {
+    const int p = blockIdx.x;
+    for (int dd = threadIdx.x; dd < D; dd += 256) {
+        const float q = protos[(size_t)p * D + dd];
+        float a = 0.0f;
+        for (int n = 0; n < N; ++n) {
+            const int s = argmin[(size_t)n * P + p];
+            a = fmaf(2.0f * coef[(size_t)n * P + p], q - (float)z[((size_t)n * S + s) * Dp + dd], a);
+        }
+        dprotos[(size_t)p * D + dd] = a;
+    }
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float a = 0.0f;
+        for (int n = 0; n < N; ++n) a = fmaf(dlogits[(size_t)n * K + k], l2_sim(min_dist[(size_t)n * P + p], activation, eps), a);
+        dfc_w[(size_t)k * P + p] = a;
+    }
+}
+
+}  // namespace pasn
+
+extern "C" int pasn_l2_head_bwd(const void* z, const float* protos, const float* fc_w, const float* min_dist, const int32_t* argmin,
+                                const float* dlogits, const float* dmin, void* dz, float* coef, float* dprotos, float* dfc_w, int N, int S,
+                                int D, int Dp, int P, int K, int dtype, int activation, float eps, void* stream) {
+    PASN_REQUIRE(z && protos && fc_w && min_dist && argmin && dlogits && dz && coef && dprotos && dfc_w, "null pointer");
+    PASN_REQUIRE(N > 0 && S > 0 && D > 0 && P > 0 && K > 0 && Dp >= D && Dp % 8 == 0, "bad head extents");
+    PASN_REQUIRE(activation == 0 || activation == 1, "activation must be 0 (log) or 1 (linear)");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16) {
+        hipLaunchKernelGGL(l2_head_bwd_z_kernel<__bf16>, dim3(N), dim3(256), 0, s, (const __bf16*)z, protos, fc_w, min_dist, argmin, dlogits, dmin,
+                           (__bf16*)dz, coef, S, D, Dp, P, K, activation, eps);
+        hipLaunchKernelGGL(l2_head_bwd_p_kernel<__bf16>, dim3(P), dim3(256), 0, s, (const __bf16*)z, protos, min_dist, argmin, dlogits, coef, dprotos,
+                           dfc_w, N, S, D, Dp, P, K, activation, eps);
+    } else {
+        hipLaunchKernelGGL(l2_head_bwd_z_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)z, protos, fc_w, min_dist, argmin, dlogits, dmin,
+                           (float*)dz, coef, S, D, Dp, P, K, activation, eps);
+        hipLaunchKernelGGL(l2_head_bwd_p_kernel<float>, dim3(P), dim3(256), 0, s, (const float*)z, protos, min_dist, argmin, dlogits, coef, dprotos, dfc_w,
+                           N, S, D, Dp, P, K, activation, eps);
+    }
+    return check_launch("l2_head_bwd");
+}

@@ -191,8 +191,8 @@ class PPNet(nn.Module):
 
     def _guard(self, x: torch.Tensor) -> None:
         if self.training:
-            raise NotImplementedError("train-mode forward / backward of the ProtoPNet head (head A) is not built yet: call .eval(); "
-                                      "the XProtoNet / Video_XProtoNet models train (see DESIGN.md)")
+            raise NotImplementedError("only forward() (and, for the XProtoNet models, compute_occurence_map()) run in train mode; "
+                                      "call .eval() for push_forward / conv_features / prototype_distances")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("the eval-mode HIP forward records no autograd graph: run it under torch.no_grad(), "
                                       "or call .train() for the differentiable (batch-statistics) pass")
@@ -252,7 +252,25 @@ class PPNet(nn.Module):
             return -distances
         return self.prototype_activation_function(distances)
 
+    def _train_pass_a(self, x: torch.Tensor):
+        """Train-mode forward of the ProtoPNet model (differentiable; ``train.TrainRunner`` with head A)."""
+        from .train import TrainRunner
+
+        if not x.is_cuda:
+            raise RuntimeError("protoasnet_amd models run on the GPU only; there is no CPU fallback")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        runners = self.__dict__.setdefault("_train_runners", {})
+        key = (tuple(x.shape), x.dtype, self._dtype(), "A", id(self.prototype_vectors), tuple(self.prototype_shape))
+        runner = runners.get(key)
+        if runner is None:
+            runner = runners[key] = TrainRunner(self, x, 0, head="A")
+        return runner(x)
+
     def forward(self, x: torch.Tensor):
+        if self.training:
+            return self._train_pass_a(x)
         z, (n, h, w) = self._conv_rows(x)
         logits, min_d, _ = self._head(z, n, h * w, want_dist=False)
         return logits, min_d

@@ -378,6 +378,33 @@ class TrainBuilder(PlanBuilder):
 
         self.tape.append(backward)
 
+    # ---- head A tail (ProtoPNet) -----------------------------------------------------------------------------------
+    def l2_tail(self, z: Act, model, ext: Dict[str, int]) -> None:
+        """z: add-on output after the Sigmoid.  External tensors: min_d, logits (forward), dlogits, dmin (backward)."""
+        P, K, D = model.num_prototypes, model.num_classes, model.prototype_shape[1]
+        pv, fw = model.prototype_vectors, model.last_layer.weight
+        for t in (pv, fw):
+            _need_fp32_param(t, "a head parameter")
+        act = model.prototype_activation_function
+        if act not in ("log", "linear"):
+            raise NotImplementedError("only the 'log' and 'linear' prototype activations run on the HIP path")
+        actc, eps = (0 if act == "log" else 1), float(model.epsilon)
+        N, S = z.N, z.positions
+        code, lib, B, Pm, e = self.code, self.lib, self.B, self.Pm, ext
+        amin = self._new_buf(N * P * 4)
+        self._use(z.buf, amin)
+        self._op(lib.pasn_l2_head_fwd, B(z.buf), Pm(pv), Pm(fw), 0, B(e["min_d"]), B(amin), B(e["logits"]), N, S, D, z.Cp, P, K, code, actc, eps)
+
+        def backward() -> None:
+            dz = self.like(z)
+            coef = self._new_buf(N * P * 4)
+            self._use(z.buf, amin, dz.buf, coef)
+            self._op(lib.pasn_l2_head_bwd, B(z.buf), Pm(pv), Pm(fw), B(e["min_d"]), B(amin), B(e["dlogits"]), B(e["dmin"]), B(dz.buf), B(coef),
+                     self.Gp(self.slot(pv)), self.Gp(self.slot(fw)), N, S, D, z.Cp, P, K, code, actc, eps)
+            self.add_grad(z, dz)
+
+        self.tape.append(backward)
+
     # ---- finish: generate the backward list, then place every buffer ----------------------------------------------------
     def finish_train(self, x_in: Act, ext: Dict[str, int]) -> "TrainPlan":
         self.n_fwd = len(self.ops)
@@ -473,35 +500,46 @@ class _TrainFn(torch.autograd.Function):
 
 
 class TrainRunner:
-    """One compiled training pass of a head-B model for one input shape: mode 0 = forward(), 1 = compute_occurence_map()."""
+    """One compiled training pass of a model for one input shape.  Head B (XProtoNet / Video_XProtoNet): mode 0 = forward(),
+    1 = compute_occurence_map().  Head A (PPNet): mode 0 = forward() -> (logits, min_distances)."""
 
-    def __init__(self, model, x: torch.Tensor, mode: int):
+    def __init__(self, model, x: torch.Tensor, mode: int, head: str = "B"):
         dtype = model._dtype()
         tb = TrainBuilder(x.device, dtype, x.dtype)
         x_in = tb.input(tuple(x.shape))
-        feat = model.cnn_backbone.build_train(tb, x_in)
-        ext = {n: tb._new_buf(0, external=True) for n in ("occ", "feat", "sim", "logits", "dlogits", "dsim", "docc")}
-        a_convs, o_convs = model.add_on_layers._steps(), model.occurrence_module._steps()
-        z = None
-        if mode == 0:
-            z = feat
-            for conv, act in a_convs:
-                z = tb.unit(z, conv, None, act)
-        r = feat
-        for conv, act in o_convs:
-            r = tb.unit(r, conv, None, act)
-        tb.xproto_tail(z, r, model, ext)
-        self.plan = tb.finish_train(x_in, ext)
-        self.mode, self.model = mode, model
+        trunk = model.cnn_backbone if head == "B" else model.features
+        feat = trunk.build_train(tb, x_in)
+        self.head, self.mode, self.model = head, mode, model
         self.N, self.S = feat.N, feat.positions
         self.spatial = (feat.T, feat.H, feat.W) if x.dim() == 5 else (feat.H, feat.W)
-        self.out_names = ("logits", "sim", "occ") if mode == 0 else ("occ",)
-        self.grad_names = ("dlogits", "dsim", "docc") if mode == 0 else ("docc",)
+        if head == "B":
+            ext = {n: tb._new_buf(0, external=True) for n in ("occ", "feat", "sim", "logits", "dlogits", "dsim", "docc")}
+            z = None
+            if mode == 0:
+                z = feat
+                for conv, act in model.add_on_layers._steps():
+                    z = tb.unit(z, conv, None, act)
+            r = feat
+            for conv, act in model.occurrence_module._steps():
+                r = tb.unit(r, conv, None, act)
+            tb.xproto_tail(z, r, model, ext)
+            self.out_names = ("logits", "sim", "occ") if mode == 0 else ("occ",)
+            self.grad_names = ("dlogits", "dsim", "docc") if mode == 0 else ("docc",)
+        else:
+            ext = {n: tb._new_buf(0, external=True) for n in ("min_d", "logits", "dlogits", "dmin")}
+            z = feat
+            for conv, act in model.add_on_layers._steps():
+                z = tb.unit(z, conv, None, act)
+            tb.l2_tail(z, model, ext)
+            self.out_names, self.grad_names = ("logits", "min_d"), ("dlogits", "dmin")
+        self.plan = tb.finish_train(x_in, ext)
         self.params = [p for p in model.parameters()]
 
     def alloc_outputs(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         m, dev, f32 = self.model, x.device, torch.float32
         P, D, K = m.num_prototypes, m.prototype_shape[1], m.num_classes
+        if self.head == "A":
+            return {"logits": torch.empty((self.N, K), dtype=f32, device=dev), "min_d": torch.empty((self.N, P), dtype=f32, device=dev)}
         outs = {"occ": torch.empty((self.N, P, 1) + self.spatial, dtype=f32, device=dev)}
         if self.mode == 0:
             outs["feat"] = torch.empty((self.N, P, D), dtype=f32, device=dev)
@@ -509,9 +547,14 @@ class TrainRunner:
             outs["logits"] = torch.empty((self.N, K), dtype=f32, device=dev)
         else:
             outs["feat"] = outs["sim"] = outs["logits"] = None
-        return {k: v for k, v in outs.items()}
+        return outs
 
     def fix_grads(self, tensors, outs):
+        if self.head == "A":
+            if tensors.get("dlogits") is None:
+                tensors["dlogits"] = torch.zeros_like(outs["logits"])
+            tensors.setdefault("dmin", None)
+            return tensors
         if self.mode == 0 and tensors.get("dlogits") is None:
             tensors["dlogits"] = torch.zeros_like(outs["logits"])
         if self.mode == 1:

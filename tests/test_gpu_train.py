@@ -15,7 +15,7 @@ import oracle
 from conftest import assert_close
 from protoasnet_amd import _lib, synth
 from protoasnet_amd._lib import ConvDesc, XProtoDesc
-from util import CFG_VIDEO_R2P1D, CFG_VIDEO_X3D, CFG_XPROTO, synth_model
+from util import CFG_PPNET, CFG_PPNET_BOTTLENECK, CFG_VIDEO_R2P1D, CFG_VIDEO_X3D, CFG_XPROTO, synth_model
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -421,6 +421,28 @@ def test_reference_trunks_train_step_fp32_vs_oracle_autograd(cfg, shape, spatial
     for k_, v in sd_ref.items():
         if "running_" in k_:
             _rel(sd1[k_], v, 1e-4, k_)
+
+
+@pytest.mark.parametrize("cfg", [CFG_PPNET, CFG_PPNET_BOTTLENECK], ids=["regular", "bottleneck"])
+def test_ppnet_train_step_fp32_vs_oracle_autograd(cfg):
+    """ProtoPNet (head A: distance map, min pooling, log activation, last layer; Sigmoid add-on) in train mode: logits,
+    min_distances and every parameter gradient, with gradients entering through both outputs (cross entropy acts on the logits,
+    the cluster / separation costs on min_distances: ProtoPNet_Base.py)."""
+    m = _train_model(kink_free=True, cfg=cfg)
+    shape = (3, 3, 96, 96)
+    x = synth.echo_clips(shape)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    wl, wm = torch.randn(3, m.num_classes, generator=g), torch.randn(3, m.num_prototypes, generator=g)
+    logits, min_d = m(x.to(DEV))
+    assert logits.requires_grad and min_d.requires_grad
+    ((logits * wl.to(DEV)).sum() + (min_d * wm.to(DEV)).sum()).backward()
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
+    ref = oracle.nets.ppnet_train_forward(sd, x, arch="resnet18")
+    ((ref["logits"] * wl).sum() + (ref["min_distances"] * wm).sum()).backward()
+    _rel(logits, ref["logits"], 1e-3, "logits")
+    _rel(min_d, ref["min_distances"], 1e-3, "min_distances")
+    _check_grads(m, sd, 1e-3)
 
 
 def test_video_x3d_train_unmodified_model_vs_oracle():
