@@ -331,6 +331,12 @@ int pasn_l2_head_bwd(const void* z, const float* protos, const float* fc_w, cons
                      const float* dlogits, const float* dmin, void* dz, float* coef, float* dprotos, float* dfc_w, int N, int S, int D,
                      int Dp, int P, int K, int dtype, int activation, float eps, void* stream);
 
+/* The affine warp of TransformLoss (loss.py:257-320): torchvision.transforms.functional.affine with
+ * translate = 0, shear = 0, bilinear, fill = 0, applied to every H x W plane of a planar tensor ((N,3,T,H,W) clips: N*3*T planes;
+ * (N,P,T',H',W') occurrence maps: N*P*T' planes).  bwd is the adjoint on fp32 (dx zeroed by the caller; fp32 atomics). */
+int pasn_affine_warp_fwd(const void* x, void* y, long planes, int H, int W, float angle_deg, float scale, int dtype, void* stream);
+int pasn_affine_warp_bwd(const float* dy, float* dx, long planes, int H, int W, float angle_deg, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_long, c_size_t, c_void_p
 
 F32, BF16 = 0, 1
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "swish": 3, "abs": 4}
@@ -71,6 +71,8 @@ SIGNATURES = {
     "pasn_xproto_tail_fwd": (c_int, [c_void_p] * 8 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_xproto_tail_bwd": (c_int, [c_void_p] * 14 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_l2_head_bwd": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_void_p]),
+    "pasn_affine_warp_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_float, c_int, c_void_p]),
+    "pasn_affine_warp_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_float, c_void_p]),
     "pasn_push_ppnet_update": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
 }
 

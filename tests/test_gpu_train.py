@@ -492,3 +492,44 @@ def test_training_guards():
     m2 = synth_model(CFG_VIDEO_X3D).to(DEV).bfloat16().train()
     with pytest.raises(RuntimeError, match="fp32 master"):
         m2(synth.echo_clips((1, 3, 4, 64, 64)).to(DEV).bfloat16())
+
+
+# ------------------------------------------------------------------------------------------------- TransformLoss
+@pytest.mark.parametrize("shape,angle,scale", [((6, 3, 17, 23), 13.0, 0.8), ((4, 2, 32, 32), -20.0, 1.5), ((3, 5, 7, 7), 7.5, 0.6)])
+def test_affine_warp_forward_backward_vs_torchvision_restatement(shape, angle, scale):
+    from protoasnet_amd.losses import affine_warp
+
+    g = torch.Generator().manual_seed(shape[-1])
+    x = torch.randn(shape, generator=g).requires_grad_()
+    ref = oracle.losses.affine(x, angle, scale)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_()
+    y = affine_warp(xd, angle, scale)
+    (y * w.to(DEV)).sum().backward()
+    _rel(y, ref, 1e-5, "warped planes")
+    _rel(xd.grad, x.grad, 1e-5, "warp adjoint")
+    yb = affine_warp(x.detach().to(DEV).bfloat16(), angle, scale)
+    _rel(yb, oracle.losses.affine(x.detach().bfloat16().float(), angle, scale), 1e-2, "bf16 planes")
+
+
+def test_transform_loss_value_and_gradients_vs_oracle():
+    """TransformLoss.compute (loss.py:283-320): warped clip -> second trunk pass with gradients, warped maps, L1."""
+    from protoasnet_amd.losses import TransformLoss
+
+    m = _train_model(kink_free=True)
+    x = synth.echo_clips(SHAPE)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    cfg = {"angle": 11.0, "scale": 0.9}
+    _, _, occ = m(x.to(DEV))
+    loss = TransformLoss(loss_weight=1e-2, reduction="mean").compute(x.to(DEV), occ, m, config=cfg)
+    loss.backward()
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
+    occ_ref = oracle.nets.xprotonet_train_forward(sd, x, arch="x3d_s")["occurrence_map"]
+    ref = oracle.losses.transform_loss(x, occ_ref, lambda xt: oracle.nets.xprotonet_train_forward(sd, xt, arch="x3d_s", occurrence_only=True)["occurrence_map"],
+                                       cfg["angle"], cfg["scale"], loss_weight=1e-2, reduction="mean")
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-3 * abs(float(ref)), (float(loss), float(ref))
+    head_only = {n for n, _ in m.named_parameters() if n.startswith("add_on_layers") or n in ("prototype_vectors", "last_layer.weight")}
+    # |a - b| has its own kink at a == b; the maps differ everywhere here, so the strict bound holds
+    _check_grads(m, sd, 2e-3, skip=head_only)
