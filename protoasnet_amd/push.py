@@ -136,22 +136,74 @@ def push_prototypes(dataloader, model, class_specific=True, abstain_class=True, 
     lib = _lib.lib()
     batch_size = getattr(dataloader, "batch_size", None)
     seen = 0
+    save = root_dir_for_saving_prototypes is not None
+    if save and world_size > 1:
+        raise NotImplementedError("prototype artefacts (prototypes_info.pickle) are written by a single-process push; "
+                                  "run the sharded sweep without root_dir_for_saving_prototypes")
+    rec, names, ar = None, {}, torch.arange(P, device=device)
     for i, sample in _iter_shard(dataloader, rank, world_size):
         x = sample["cine"]
         if preprocess_input_function is not None:
             x = preprocess_input_function(x)
         labels = sample["target_AS"].to(device=device, dtype=torch.int64).contiguous()
+        xdev = x.to(device)
         with torch.no_grad():
-            feats, proto_dist, _occ, _logits = model.push_forward(x.to(device))
+            feats, proto_dist, occ, logits = model.push_forward(xdev)
         B = int(x.shape[0])
         base = i * batch_size if batch_size else seen
         feats, proto_dist = feats.contiguous(), proto_dist.contiguous()
         _lib.check(lib.pasn_push_xproto_update(
             proto_dist.data_ptr(), feats.data_ptr(), labels.data_ptr(), proto_class.data_ptr(), mask.data_ptr(),
             state.dist.data_ptr(), state.index.data_ptr(), state.vec.data_ptr(), B, P, D, int(base), _lib.current_stream()))
+        if save:
+            # the records the reference keeps per prototype (push_abs_revision.py:300-307) stay ON THE DEVICE: a prototype
+            # whose current winner lies in this batch takes the batch's occurrence map / logits / clip / label; no host sync
+            names[int(base)] = list(sample.get("filename", [""] * B))
+            here = (state.index >= base) & (state.index < base + B)
+            b = (state.index - base).clamp(0, B - 1)
+            new = (occ[b, ar], logits[b], xdev[b].float(), labels[b])
+            if rec is None:
+                rec = [torch.zeros_like(t) for t in new]
+            rec = [torch.where(here.view((P,) + (1,) * (t.dim() - 1)), t, r) for t, r in zip(new, rec)]
         seen += B
     merged = _all_gather_states(state, merge_xproto) if world_size > 1 else state.tensors()
+    if save and rec is not None:
+        _save_xproto_artefacts(root_dir_for_saving_prototypes, epoch_number, merged, rec, names, log)
     return _finish(model, merged, model.prototype_shape, replace_prototypes, log, start)
+
+
+def _save_xproto_artefacts(root: str, epoch_number, merged, rec, names, log) -> str:
+    """``prototypes_info.pickle`` with the reference's keys and array shapes (push_abs_revision.py:309-325), read by
+    ``explain_local`` (src/utils/local_explainability.py:36-41).  The visualisation loop that follows it in the reference
+    (plots, GIFs) is not part of this package."""
+    import os
+    import pickle
+
+    import numpy as np
+
+    proto_epoch_dir = os.path.join(root, "epoch-" + str(epoch_number)) if epoch_number is not None else root
+    os.makedirs(proto_epoch_dir, exist_ok=True)
+    dist, index, _ = merged
+    occ, logits, imgs, gts = (t.detach().cpu().numpy() for t in rec)
+    idx = index.detach().cpu().numpy().astype(np.int64)
+    bases = sorted(names)
+    files = []
+    for g in idx:
+        base = max([b for b in bases if b <= g], default=None) if g >= 0 else None
+        files.append(names[base][g - base] if base is not None and g - base < len(names[base]) else None)
+    data = {
+        "prototypes_filenames": np.array(files),
+        "prototypes_src_imgs": imgs,                       # (P, 3, (To), Ho, Wo)
+        "prototypes_gts": gts,                             # (P)
+        "prototypes_preds": logits,                        # (P, K)
+        "prototypes_occurrence_maps": occ,                 # (P, 1, (T), H, W)
+        "prototypes_similarity_to_src_ROIs": 1 - dist.detach().cpu().numpy(),  # (P)
+    }
+    path = os.path.join(proto_epoch_dir, "prototypes_info.pickle")
+    with open(path, "wb") as handle:
+        pickle.dump(data, handle, protocol=pickle.HIGHEST_PROTOCOL)
+    log(f"data successfully saved in {path}")
+    return path
 
 
 # ------------------------------------------------------------------------------------------------- PPNet

@@ -137,6 +137,40 @@ def test_push_prototypes_video_end_to_end():
     assert float(sim[ref_w[0][1], 0]) < 1e-5  # the projected prototype now sits on its source feature
 
 
+def test_push_prototypes_writes_reference_pickle(tmp_path):
+    """root_dir_for_saving_prototypes: prototypes_info.pickle with the reference's keys (push_abs_revision.py:309-325); the
+    records are those of the winning clips, computed with the prototypes as they were BEFORE the projection."""
+    import pickle
+
+    from protoasnet_amd.push import push_prototypes
+
+    m = synth_model(CFG_VIDEO_X3D).to(DEV).eval()
+    loader = _loader((3, 4, 64, 64), nb=4, seed=70)
+    rec = []
+    with torch.no_grad():
+        for s in loader:
+            f, d, o, l = m.push_forward(s["cine"].to(DEV))
+            rec.append((d.cpu(), o.cpu(), l.cpu()))
+    out = push_prototypes(loader, m, class_specific=True, abstain_class=False, replace_prototypes=True, log=lambda *_: None,
+                          root_dir_for_saving_prototypes=str(tmp_path), epoch_number=3)
+    with open(tmp_path / "epoch-3" / "prototypes_info.pickle", "rb") as fh:
+        info = pickle.load(fh)
+    assert sorted(info) == sorted(["prototypes_filenames", "prototypes_src_imgs", "prototypes_gts", "prototypes_preds",
+                                   "prototypes_occurrence_maps", "prototypes_similarity_to_src_ROIs"])
+    P = m.num_prototypes
+    assert info["prototypes_src_imgs"].shape == (P, 3, 4, 64, 64) and info["prototypes_occurrence_maps"].shape == (P, 1, 4, 2, 2)
+    assert info["prototypes_preds"].shape == (P, 3) and info["prototypes_gts"].shape == (P,)
+    idx = out["proto_index"].cpu().numpy()
+    for j in range(P):
+        bi, a = divmod(int(idx[j]), 4)
+        assert info["prototypes_filenames"][j] == f"c{bi}_{a}"
+        assert int(info["prototypes_gts"][j]) == int(loader[bi]["target_AS"][a])
+        assert np.array_equal(info["prototypes_src_imgs"][j], loader[bi]["cine"][a].numpy())
+        assert np.array_equal(info["prototypes_occurrence_maps"][j], rec[bi][1][a, j].numpy())
+        assert np.array_equal(info["prototypes_preds"][j], rec[bi][2][a].numpy())
+        assert info["prototypes_similarity_to_src_ROIs"][j] == np.float32(1) - rec[bi][0][a, j].numpy()
+
+
 def test_push_prototypes_ppnet_end_to_end():
     from protoasnet_amd.push import push_prototypes_ppnet
 
