@@ -25,7 +25,13 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[di
     if not grads:
         return 0
     flat = _flatten_dense_tensors(grads)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU, where RCCL refuses to start): stage the bucket through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # RCCL over xGMI on a real node
     if average:
         flat /= dist.get_world_size(group)
     for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):

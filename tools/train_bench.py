@@ -120,7 +120,7 @@ def main(argv=None):
                                    f"{args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (one flat fp32 gradient bucket all-reduced per step)"},
             "launches": {"forward": plan.n_fwd, "backward": len(plan.ops) - plan.n_fwd}, "arena_bytes": plan.arena_bytes,
-            "naive_bytes": plan.naive_bytes, "grad_bucket_bytes": plan.gsize * 4, "loss": round(float(loss), 5),
+            "naive_bytes": plan.naive_bytes, "grad_bucket_bytes": plan.gsize * 4, "loss": round(float(loss.detach()), 5),
         }))
     if world > 1:
         dist.destroy_process_group()
