@@ -278,13 +278,16 @@ int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, 
  *   mode 0:  d <- d * act'(y*sc + sh + residual);   coef = (sum d / R, sum d*yhat / R), dgamma = sum d*yhat, dbeta = sum d
  *   mode 1:  d <- d * act'((y*sc + sh) * gate);     ws partials of sum_s d*(y*sc + sh) per clip (gradient of the gate)
  *   mode 2:  d <- d * gate + add[n][c];             coef / dgamma / dbeta as mode 0
+ *   mode 3:  the sums of mode 0 WITHOUT writing d back (no residual branch needs it): pasn_bn_bwd_apply is then called with
+ *            the unit's `act` and differentiates on the fly -- one tensor write less per unit
  * (yhat = (y - mean) * invstd, R = N*S; after mode 0 the buffer d is also the gradient of `residual`.) */
 int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const float* stat, const void* residual, const float* gate, const float* add,
                          float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int act, int dtype, void* stream);
 
-/* Batch-norm input gradient: dy = sc * (d - coef[0] - yhat * coef[1]);  dy may alias d. */
-int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp, int dtype,
-                      void* stream);
+/* Batch-norm input gradient: dy = sc * (d' - coef[0] - yhat * coef[1]) with d' = d (act = PASN_ACT_NONE: d was differentiated in
+ * place by mode 0 / 2) or d' = d * act'(y*sc + sh) (after mode 3);  dy may alias d. */
+int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp, int act,
+                      int dtype, void* stream);
 
 /* Squeeze-excite backward: from the mode-1 partials `ws` and the pooled input `pool_u`, through sigmoid / fc2 / ReLU / fc1:
  *   add : fp32 [N][Cp] = dpool / S (the term mode 2 adds);  dw1 [Cse][C], db1 [Cse], dw2 [C][Cse], db2 [C]

@@ -57,7 +57,7 @@ SIGNATURES = {
     "pasn_bn_stats_fwd": (c_int, [c_void_p] * 6 + [c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pasn_affine_act_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "pasn_unit_bwd_reduce": (c_int, [c_int] + [c_void_p] * 10 + [c_int] * 6 + [c_void_p]),
-    "pasn_bn_bwd_apply": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "pasn_bn_bwd_apply": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "pasn_se_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "pasn_se_gate_bwd": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "pasn_scatter_strided": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),

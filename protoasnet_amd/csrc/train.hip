@@ -212,7 +212,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
                                                         const T* __restrict__ res, const float* __restrict__ gate, const float* __restrict__ add,
                                                         float* __restrict__ ws, int S, int Cp, int CG, int CGb, int rows_per_chunk,
-                                                        int chunks, int act) {
+                                                        int chunks, int act, int write_back) {
     __shared__ float red[256 * 8];
     const int n = blockIdx.y, ch = blockIdx.x;
     const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
                     acc[1][j] = fmaf(dv[j], (v[j] - mean[j]) * invstd[j], acc[1][j]);
                 }
             }
-            store8(d + o, dv);
+            if (write_back) store8(d + o, dv);
         }
     }
     block_reduce_rows<2>(acc, red, ws + ((size_t)n * chunks + ch) * 2 * Cp, Cp, CG, CGb);
@@ -312,18 +312,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
-// dy = sc * (d - m1 - yhat * m2)
+// dy = sc * (d' - m1 - yhat * m2),  d' = d (act == NONE: already differentiated by the reduce pass) or d * act'(y*sc + sh)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
                                                            const float* __restrict__ coef, T* __restrict__ dy, int S, int Cp, int CG, int CGb,
-                                                           int rows_per_chunk) {
+                                                           int rows_per_chunk, int act) {
     const int n = blockIdx.y, ch = blockIdx.x;
     const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
     if (cg >= CG) return;
-    float mean[8], invstd[8], sc[8], m1[8], m2[8];
+    float mean[8], invstd[8], sc[8], sh[8], m1[8], m2[8];
     load8(stat + cg * 8, mean);
     load8(stat + Cp + cg * 8, invstd);
     load8(stat + 2 * Cp + cg * 8, sc);
+    load8(stat + 3 * Cp + cg * 8, sh);
     load8(coef + cg * 8, m1);
     load8(coef + Cp + cg * 8, m2);
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
@@ -334,6 +335,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         float v[8], dv[8];
         load8(y + o, v);
         load8(d + o, dv);
+        if (act != PASN_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dv[j] *= act_grad(fmaf(v[j], sc[j], sh[j]), act);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (dv[j] - m1[j] - (v[j] - mean[j]) * invstd[j] * m2[j]);
         store8(dy + o, dv);
@@ -563,8 +568,8 @@ static void launch_grad_pass(int mode, void* d, const void* y, const float* stat
     const dim3 grid(g.chunks, N);
 #define GP(M)                                                                                                                      \
     hipLaunchKernelGGL((grad_pass_kernel<T, M>), grid, dim3(256), 0, s, (T*)d, (const T*)y, stat, (const T*)res, gate, add, ws, S, Cp, g.CG, \
-                       g.CGb, g.rows_per_chunk, g.chunks, act)
-    if (mode == 0) GP(0);
+                       g.CGb, g.rows_per_chunk, g.chunks, act, (int)(mode != 3))
+    if (mode == 0 || mode == 3) GP(0);
     else if (mode == 1) GP(1);
     else GP(2);
 #undef GP
@@ -574,10 +579,11 @@ extern "C" int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const floa
                                     const float* add, float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp,
                                     int act, int dtype, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
-    PASN_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+    PASN_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0, 1, 2 or 3");
     PASN_REQUIRE(d && y && stat && ws, "null pointer");
     PASN_REQUIRE(mode == 1 || coef, "coef is required for modes 0 and 2");
-    PASN_REQUIRE(mode == 0 || gate, "modes 1 and 2 need the gate");
+    PASN_REQUIRE(mode == 0 || mode == 3 || gate, "modes 1 and 2 need the gate");
+    PASN_REQUIRE(mode != 3 || residual == nullptr, "mode 3 leaves d untouched: a residual branch needs the differentiated d of mode 0");
     const RowGeom g = row_geom(N, S, Cp);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16) launch_grad_pass<__bf16>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s);
@@ -588,7 +594,7 @@ extern "C" int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const floa
 }
 
 extern "C" int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp,
-                                 int dtype, void* stream) {
+                                 int act, int dtype, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
     PASN_REQUIRE(d && y && stat && coef && dy, "null pointer");
     const RowGeom g = row_geom(N, S, Cp);
@@ -596,10 +602,10 @@ extern "C" int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)d, (const __bf16*)y, stat, coef, (__bf16*)dy, S, Cp,
-                           g.CG, g.CGb, g.rows_per_chunk);
+                           g.CG, g.CGb, g.rows_per_chunk, act);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)d, (const float*)y, stat, coef, (float*)dy, S, Cp, g.CG,
-                           g.CGb, g.rows_per_chunk);
+                           g.CGb, g.rows_per_chunk, act);
     return check_launch("bn_bwd_apply");
 }
 

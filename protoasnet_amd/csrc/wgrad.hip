@@ -502,19 +502,24 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
     // zero the LDS rows of padded channels once (channels >= C*_p of the last tile are never written by the staging)
     for (int i = tid * 16; i < (co_tiles + ci_tiles) * 32 * PITCH; i += 256 * 16) *reinterpret_cast<uint4*>(lds + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const int units = (KT / 8) * (CGo + CGi);  // 8-row x 8-channel patches per staged K tile
-    for (long rb = r0; rb < r1; rb += KT) {
-        for (int u = tid; u < units; u += 256) {
-            const int g = u % (CGo + CGi), r8 = u / (CGo + CGi);
+    const int units = (KT / 8) * (CGo + CGi);  // 8-row x 8-channel patches per staged K tile (at most 2 per thread, checked on the host)
+    // software pipeline: the global loads of K tile i+1 are in flight (raw registers) while tile i is multiplied out of LDS
+    uint4 pre[2][8];
+    auto fetch = [&](long rb) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int u = tid + v * 256;
+            const bool live = u < units;
+            const int uc = live ? u : 0;
+            const int g = uc % (CGo + CGi), r8 = uc / (CGo + CGi);
             const bool is_a = g < CGo;
             const int cg = is_a ? g : g - CGo;
             const int cp = is_a ? d.Cout_p : d.Cin_p;
             const __bf16* src = is_a ? dy : x;
-            uint4 in[8], out[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long r = rb + r8 * 8 + i;
-                const bool ok = r < r1;
+                const bool ok = live && r < r1;
                 long row = ok ? r : r0;
                 if (!is_a && strided) {
                     const int wo = (int)(row % d.Wo);
@@ -524,15 +529,32 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
                     const int to = (int)(q % d.To), n = (int)(q / d.To);
                     row = (((long)n * d.Ti + to * d.st) * d.Hi + ho * d.sh) * d.Wi + wo * d.sw;
                 }
-                in[i] = *reinterpret_cast<const uint4*>(src + row * cp + cg * 8);
-                if (!ok) in[i] = make_uint4(0, 0, 0, 0);
+                pre[v][i] = *reinterpret_cast<const uint4*>(src + row * cp + cg * 8);
+                if (!ok) pre[v][i] = make_uint4(0, 0, 0, 0);
             }
-            transpose8x8_bf16(in, out);
-            unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * PITCH + r8 * 16;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst + c * PITCH) = out[c];
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int u = tid + v * 256;
+            if (u < units) {
+                const int g = u % (CGo + CGi), r8 = u / (CGo + CGi);
+                const bool is_a = g < CGo;
+                const int cg = is_a ? g : g - CGo;
+                uint4 out[8];
+                transpose8x8_bf16(pre[v], out);
+                unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * PITCH + r8 * 16;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst + c * PITCH) = out[c];
+            }
+        }
+    };
+    fetch(r0);
+    for (long rb = r0; rb < r1; rb += KT) {
+        stage();
         __syncthreads();
+        if (rb + KT < r1) fetch(rb + KT);
 #pragma unroll
         for (int kk = 0; kk < KT / 16; ++kk) {
 #pragma unroll
@@ -580,6 +602,7 @@ bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_des
     const bool small = (co_tiles + ci_tiles) <= 6;  // few channels: stage more rows per step so every thread has a patch to move
     const int KT = small ? 128 : 32;
     if ((size_t)(co_tiles + ci_tiles) * 32 * (KT * 2 + 16) > 64 * 1024) return false;
+    if ((KT / 8) * (d.Cout_p / 8 + d.Cin_p / 8) > 512) return false;  // the kernel's register pipeline holds 2 patches per thread
     int tpw = ceil_div(ntiles, 4);
     tpw = tpw <= 1 ? 1 : tpw <= 2 ? 2 : tpw <= 4 ? 4 : 8;
     const int gy = ceil_div(ntiles, 4 * tpw);
@@ -716,6 +739,70 @@ __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __res
     }
 }
 
+// Temporal-only depthwise conv (kh = kw = 1, stride 1: the X3D stem's (5,1,1) conv): a thread owns 8 channels of one plane
+// position and walks the frames; no divisions in the loop, the kt input frames of a step are the previous step's plus one.
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_temporal_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
+                                                                pasn_conv_desc d, int CG, int CGb, long items) {
+    __shared__ float red[256 * 8];
+    constexpr int KMAX = 5;
+    const int cg = threadIdx.x % CGb, pl = threadIdx.x / CGb, PL = 256 / CGb;
+    const long HW = (long)d.Hi * d.Wi;
+    float acc[KMAX][8];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.0f;
+    for (long item = (long)blockIdx.x * PL + pl; cg < CG && item < items; item += (long)gridDim.x * PL) {
+        const long n = item / HW, pos = item % HW;
+        const T* xp = x + ((size_t)n * d.Ti * HW + pos) * d.Cin_p + cg * 8;
+        const T* gp = dy + ((size_t)n * d.To * HW + pos) * d.Cout_p + cg * 8;
+        for (int t = 0; t < d.To; ++t) {
+            float g[8];
+            load8(gp + (size_t)t * HW * d.Cout_p, g);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int ti = t - d.pt + k;
+                if (k < d.kt && ti >= 0 && ti < d.Ti) {
+                    float v[8];
+                    load8(xp + (size_t)ti * HW * d.Cin_p, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(g[j], v[j], acc[k][j]);
+                }
+            }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * d.kt * d.Cout_p;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < d.kt) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[k][j];
+            __syncthreads();
+            for (int t = threadIdx.x; t < CGb * 8; t += 256) {
+                const int g2 = t >> 3, j = t & 7;
+                if (g2 < CG) {
+                    float sum = 0.0f;
+                    for (int q2 = 0; q2 < PL; ++q2) sum += red[(q2 * CGb + g2) * 8 + j];
+                    out[(size_t)k * d.Cout_p + g2 * 8 + j] = sum;
+                }
+            }
+        }
+    }
+}
+
+static bool dw_temporal_ok(const pasn_conv_desc& d) {
+    return d.kh == 1 && d.kw == 1 && d.kt <= 5 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.Ti == d.To &&
+           d.Cout_p % 8 == 0 && d.Cout_p <= 2048;
+}
+static long dw_temporal_blocks(const pasn_conv_desc& d) {
+    int CG = d.Cout_p / 8, b = 1;
+    while (b < CG) b <<= 1;
+    const long items = (long)d.N * d.Hi * d.Wi;
+    return std::min<long>((items + 256 / b - 1) / (256 / b), 2048);
+}
+
 struct DwWgGeom {
     int ok, SW, WT, strips, HR, hgroups, CG, CGb, PL;
     long items, blocks;
@@ -752,11 +839,26 @@ static DwWgGeom dw_wgrad_strip_geom(const pasn_conv_desc& d) {
 namespace pasn {
 
 size_t dw_wgrad_strip_floats(const pasn_conv_desc& d) {
+    if (dw_temporal_ok(d)) return (size_t)dw_temporal_blocks(d) * d.kt * d.Cout_p;
     const DwWgGeom g = dw_wgrad_strip_geom(d);
     return g.ok ? (size_t)g.blocks * d.kt * 9 * d.Cout_p : 0;
 }
 
 bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const pasn_conv_desc& d, int dtype, hipStream_t s) {
+    if (dw_temporal_ok(d)) {
+        int CG = d.Cout_p / 8, CGb = 1;
+        while (CGb < CG) CGb <<= 1;
+        const long items = (long)d.N * d.Hi * d.Wi, blocks = dw_temporal_blocks(d);
+        if (dtype == PASN_BF16)
+            hipLaunchKernelGGL(dw_wgrad_temporal_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, ws, d, CG,
+                               CGb, items);
+        else
+            hipLaunchKernelGGL(dw_wgrad_temporal_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, (const float*)dy, ws, d, CG, CGb,
+                               items);
+        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div((long)d.kt * d.Cout_p, 64)), dim3(256), 0, s, ws, dw, (int)blocks, d.kt, d.Cout,
+                           d.Cout_p);
+        return true;
+    }
     const DwWgGeom g = dw_wgrad_strip_geom(d);
     if (!g.ok) return false;
     const dim3 grid((unsigned)g.blocks, 1, d.kt);

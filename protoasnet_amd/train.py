@@ -233,9 +233,10 @@ class TrainBuilder(PlanBuilder):
                     dg, db = 0, self.Gp(self.slot(conv.bias))
                 else:
                     dg = db = 0
+                lazy = se is None and norm is not None and residual is None  # nobody but the apply pass reads the differentiated d
                 if se is None:
                     self._use(g.buf, y.buf, rb, stat_buf, ws, coef)
-                    self._op(red, 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
+                    self._op(red, 3 if lazy else 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
                 else:
                     cse = se.fc1.out_channels
                     addb = self._new_buf(N * Cp * 4)
@@ -253,7 +254,7 @@ class TrainBuilder(PlanBuilder):
                 if norm is not None:
                     dy = self.like(y) if residual is not None else g
                     self._use(g.buf, y.buf, stat_buf, coef, dy.buf)
-                    self._op(lib.pasn_bn_bwd_apply, B(g.buf), B(y.buf), stat, B(coef), B(dy.buf), N, S, C, Cp, code)
+                    self._op(lib.pasn_bn_bwd_apply, B(g.buf), B(y.buf), stat, B(coef), B(dy.buf), N, S, C, Cp, actc if lazy else 0, code)
             # ---- weight gradient
             dW = self.Gp(self.slot(conv.weight))
             if kind == "first":

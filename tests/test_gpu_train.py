@@ -85,11 +85,26 @@ def test_bn_unit_forward_backward(c, shape, offset):
                                         dg.data_ptr(), db.data_ptr(), n, S, c, cp, 1, F32, _st()))
     _rel(_ncl(dd, c), res.grad, 1e-5, "residual gradient")
     dy = torch.empty_like(yd)
-    _lib.check(lib.pasn_bn_bwd_apply(dd.data_ptr(), yd.data_ptr(), stat.data_ptr(), coef.data_ptr(), dy.data_ptr(), n, S, c, cp, F32, _st()))
+    _lib.check(lib.pasn_bn_bwd_apply(dd.data_ptr(), yd.data_ptr(), stat.data_ptr(), coef.data_ptr(), dy.data_ptr(), n, S, c, cp, 0, F32, _st()))
     _rel(dg, gamma.grad, 1e-4, "dgamma")
     _rel(db, beta.grad, 1e-4, "dbeta")
     _rel(_ncl(dy, c), y.grad, 2e-4, "dy")
     assert float(dy[..., c:].abs().max() if cp > c else 0.0) == 0.0, "padded channels must stay zero"
+    # mode 3 (sums only, d untouched) + apply differentiating on the fly == mode 0 + plain apply, for a unit without residual.
+    # (Not for the large-mean case: u = y*sc + sh carries ~ulp(mean) of absolute error there, enough to flip one ReLU mask
+    # against torch's (y - mean) * invstd form, and one flipped element shifts its whole channel's dy by d/R.)
+    if offset != 0.0:
+        return
+    y2 = y.detach().clone().requires_grad_()
+    out2 = F.relu(F.batch_norm(y2, None, None, gamma.detach(), beta.detach(), True, 0.1, 1e-5))
+    out2.backward(da)
+    d2 = _cl(da)
+    keep = d2.clone()
+    _lib.check(lib.pasn_unit_bwd_reduce(3, d2.data_ptr(), yd.data_ptr(), stat.data_ptr(), 0, 0, 0, ws.data_ptr(), coef.data_ptr(), dg.data_ptr(),
+                                        db.data_ptr(), n, S, c, cp, 1, F32, _st()))
+    assert torch.equal(d2, keep), "mode 3 must not write d"
+    _lib.check(lib.pasn_bn_bwd_apply(d2.data_ptr(), yd.data_ptr(), stat.data_ptr(), coef.data_ptr(), dy.data_ptr(), n, S, c, cp, 1, F32, _st()))
+    _rel(_ncl(dy, c), y2.grad, 2e-4, "dy (lazy differentiation)")
 
 
 def test_se_unit_forward_backward():
@@ -132,7 +147,7 @@ def test_se_unit_forward_backward():
                                     cse, _st()))
     _lib.check(lib.pasn_unit_bwd_reduce(2, dd.data_ptr(), yd.data_ptr(), stat.data_ptr(), 0, gated.data_ptr(), add.data_ptr(), ws.data_ptr(),
                                         coef.data_ptr(), G[0].data_ptr(), G[1].data_ptr(), n, S, c, cp, 3, F32, _st()))
-    _lib.check(lib.pasn_bn_bwd_apply(dd.data_ptr(), yd.data_ptr(), stat.data_ptr(), coef.data_ptr(), dd.data_ptr(), n, S, c, cp, F32, _st()))
+    _lib.check(lib.pasn_bn_bwd_apply(dd.data_ptr(), yd.data_ptr(), stat.data_ptr(), coef.data_ptr(), dd.data_ptr(), n, S, c, cp, 0, F32, _st()))
     for got, ref, name in zip(G, (gamma, beta, w1, b1, w2, b2), ("dgamma", "dbeta", "dfc1.w", "dfc1.b", "dfc2.w", "dfc2.b")):
         _rel(got, ref.grad, 2e-4, name)
     _rel(_ncl(dd, c), y.grad, 2e-4, "dy")
