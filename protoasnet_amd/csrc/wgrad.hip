@@ -503,9 +503,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
     for (int i = tid * 16; i < (co_tiles + ci_tiles) * 32 * PITCH; i += 256 * 16) *reinterpret_cast<uint4*>(lds + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int units = (KT / 8) * (CGo + CGi);  // 8-row x 8-channel patches per staged K tile (at most 2 per thread, checked on the host)
-    // software pipeline: the global loads of K tile i+1 are in flight (raw registers) while tile i is multiplied out of LDS
+    // the 16 row loads of a thread are issued as one batch (raw registers), transposed and staged afterwards
     uint4 pre[2][8];
+    unsigned okbits = 0;  // validity of the 16 prefetched rows; applied when they are staged (a select right after a load would
+                          // make hipcc wait for that load on the spot and serialise the batch)
     auto fetch = [&](long rb) {
+        okbits = 0;
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int u = tid + v * 256;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
                     row = (((long)n * d.Ti + to * d.st) * d.Hi + ho * d.sh) * d.Wi + wo * d.sw;
                 }
                 pre[v][i] = *reinterpret_cast<const uint4*>(src + row * cp + cg * 8);
-                if (!ok) pre[v][i] = make_uint4(0, 0, 0, 0);
+                okbits |= (ok ? 1u : 0u) << (v * 8 + i);
             }
         }
     };
@@ -543,6 +546,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
                 const bool is_a = g < CGo;
                 const int cg = is_a ? g : g - CGo;
                 uint4 out[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (!((okbits >> (v * 8 + i)) & 1u)) pre[v][i] = make_uint4(0, 0, 0, 0);
                 transpose8x8_bf16(pre[v], out);
                 unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * PITCH + r8 * 16;
 #pragma unroll
@@ -550,11 +556,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
             }
         }
     };
-    fetch(r0);
+    // (Issuing the next tile's loads before this tile's MFMAs -- a register software pipeline -- was measured 5 % SLOWER over the
+    // 61 layers: the kernel is bound by HBM on the large layers and by its few blocks on the small ones, not by load latency.)
     for (long rb = r0; rb < r1; rb += KT) {
+        fetch(rb);
         stage();
         __syncthreads();
-        if (rb + KT < r1) fetch(rb + KT);
 #pragma unroll
         for (int kk = 0; kk < KT / 16; ++kk) {
 #pragma unroll
