@@ -240,18 +240,6 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const T* __restri
     }
 }
 
-// dw[c][tap] = sum_chunks partial[chunk][tap][c]
-__global__ __launch_bounds__(256) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int taps,
-                                                                int C, int Cp) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= taps * Cp) return;
-    const int tap = i / Cp, c = i % Cp;
-    if (c >= C) return;
-    float s = 0.0f;
-    for (int ch = 0; ch < chunks; ++ch) s += partial[((size_t)ch * taps + tap) * Cp + c];
-    dw[(size_t)c * taps + tap] = s;
-}
-
 __global__ void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int taps, int C, int Cp);
 bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s);
 size_t dw_wgrad_strip_floats(const pasn_conv_desc& d);

@@ -262,9 +262,11 @@ class PPNet(nn.Module):
             x = x.float()
         x = x.contiguous()
         runners = self.__dict__.setdefault("_train_runners", {})
-        key = (tuple(x.shape), x.dtype, self._dtype(), "A", id(self.prototype_vectors), tuple(self.prototype_shape))
+        key = (tuple(x.shape), x.dtype, self._dtype(), "A", hash(tuple(p.data_ptr() for p in self.parameters())), tuple(self.prototype_shape))
         runner = runners.get(key)
         if runner is None:
+            for stale in [k for k in runners if k[:4] == key[:4]]:
+                del runners[stale]
             runner = runners[key] = TrainRunner(self, x, 0, head="A")
         return runner(x)
 
@@ -324,9 +326,12 @@ class _XProtoHeadMixin:
             x = x.float()
         x = x.contiguous()
         runners = self.__dict__.setdefault("_train_runners", {})
-        key = (tuple(x.shape), x.dtype, self._dtype(), mode, id(self.prototype_vectors), tuple(self.prototype_shape))
+        # the launch lists hold the parameters' device addresses: a model moved / cast / pruned since gets a fresh compilation
+        key = (tuple(x.shape), x.dtype, self._dtype(), mode, hash(tuple(p.data_ptr() for p in self.parameters())), tuple(self.prototype_shape))
         runner = runners.get(key)
         if runner is None:
+            for stale in [k for k in runners if k[:4] == key[:4]]:
+                del runners[stale]
             if len(self.add_on_layers.convs()) != 2 or len(self.occurrence_module.convs()) != 3:
                 raise NotImplementedError("the training path supports the 2-conv add-on and 3-conv occurrence module of the shipped configs")
             runner = runners[key] = TrainRunner(self, x, mode)
