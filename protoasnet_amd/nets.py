@@ -262,7 +262,8 @@ class PPNet(nn.Module):
             x = x.float()
         x = x.contiguous()
         runners = self.__dict__.setdefault("_train_runners", {})
-        key = (tuple(x.shape), x.dtype, self._dtype(), "A", hash(tuple(p.data_ptr() for p in self.parameters())), tuple(self.prototype_shape))
+        key = (tuple(x.shape), x.dtype, self._dtype(), "A", hash(tuple((p.data_ptr(), p.requires_grad) for p in self.parameters())),
+               tuple(self.prototype_shape))
         runner = runners.get(key)
         if runner is None:
             for stale in [k for k in runners if k[:4] == key[:4]]:
@@ -327,7 +328,8 @@ class _XProtoHeadMixin:
         x = x.contiguous()
         runners = self.__dict__.setdefault("_train_runners", {})
         # the launch lists hold the parameters' device addresses: a model moved / cast / pruned since gets a fresh compilation
-        key = (tuple(x.shape), x.dtype, self._dtype(), mode, hash(tuple(p.data_ptr() for p in self.parameters())), tuple(self.prototype_shape))
+        key = (tuple(x.shape), x.dtype, self._dtype(), mode, hash(tuple((p.data_ptr(), p.requires_grad) for p in self.parameters())),
+               tuple(self.prototype_shape))
         runner = runners.get(key)
         if runner is None:
             for stale in [k for k in runners if k[:4] == key[:4]]:

@@ -48,6 +48,10 @@ class TrainBuilder(PlanBuilder):
         self.nbt: List[torch.Tensor] = []      # num_batches_tracked counters bumped once per forward
         self.n_fwd = -1
         self.op_names: List[str] = []
+        # activation buffer id -> does anything that produced it hold a parameter with requires_grad?  (The reference's agents
+        # freeze the trunk / everything but the last layer in some phases: XProtoNet_Base.py:253-293; frozen parts get no
+        # backward launches at all.)
+        self.live: Dict[int, bool] = {}
 
     # ---- small helpers -------------------------------------------------------------------------------------------
     def const(self, rows: int, value: float) -> torch.Tensor:
@@ -93,6 +97,16 @@ class TrainBuilder(PlanBuilder):
     def Gp(self, off: int):
         """Address of a parameter-gradient slot inside this backward pass's flat gradient buffer."""
         return lambda ptrs, g=self.gbuf, o=4 * off: ptrs[g] + o
+
+    def Gof(self, p: Optional[torch.Tensor], nullable: bool = True):
+        """Where a kernel writes ``p``'s gradient: its slot, or -- for a frozen parameter -- NULL (``nullable``) / arena scratch."""
+        if p is not None and p.requires_grad:
+            return self.Gp(self.slot(p))
+        if nullable or p is None:
+            return 0
+        scratch = self._new_buf(p.numel() * 4)
+        self._use(scratch)
+        return self.B(scratch)
 
     def add_grad(self, a: Act, g: Act) -> None:
         have = self.grads.get(a.buf)
@@ -215,11 +229,19 @@ class TrainBuilder(PlanBuilder):
             self._use(y.buf, out.buf, rb, stat_buf, gate_buf)
             self._op(lib.pasn_affine_act_fwd, B(y.buf), stat, B(rb), B(gate_buf), B(out.buf), N, S, C, Cp, actc, code)
 
+        own = [conv.weight, conv.bias] + ([norm.weight, norm.bias] if norm is not None else []) + \
+              ([se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias] if se is not None else [])
+        own_live = any(t is not None and t.requires_grad for t in own)
+        x_live = self.live.get(x.buf, False)
+        res_live = residual is not None and self.live.get(residual.buf, False)
+        self.live[out.buf] = x_live or own_live or res_live
+        w_live = conv.weight.requires_grad
+
         # ---------------- backward emitter ----------------
         def backward() -> None:
             g = self.grads.get(out.buf)
-            if g is None:
-                return  # nothing downstream needs this unit's gradient
+            if g is None or not self.live[out.buf]:
+                return  # nothing downstream needs this unit's gradient / nothing in or before it is trainable
             dy = g
             if not plain:
                 chunks = int(lib.pasn_train_chunks(N, S, Cp))
@@ -228,9 +250,9 @@ class TrainBuilder(PlanBuilder):
                 rb = residual.buf if residual is not None else None
                 red = lib.pasn_unit_bwd_reduce
                 if norm is not None:
-                    dg, db = self.Gp(self.slot(norm.weight)), self.Gp(self.slot(norm.bias))
+                    dg, db = self.Gof(norm.weight), self.Gof(norm.bias)
                 elif conv.bias is not None:
-                    dg, db = 0, self.Gp(self.slot(conv.bias))
+                    dg, db = 0, self.Gof(conv.bias)
                 else:
                     dg = db = 0
                 lazy = se is None and norm is not None and residual is None  # nobody but the apply pass reads the differentiated d
@@ -241,7 +263,7 @@ class TrainBuilder(PlanBuilder):
                     cse = se.fc1.out_channels
                     addb = self._new_buf(N * Cp * 4)
                     pn = self._new_buf(int(lib.pasn_se_bwd_workspace_floats(N, C, cse)) * 4)
-                    o = [self.Gp(self.slot(t)) for t in (se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)]
+                    o = [self.Gof(t, nullable=False) for t in (se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)]
                     self._use(g.buf, y.buf, stat_buf, gate_buf, ws)
                     self._op(red, 1, B(g.buf), B(y.buf), stat, 0, B(gate_buf), 0, B(ws), 0, 0, 0, N, S, C, Cp, actc, code)
                     self._use(ws, pool_buf, addb, pn)
@@ -249,22 +271,30 @@ class TrainBuilder(PlanBuilder):
                              B(addb), B(pn), o[0], o[1], o[2], o[3], N, S, C, Cp, cse)
                     self._use(g.buf, y.buf, stat_buf, gate_buf, addb, ws, coef)
                     self._op(red, 2, B(g.buf), B(y.buf), stat, 0, B(gate_buf), B(addb), B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
-                if residual is not None:
+                if residual is not None and res_live:
                     self.add_grad(residual, g)  # after mode 0, g is the gradient of the pre-activation sum
+                if not (x_live or w_live):
+                    return  # only this unit's norm / bias / SE parameters were trainable: their gradients are out already
                 if norm is not None:
                     dy = self.like(y) if residual is not None else g
                     self._use(g.buf, y.buf, stat_buf, coef, dy.buf)
                     self._op(lib.pasn_bn_bwd_apply, B(g.buf), B(y.buf), stat, B(coef), B(dy.buf), N, S, C, Cp, actc if lazy else 0, code)
+            elif not (x_live or w_live):
+                return
             # ---- weight gradient
-            dW = self.Gp(self.slot(conv.weight))
+            dW = self.Gof(conv.weight)
             if kind == "first":
-                self._use(x.buf, dy.buf)
-                self._op(lib.pasn_first_conv_wgrad, B(x.buf), B(dy.buf), dW, dref, _lib.dtype_code(self.in_dtype), code)
+                if w_live:
+                    self._use(x.buf, dy.buf)
+                    self._op(lib.pasn_first_conv_wgrad, B(x.buf), B(dy.buf), dW, dref, _lib.dtype_code(self.in_dtype), code)
                 return
             if kind == "dw":
-                wsb = self._new_buf(int(lib.pasn_dwconv3d_wgrad_workspace_floats(dref)) * 4)
-                self._use(x.buf, dy.buf, wsb)
-                self._op(lib.pasn_dwconv3d_wgrad, B(x.buf), B(dy.buf), B(wsb), dW, dref, code)
+                if w_live:
+                    wsb = self._new_buf(int(lib.pasn_dwconv3d_wgrad_workspace_floats(dref)) * 4)
+                    self._use(x.buf, dy.buf, wsb)
+                    self._op(lib.pasn_dwconv3d_wgrad, B(x.buf), B(dy.buf), B(wsb), dW, dref, code)
+                if not x_live:
+                    return
                 dx = self.like(x)
                 same = s == (1, 1, 1) and all(kk % 2 == 1 and pp == kk // 2 for kk, pp in zip(k, p))
                 if same:
@@ -283,8 +313,11 @@ class TrainBuilder(PlanBuilder):
                     self._op(lib.pasn_dwconv3d_dgrad, B(dy.buf), dw_w.data_ptr(), B(dx.buf), dref, code)
                 self.add_grad(x, dx)
                 return
-            self._use(x.buf, dy.buf)
-            self._op(lib.pasn_conv3d_wgrad, B(x.buf), B(dy.buf), dW, dref, code)
+            if w_live:
+                self._use(x.buf, dy.buf)
+                self._op(lib.pasn_conv3d_wgrad, B(x.buf), B(dy.buf), dW, dref, code)
+            if not x_live:
+                return
             # ---- input gradient of the dense conv
             one = (1, 1, 1)
             have = self.grads.get(x.buf)
@@ -333,10 +366,11 @@ class TrainBuilder(PlanBuilder):
         dref, code, lib, B = ctypes.byref(d), self.code, self.lib, self.B
         self._use(x.buf, y.buf)
         self._op(lib.pasn_maxpool3d_fwd, B(x.buf), B(y.buf), dref, code)
+        self.live[y.buf] = self.live.get(x.buf, False)
 
         def backward() -> None:
             g = self.grads.get(y.buf)
-            if g is None:
+            if g is None or not self.live[y.buf]:
                 return
             dx = self.like(x)
             self._use(x.buf, g.buf, dx.buf)
@@ -368,14 +402,15 @@ class TrainBuilder(PlanBuilder):
             dz = self.like(z) if z is not None else None
             dr = self.like(r)
             dfeat = self._new_buf(r.N * P * D * 4) if z is not None else None
-            gp, gf = (self.Gp(self.slot(pv)), self.Gp(self.slot(fw))) if z is not None else (0, 0)
+            gp, gf = (self.Gof(pv, nullable=False), self.Gof(fw, nullable=False)) if z is not None else (0, 0)
             dzb = dz.buf if dz is not None else None
             self._use(zb, r.buf, dzb, dr.buf, dfeat)
             self._op(lib.pasn_xproto_tail_bwd, B(zb), B(r.buf), Pm(pv), Pm(fw), B(e["feat"]), B(e["sim"]), B(e["dlogits"]), B(e["dsim"]),
                      B(e["docc"]), B(dfeat), B(dzb), B(dr.buf), gp, gf, dref, code)
-            if z is not None:
+            if z is not None and self.live.get(z.buf, False):
                 self.add_grad(z, dz)
-            self.add_grad(r, dr)
+            if self.live.get(r.buf, False):
+                self.add_grad(r, dr)
 
         self.tape.append(backward)
 
@@ -401,8 +436,9 @@ class TrainBuilder(PlanBuilder):
             coef = self._new_buf(N * P * 4)
             self._use(z.buf, amin, dz.buf, coef)
             self._op(lib.pasn_l2_head_bwd, B(z.buf), Pm(pv), Pm(fw), B(e["min_d"]), B(amin), B(e["dlogits"]), B(e["dmin"]), B(dz.buf), B(coef),
-                     self.Gp(self.slot(pv)), self.Gp(self.slot(fw)), N, S, D, z.Cp, P, K, code, actc, eps)
-            self.add_grad(z, dz)
+                     self.Gof(pv, nullable=False), self.Gof(fw, nullable=False), N, S, D, z.Cp, P, K, code, actc, eps)
+            if self.live.get(z.buf, False):
+                self.add_grad(z, dz)
 
         self.tape.append(backward)
 
