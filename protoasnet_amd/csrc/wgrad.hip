@@ -469,7 +469,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
     const int m = lane & 31, h = lane >> 5;
     const long R = (long)d.N * d.To * d.Ho * d.Wo;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    const bool strided = d.st != 1 || d.sh != 1 || d.sw != 1;
+    // rows of x are gathered through the conv's window map when it is not the identity (strided 1x1x1 convs, windowed convs:
+    // one tap per blockIdx.z, rows that fall into the padding read as zero)
+    const int taps = d.kt * d.kh * d.kw, tap = blockIdx.z;
+    const int tt = tap / (d.kh * d.kw), th = (tap / d.kw) % d.kh, tw = tap % d.kw;
+    const bool strided = d.st != 1 || d.sh != 1 || d.sw != 1 || taps != 1 || d.pt || d.ph || d.pw;
     const int ntiles = co_tiles * ci_tiles;
     // this wave's tiles: (blockIdx.y * 4 + wave) * TPW + j; out-of-range ones alias tile 0 and are dropped at the end
     int t_co[TPW], t_ci[TPW];
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long r = rb + r8 * 8 + i;
-                const bool ok = live && r < r1;
+                bool ok = live && r < r1;
                 long row = ok ? r : r0;
                 if (!is_a && strided) {
                     const int wo = (int)(row % d.Wo);
@@ -518,7 +522,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
                     const int ho = (int)(q % d.Ho);
                     q /= d.Ho;
                     const int to = (int)(q % d.To), n = (int)(q / d.To);
-                    row = (((long)n * d.Ti + to * d.st) * d.Hi + ho * d.sh) * d.Wi + wo * d.sw;
+                    const int ti = to * d.st - d.pt + tt, hi = ho * d.sh - d.ph + th, wi = wo * d.sw - d.pw + tw;
+                    const bool in = ti >= 0 && ti < d.Ti && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
+                    ok = ok && in;
+                    row = in ? (((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi : 0;
                 }
                 pre[v][i] = *reinterpret_cast<const uint4*>(src + row * cp + cg * 8);
                 okbits |= (ok ? 1u : 0u) << (v * 8 + i);
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int cog = t_co[j] * 32 + acc_row(reg, h);
-                if (cog < d.Cout) unsafeAtomicAdd(dw + (size_t)cog * d.Cin + cig, acc[j][reg]);
+                if (cog < d.Cout) unsafeAtomicAdd(dw + ((size_t)cog * d.Cin + cig) * taps + tap, acc[j][reg]);
             }
         }
     }
@@ -580,10 +587,11 @@ static void launch_pw_wgrad_bf16(const void* x, const void* dy, float* dw, const
     const long R = (long)d.N * d.To * d.Ho * d.Wo;
     // split-K partitions: enough blocks to fill the chip, but every partition ends in ntiles*1024 atomics on the same addresses
     const long ntiles = (long)co_tiles * ci_tiles;
-    const long want_blocks = std::max<long>(1, std::min<long>(2048 / gy, std::max<long>(16, 3000 / ntiles)));
+    const int taps = d.kt * d.kh * d.kw;
+    const long want_blocks = std::max<long>(1, std::min<long>(2048 / ((long)gy * taps) + 1, std::max<long>(16, 3000 / ntiles)));
     long rpb = std::max<long>(KT, (R + want_blocks - 1) / want_blocks);
     rpb = (rpb + KT - 1) / KT * KT;
-    const dim3 grid(ceil_div(R, rpb), gy);
+    const dim3 grid(ceil_div(R, rpb), gy, taps);
     const size_t lds = (size_t)(co_tiles + ci_tiles) * 32 * WgLds<KT>::PITCH;
     hipLaunchKernelGGL((pw_wgrad_bf16_kernel<KT, TPW>), grid, dim3(256), lds, s, (const __bf16*)x, (const __bf16*)dy, dw, d, co_tiles, ci_tiles,
                        (int)rpb);
@@ -591,7 +599,7 @@ static void launch_pw_wgrad_bf16(const void* x, const void* dy, float* dw, const
 
 // returns false when the geometry is outside the fast path
 bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s) {
-    if (d.kt * d.kh * d.kw != 1 || d.pt || d.ph || d.pw) return false;
+    if (d.kt * d.kh * d.kw > 64) return false;
     const int co_tiles = ceil_div(d.Cout_p, 32), ci_tiles = ceil_div(d.Cin_p, 32);
     const int ntiles = co_tiles * ci_tiles;
     const bool small = (co_tiles + ci_tiles) <= 6;  // few channels: stage more rows per step so every thread has a patch to move

@@ -4,6 +4,8 @@
     python tools/configs_bench.py sweep     # config 5: X3D-M, 32x312x312 clips, 60 prototypes -- fp32 vs bf16 vs CPU oracle
     python tools/configs_bench.py push      # config 4: push_prototypes over 10k synthetic clips, 30 prototypes, 1 GPU
     python tools/configs_bench.py r2p1d     # reference-faithful trunk: R(2+1)D-18[:-3], 32x112x112 and 16x224x224 clips
+    python tools/configs_bench.py image     # config 1: Image ProtoASNet (XProtoNet, ResNet-18, 40 prototypes, 224^2), batch 8: CPU oracle vs HIP
+    python tools/configs_bench.py train     # config 3 at N = 1: training step of every trunk (fwd + loss + bwd + Adam), bf16
 """
 import json
 import os
@@ -118,5 +120,87 @@ def r2p1d():
                           "ms_per_batch": round(sec * 1e3, 2), "trunk_TFLOPs": round(2 * gmac * shape[0] / sec / 1e3, 1)}))
 
 
+def image():
+    """Config 1 (Ours_ProtoASNet_Image.yml: ResNet-18, P=40, D=512, K=4, 224^2, batch 8) -- the reference's CPU-runnable case."""
+    import oracle
+
+    cfg = dict(checkpoint_path="", name="XProtoNet", base_architecture="resnet18", pretrained=False, prototype_shape="(40, 512, 1, 1)",
+               num_classes=4, img_size=224, add_on_layers_type="regular")
+    m = model_builder.build(cfg)
+    synth.load_synth(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = synth.echo_clips((8, 3, 224, 224))
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        oracle.nets.xprotonet_forward(sd, x[:1], arch="resnet18")
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            ref = oracle.nets.xprotonet_forward(sd, x, arch="resnet18")
+            reps += 1
+        t_cpu = (time.perf_counter() - t0) / reps
+    m = m.to(DEV).eval()
+    row = {"config": "Image ProtoASNet (XProtoNet), ResNet-18, P=40, D=512, K=4, 8x3x224x224 (BASELINE config 1)",
+           "cpu_oracle_images_per_s": round(8 / t_cpu, 1), "cpu_threads": cores}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m.set_compute_dtype(dt)
+        xin = x.to(DEV).to(dt)
+
+        def f():
+            with torch.no_grad():
+                return m(xin)
+
+        sec, out = timed(f, 50)
+        row[name] = {"images_per_s_batch8": round(8 / sec, 1), "ms_per_batch": round(sec * 1e3, 3),
+                     "max_abs_similarity_vs_cpu": float((out[1].float().cpu() - ref["similarity"]).abs().max())}
+    xb = synth.echo_clips((256, 3, 224, 224)).to(DEV).to(torch.bfloat16)
+
+    def g():
+        with torch.no_grad():
+            return m(xb)
+
+    sec, _ = timed(g, 10)
+    row["bf16"]["images_per_s_batch256"] = round(256 / sec, 1)
+    print(json.dumps(row))
+
+
+def train():
+    """Training step (config 3's per-GPU work) for each trunk: forward + loss + backward + Adam, bf16 activations."""
+    import torch.nn.functional as F
+
+    for arch, shape, name in (("x3d_s", (32, 3, 16, 224, 224), "Video_XProtoNet"), ("x3d_m", (8, 3, 32, 312, 312), "Video_XProtoNet"),
+                              ("resnet2p1d_18", (8, 3, 32, 112, 112), "Video_XProtoNet"), ("resnet18", (64, 3, 224, 224), "XProtoNet")):
+        video = len(shape) == 5
+        cfg = dict(checkpoint_path="", name=name, base_architecture=arch, pretrained=False, num_classes=3, img_size=shape[-1],
+                   prototype_shape="(30, 256, 1, 1, 1)" if video else "(30, 512, 1, 1)")
+        if video:
+            cfg["backbone_last_layer_num"] = -3
+        else:
+            cfg["add_on_layers_type"] = "regular"
+        m = model_builder.build(cfg)
+        synth.load_synth(m)
+        m = m.to(DEV).train().set_compute_dtype(torch.bfloat16)
+        x = synth.echo_clips(shape).to(DEV).to(torch.bfloat16)
+        labels = torch.randint(0, 3, (shape[0],), generator=torch.Generator().manual_seed(0)).to(DEV)
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-3)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            logits, sim, occ = m(x)
+            loss = F.cross_entropy(logits, labels) + 1e-3 * occ.abs().mean() - 0.1 * sim.max(dim=1)[0].mean()
+            loss.backward()
+            opt.step()
+            return loss
+
+        sec, loss = timed(step, 5)
+        plan = next(iter(m._train_runners.values())).plan
+        print(json.dumps({"config": f"train step, {name} / {arch}, {shape} bf16", "clips_per_s": round(shape[0] / sec, 1),
+                          "ms_per_step": round(sec * 1e3, 2), "launches": len(plan.ops), "arena_GB": round(plan.arena_bytes / 1e9, 2),
+                          "loss": round(float(loss.detach()), 4)}))
+        del m, opt, x
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
-    {"sweep": sweep, "push": push, "r2p1d": r2p1d}[sys.argv[1]]()
+    {"sweep": sweep, "push": push, "r2p1d": r2p1d, "image": image, "train": train}[sys.argv[1]]()
