@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--per-op", default="", help="write a per-launch timing table to this file")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward = the BASELINE.json headline metric (default); train = config 3's training step (tools/train_bench.py)")
+    ap.add_argument("--train-loss", default="reference", choices=["reference", "simple"], help="--mode train: the reference's loss recipe "
+                    "(incl. TransformLoss's second trunk pass) or a single-pass loss")
     return ap.parse_args()
 
 
@@ -57,7 +59,8 @@ def main():
         import train_bench
 
         return train_bench.main(["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
-                                 "--frames", str(args.frames), "--size", str(args.size), "--arch", args.arch, "--dtype", args.dtype]
+                                 "--frames", str(args.frames), "--size", str(args.size), "--arch", args.arch, "--dtype", args.dtype,
+                                 "--loss", args.train_loss]
                                 + (["--per-op", args.per_op] if args.per_op else []))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -5,9 +5,11 @@ of Video ProtoASNet (X3D-S trunk, head B) on synthetic echo batches, one process
     python tools/train_bench.py --steps 10 --warmup 3 [--dtype bf16|f32] [--batch 32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/train_bench.py --gpus N
 
-Loss: cross-entropy on the logits + the L1 norm of the occurrence maps + a cluster-style term on the similarities (plain torch
-ops on the tiny head outputs; the reference's loss stack is SURVEY.md section 8f row 1, not built).  The optimizer is
-torch.optim.Adam (lr 1e-4, weight_decay 1e-3) as in the reference's agents (Video_XProtoNet_e2e.py:36-62)."""
+Loss (``--loss reference``, default): the recipe of src/configs/Ours_ProtoASNet_Video.yml:31-58 as the agent applies it
+(Video_XProtoNet_e2e.py:88-100) -- CeLoss (mean) + 0.8 ClusterRoiFeat + 0.08 SeparationRoiFeat + 1e-3 TransformLoss (a SECOND trunk
+pass, with gradients, over the affinely warped clip: model.compute_occurence_map) + 1e-4 L1 of the last layer's off-class weights;
+``--loss simple`` keeps one pass (cross entropy + L1 of the maps + a cluster term).  protoasnet_amd.losses supplies the classes.
+The optimizer is torch.optim.Adam (lr 1e-4) as in the reference's agents (Video_XProtoNet_e2e.py:36-62)."""
 import argparse
 import json
 import os
@@ -32,6 +34,7 @@ def main(argv=None):
     ap.add_argument("--arch", default="x3d_s")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--per-op", default="", help="write per-launch device times of one step to this file")
+    ap.add_argument("--loss", default="reference", choices=["reference", "simple"])
     args = ap.parse_args(argv)
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
@@ -53,14 +56,27 @@ def main(argv=None):
     x = synth.echo_clips((args.batch, 3, args.frames, args.size, args.size), seed=synth.DEFAULT_SEED + rank).to(dev).to(dtype)
     labels = torch.randint(0, 3, (args.batch,), generator=torch.Generator().manual_seed(rank)).to(dev)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-3)
+    opt = torch.optim.Adam(params, lr=1e-4)
     ident = model.prototype_class_identity.to(dev)
+    from protoasnet_amd import losses as L
+
+    ce, cluster = L.CeLoss(loss_weight=1, reduction="mean"), L.ClusterRoiFeat(loss_weight=0.8, num_classes=3, reduction="mean")
+    separation = L.SeparationRoiFeat(loss_weight=0.08, num_classes=3, reduction="mean", abstain_class=False)
+    trans = L.TransformLoss(loss_weight=1e-3, reduction="mean")
+    fc_l1 = L.L_norm(mask=1 - torch.t(model.prototype_class_identity), p=1, loss_weight=1e-4)
+    import random
+
+    random.seed(1234 + rank)
 
     def step():
         opt.zero_grad(set_to_none=True)
         logits, sim, occ = model(x)
-        own = ident[:, labels].t()  # (N, P): prototypes of the clip's class
-        loss = F.cross_entropy(logits, labels) + 1e-3 * occ.abs().mean() + 0.1 * ((1 - sim) * own).sum(1).mean()
+        if args.loss == "reference":
+            loss = (ce.compute(logits, labels) + cluster.compute(sim, labels) + separation.compute(sim, labels)
+                    + trans.compute(x, occ, model) + fc_l1.compute(model.last_layer.weight))
+        else:
+            own = ident[:, labels].t()  # (N, P): prototypes of the clip's class
+            loss = F.cross_entropy(logits, labels) + 1e-3 * occ.abs().mean() + 0.1 * ((1 - sim) * own).sum(1).mean()
         loss.backward()
         dp.allreduce_gradients(params)
         opt.step()
@@ -84,7 +100,7 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(loss), "non-finite loss"
-    runner = next(iter(model._train_runners.values()))
+    runner = next(r for r in model._train_runners.values() if r.mode == 0)
     if args.per_op and rank == 0:
         plan = runner.plan
         evs = []
@@ -116,7 +132,8 @@ def main(argv=None):
             "metric": "clips/sec train step", "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"Video ProtoASNet train step (fwd + loss + bwd + grad all-reduce + Adam), {args.arch} + head B, "
+            "config": {"workload": f"Video ProtoASNet train step (fwd + {'reference loss recipe incl. TransformLoss second pass' if args.loss == 'reference' else 'simple loss'}"
+                                   f" + bwd + grad all-reduce + Adam), {args.arch} + head B, "
                                    f"{args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (one flat fp32 gradient bucket all-reduced per step)"},
             "launches": {"forward": plan.n_fwd, "backward": len(plan.ops) - plan.n_fwd}, "arena_bytes": plan.arena_bytes,
