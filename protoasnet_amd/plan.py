@@ -496,7 +496,7 @@ def channels_last_rows(feat: torch.Tensor, dtype: torch.dtype) -> Tuple[torch.Te
 
 
 class HipTrunk(nn.Module):
-    """Base of the feature trunks: parameter container + cached HIP plans (forward only, eval mode)."""
+    """Base of the feature trunks: parameter container + cached eval-mode HIP plans; ``build_train`` feeds the training tape."""
 
     arch = "trunk"
     out_channels = 0
