@@ -504,13 +504,16 @@ def test_video_x3d_train_unmodified_model_vs_oracle():
     assert cos > 0.98 and median < 5e-2, f"gradient direction cosine {cos:.4f}, median per-tensor error {median:.2e}; worst {rows[:3]}"
 
 
-def test_video_x3d_train_bf16_activations_track_fp32():
-    """bf16 activations / activation gradients (fp32 statistics, reductions, parameter gradients) against the fp32 mode."""
-    x = synth.echo_clips(SHAPE).to(DEV)
-    wl, ws, wo = (t.to(DEV) for t in _loss_weights(2, 30, 3, SPATIAL))
+@pytest.mark.parametrize("cfg,shape,spatial", [(CFG_VIDEO_X3D, SHAPE, SPATIAL), (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4)),
+                                               (CFG_XPROTO, (3, 3, 96, 96), (3, 3))], ids=["x3d_s", "r2plus1d", "resnet18"])
+def test_train_bf16_activations_track_fp32(cfg, shape, spatial):
+    """bf16 activations / activation gradients (fp32 statistics, reductions, parameter gradients) against the fp32 mode, every trunk
+    (bf16 takes other kernels: T-marching stencils, LDS-transposed MFMA weight gradients incl. the windowed ones)."""
+    x = synth.echo_clips(shape).to(DEV)
     grads, outs = {}, {}
     for tag, dt in (("f32", None), ("bf16", torch.bfloat16)):
-        m = _train_model(kink_free=True)
+        m = _train_model(kink_free=True, cfg=cfg)
+        wl, ws, wo = (t.to(DEV) for t in _loss_weights(shape[0], m.num_prototypes, m.num_classes, spatial))
         m.set_compute_dtype(dt)
         logits, sim, occ = m(x)
         ((logits * wl).sum() + (sim * ws).sum() + (occ * wo).sum()).backward()
