@@ -641,16 +641,17 @@ __device__ __forceinline__ void loadc(const T* p, float (&v)[CH]) {
 
 // CH channels per thread (4: half the registers of 8, twice the resident waves -- the kernel is bound by load latency, not by
 // bytes per load instruction); CGb = lanes per position (power of two >= Cp / CH)
-template <typename T, int SW, int WT, int CH>
+// NA = temporal taps handled by one thread: 1 (one tap per blockIdx.z: x and dy stream from HBM once per tap) or 3 (all three in
+// one pass: a third of the HBM traffic, three times the accumulators)
+template <typename T, int SW, int WT, int CH, int NA>
 __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
                                                              pasn_conv_desc d, int CG, int CGb, int strips, int HR, int hgroups, long items) {
     __shared__ float red[256 * CH];
     constexpr int IW = (WT - 1) * SW + 3;
     const int cg = threadIdx.x % CGb, pl = threadIdx.x / CGb, PL = 256 / CGb;
-    const int a = blockIdx.z;
-    float acc[9][CH];
+    float acc[NA * 9][CH];
 #pragma unroll
-    for (int p = 0; p < 9; ++p)
+    for (int p = 0; p < NA * 9; ++p)
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[p][j] = 0.0f;
     // over (n, to, hgroup, strip); a block keeps accumulating over several item groups before its one partial is written
@@ -660,12 +661,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
         const int hg = (int)(q % hgroups);
         q /= hgroups;
         const int to = (int)(q % d.To), n = (int)(q / d.To);
-        const int ti = to * d.st - d.pt + a;
-        if (ti >= 0 && ti < d.Ti) {
-            const int wo0 = strip * WT, wi0 = wo0 * SW - 1;
-            const T* xp = x + (((size_t)n * d.Ti + ti) * d.Hi) * d.Wi * d.Cin_p + cg * CH;
-            const T* gp = dy + (((size_t)n * d.To + to) * d.Ho) * d.Wo * d.Cout_p + cg * CH;
-            const int h1 = min(d.Ho, (hg + 1) * HR);
+        const int wo0 = strip * WT, wi0 = wo0 * SW - 1;
+        const T* gp = dy + (((size_t)n * d.To + to) * d.Ho) * d.Wo * d.Cout_p + cg * CH;
+        const int h1 = min(d.Ho, (hg + 1) * HR);
+        {
             for (int ho = hg * HR; ho < h1; ++ho) {
                 float g[WT][CH];
 #pragma unroll
@@ -679,9 +678,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
                     }
                 }
 #pragma unroll
+                for (int ai = 0; ai < NA; ++ai) {
+                const int a = NA == 1 ? (int)blockIdx.z : ai;
+                const int ti = to * d.st - d.pt + a;
+                const bool tok = ti >= 0 && ti < d.Ti;
+                if (NA == 1 && !tok) continue;
+                const T* xp = x + (((size_t)n * d.Ti + (tok ? ti : 0)) * d.Hi) * d.Wi * d.Cin_p + cg * CH;
+#pragma unroll
                 for (int dh = 0; dh < 3; ++dh) {
                     const int hi = ho * SW - 1 + dh;
-                    const bool hok = hi >= 0 && hi < d.Hi;
+                    const bool hok = tok && hi >= 0 && hi < d.Hi;
                     float xr[IW][CH];
 #pragma unroll
                     for (int i = 0; i < IW; ++i) {
@@ -698,15 +704,17 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
 #pragma unroll
                         for (int j = 0; j < WT; ++j)
 #pragma unroll
-                            for (int e = 0; e < CH; ++e) acc[dh * 3 + dw_][e] = fmaf(g[j][e], xr[j * SW + dw_][e], acc[dh * 3 + dw_][e]);
+                            for (int e = 0; e < CH; ++e)
+                                acc[ai * 9 + dh * 3 + dw_][e] = fmaf(g[j][e], xr[j * SW + dw_][e], acc[ai * 9 + dh * 3 + dw_][e]);
+                }
                 }
             }
         }
     }
     const int taps = d.kt * 9;
-    float* out = partial + ((size_t)blockIdx.x * taps + (size_t)a * 9) * d.Cout_p;
+    float* out = partial + ((size_t)blockIdx.x * taps + (size_t)(NA == 1 ? blockIdx.z : 0) * 9) * d.Cout_p;
 #pragma unroll
-    for (int p = 0; p < 9; ++p) {
+    for (int p = 0; p < NA * 9; ++p) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < CH; ++j) red[threadIdx.x * CH + j] = acc[p][j];
@@ -864,9 +872,15 @@ bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const p
     }
     const DwWgGeom g = dw_wgrad_strip_geom(d);
     if (!g.ok) return false;
-    const dim3 grid((unsigned)g.blocks, 1, d.kt);
+    static const bool fuse3 = getenv("PASN_DWWG_FUSED") ? atoi(getenv("PASN_DWWG_FUSED")) != 0 : false;
+    const bool na3 = fuse3 && d.kt == 3;
+    const dim3 grid((unsigned)g.blocks, 1, na3 ? 1 : d.kt);
 #define DWS(T, SWv, WTv)                                                                                                              \
-    hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, SWv, WTv, 4>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, ws, d, g.CG, g.CGb, g.strips, \
+    if (na3)                                                                                                                          \
+        hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, SWv, WTv, 4, 3>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, ws, d, g.CG, g.CGb, \
+                           g.strips, g.HR, g.hgroups, g.items);                                                                      \
+    else                                                                                                                              \
+        hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, SWv, WTv, 4, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, ws, d, g.CG, g.CGb, g.strips, \
                        g.HR, g.hgroups, g.items)
     if (dtype == PASN_BF16) {
         if (g.SW == 1) DWS(__bf16, 1, 3);
