@@ -360,10 +360,16 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     const int n = blockIdx.x, tid = threadIdx.x;
     for (int c = tid; c < C; c += 256) pool[c] = pool_u[(size_t)n * Cp + c];
     __syncthreads();
-    for (int j = tid; j < Cse; j += 256) {
-        float a = b1[j];
-        for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)j * C + c], pool[c], a);
-        h[j] = fmaxf(a, 0.0f);
+    // hidden units: 8 lanes share one dot product over the channels (shuffle combine in a fixed order)
+    for (int j0 = 0; j0 < Cse; j0 += 32) {
+        const int j = j0 + (tid >> 3), sub = tid & 7;
+        float a = 0.0f;
+        if (j < Cse)
+            for (int c = sub; c < C; c += 8) a = fmaf(w1[(size_t)j * C + c], pool[c], a);
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
+        if (j < Cse && sub == 0) h[j] = fmaxf(a + b1[j], 0.0f);
     }
     __syncthreads();
     float* p = pn + (size_t)n * (2 * (size_t)C * Cse + Cse + C);
@@ -383,12 +389,19 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
         for (int j = 0; j < Cse; ++j) p_w2[(size_t)c * Cse + j] = d * h[j];
     }
     __syncthreads();
-    for (int j = tid; j < Cse; j += 256) {
+    for (int j0 = 0; j0 < Cse; j0 += 32) {
+        const int j = j0 + (tid >> 3), sub = tid & 7;
         float a = 0.0f;
-        for (int c = 0; c < C; ++c) a = fmaf(w2[(size_t)c * Cse + j], ds[c], a);
-        a = h[j] > 0.0f ? a : 0.0f;
-        dh[j] = a;
-        p_b1[j] = a;
+        if (j < Cse)
+            for (int c = sub; c < C; c += 8) a = fmaf(w2[(size_t)c * Cse + j], ds[c], a);
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
+        if (j < Cse && sub == 0) {
+            a = h[j] > 0.0f ? a : 0.0f;
+            dh[j] = a;
+            p_b1[j] = a;
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -402,14 +415,20 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     for (int c = C + tid; c < Cp; c += 256) add[(size_t)n * Cp + c] = 0.0f;
 }
 
-// out[i] = sum_n pn[n * stride + i], i < len   (fixed order)
-__global__ __launch_bounds__(256) void sum_over_clips_kernel(const float* __restrict__ pn, float* __restrict__ out, int N, size_t stride,
-                                                             size_t len) {
+// The per-clip parameter-gradient contributions pn[n][dw1 | db1 | dw2 | db2] summed over the clips (fixed order), each
+// segment into its own gradient tensor -- one launch for the four.
+__global__ __launch_bounds__(256) void se_sum_over_clips_kernel(const float* __restrict__ pn, float* __restrict__ dw1, float* __restrict__ db1,
+                                                                float* __restrict__ dw2, float* __restrict__ db2, int N, int C, int Cse) {
+    const size_t o_b1 = (size_t)Cse * C, o_w2 = o_b1 + Cse, o_b2 = o_w2 + (size_t)C * Cse, len = o_b2 + C;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= len) return;
     float s = 0.0f;
-    for (int n = 0; n < N; ++n) s += pn[(size_t)n * stride + i];
-    out[i] = s;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) s += pn[(size_t)n * len + i];
+    if (i < o_b1) dw1[i] = s;
+    else if (i < o_w2) db1[i - o_b1] = s;
+    else if (i < o_b2) dw2[i - o_w2] = s;
+    else db2[i - o_b2] = s;
 }
 
 // ---- strided scatter: dst[n][t*st][h*sh][w*sw][:] (+)= src[n][t][h][w][:], every other element 0 (or kept) -------------
@@ -621,13 +640,8 @@ extern "C" int pasn_se_gate_bwd(const float* ws, const float* pool_u, const floa
     const RowGeom g = row_geom(N, S, Cp);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), lds, s, ws, g.chunks, pool_u, w1, b1, w2, b2, add, pn, S, C, Cp, Cse);
-    // the per-clip contributions are laid out (dw1, db1, dw2, db2): sum each segment into its own gradient tensor
     const size_t len = 2 * (size_t)C * Cse + Cse + C;
-    const size_t o_b1 = (size_t)Cse * C, o_w2 = o_b1 + Cse, o_b2 = o_w2 + (size_t)C * Cse;
-    struct Seg { float* out; size_t off, n; } segs[4] = {{dw1, 0, o_b1}, {db1, o_b1, (size_t)Cse}, {dw2, o_w2, (size_t)C * Cse}, {db2, o_b2, (size_t)C}};
-    for (const Seg& sg : segs) {
-        hipLaunchKernelGGL(sum_over_clips_kernel, dim3(ceil_div((long)sg.n, 256)), dim3(256), 0, s, pn + sg.off, sg.out, N, len, sg.n);
-    }
+    hipLaunchKernelGGL(se_sum_over_clips_kernel, dim3(ceil_div((long)len, 256)), dim3(256), 0, s, pn, dw1, db1, dw2, db2, N, C, Cse);
     return check_launch("se_gate_bwd");
 }
 
