@@ -608,6 +608,8 @@ bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_des
     if ((KT / 8) * (d.Cout_p / 8 + d.Cin_p / 8) > 512) return false;  // the kernel's register pipeline holds 2 patches per thread
     int tpw = ceil_div(ntiles, 4);
     tpw = tpw <= 1 ? 1 : tpw <= 2 ? 2 : tpw <= 4 ? 4 : 8;
+    static const int tpw_cap = getenv("PASN_WG_TPW") ? atoi(getenv("PASN_WG_TPW")) : 4;  // 8 tiles per wave (occupancy 1) measured 7 % slower
+    tpw = std::min(tpw, std::max(1, tpw_cap));
     const int gy = ceil_div(ntiles, 4 * tpw);
 #define PW(K, T) launch_pw_wgrad_bf16<K, T>(x, dy, dw, d, co_tiles, ci_tiles, gy, s)
     if (small) {
