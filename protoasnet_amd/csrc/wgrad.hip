@@ -292,16 +292,65 @@ extern "C" int pasn_conv3d_wgrad(const void* x, const void* dy, float* dw, const
     return check_launch("conv3d_wgrad");
 }
 
+// im2col of the planar clip for the first conv's weight gradient: X[row][col] (bf16, 32-column groups), col = (ci, r, s); then the
+// gradient is the pointwise GEMM dW[co][col] = sum_rows dy[row][co] X[row][col] on the LDS-transposed bf16 MFMA kernel.  The
+// gather costs one pass over the clip's windows instead of one scattered 2-byte load per MFMA operand element.
+template <typename TIN>
+__global__ __launch_bounds__(256) void first_conv_im2col_kernel(const TIN* __restrict__ x, __bf16* __restrict__ X, pasn_conv_desc d, int colp) {
+    const int groups = colp / 8, cols = 3 * d.kh * d.kw;
+    const long R = (long)d.N * d.To * d.Ho * d.Wo, total = R * groups;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int g = (int)(idx % groups);
+        const long row = idx / groups;
+        const int wo = (int)(row % d.Wo);
+        long q = row / d.Wo;
+        const int ho = (int)(q % d.Ho);
+        q /= d.Ho;
+        const int to = (int)(q % d.To), n = (int)(q / d.To);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = g * 8 + j;
+            const int ci = col / (d.kh * d.kw), r = (col / d.kw) % d.kh, sx = col % d.kw;
+            const int hi = ho * d.sh - d.ph + r, wi = wo * d.sw - d.pw + sx;
+            const bool ok = col < cols && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi;
+            v[j] = ok ? (float)x[((((long)n * 3 + ci) * d.Ti + to) * d.Hi + hi) * d.Wi + wi] : 0.0f;
+        }
+        store8(X + row * colp + g * 8, v);
+    }
+}
+
+extern "C" size_t pasn_first_conv_wgrad_workspace_bytes(const pasn_conv_desc* d, int dtype) {
+    if (!d || dtype != PASN_BF16 || getenv("PASN_NO_FIRST_IM2COL")) return 0;
+    const int colp = (3 * d->kh * d->kw + 7) / 8 * 8;
+    if (colp > 512) return 0;
+    return (size_t)d->N * d->To * d->Ho * d->Wo * colp * sizeof(__bf16);
+}
+
 extern "C" int pasn_first_conv_wgrad(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int in_dtype, int dtype,
-                                     void* stream) {
+                                     void* ws, void* stream) {
     PASN_REQUIRE(x && dy && dw && d, "null pointer");
     PASN_REQUIRE(d->kt == 1 && d->st == 1 && d->pt == 0 && d->Cin == 3, "first conv is (1,kh,kw) over 3 planar channels");
     const int cols = 3 * d->kh * d->kw;
+    hipStream_t s = (hipStream_t)stream;
+    if (ws && pasn_first_conv_wgrad_workspace_bytes(d, dtype)) {
+        const int colp = (cols + 7) / 8 * 8;
+        const long R = (long)d->N * d->To * d->Ho * d->Wo, total = R * (colp / 8);
+        const int nb = (int)std::min<long>((total + 255) / 256, 1 << 20);
+        if (in_dtype == PASN_BF16)
+            hipLaunchKernelGGL(first_conv_im2col_kernel<__bf16>, dim3(nb), dim3(256), 0, s, (const __bf16*)x, (__bf16*)ws, *d, colp);
+        else
+            hipLaunchKernelGGL(first_conv_im2col_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (__bf16*)ws, *d, colp);
+        pasn_conv_desc g = *d;  // the equivalent pointwise problem over the im2col rows
+        g.Ti = d->To; g.Hi = d->Ho; g.Wi = d->Wo;
+        g.Cin = cols; g.Cin_p = colp;
+        g.kt = g.kh = g.kw = 1; g.st = g.sh = g.sw = 1; g.pt = g.ph = g.pw = 0;
+        if (pw_wgrad_bf16(ws, dy, dw, g, s)) return check_launch("first_conv_wgrad");
+    }
     const int co_tiles = ceil_div(d->Cout, 32), col_tiles = ceil_div(cols, 32);
     const long R = (long)d->N * d->To * d->Ho * d->Wo;
     const int rpw = wgrad_rows_per_wave(R, co_tiles * col_tiles);
     const dim3 grid(ceil_div(R, (long)rpw * 4), co_tiles * col_tiles);
-    hipStream_t s = (hipStream_t)stream;
 #define FW(TI, T) hipLaunchKernelGGL((first_conv_wgrad_kernel<TI, T>), grid, dim3(256), 0, s, (const TI*)x, (const T*)dy, dw, *d, col_tiles, rpw)
     if (in_dtype == PASN_BF16 && dtype == PASN_BF16) FW(__bf16, __bf16);
     else if (in_dtype == PASN_F32 && dtype == PASN_BF16) FW(float, __bf16);

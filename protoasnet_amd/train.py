@@ -285,8 +285,10 @@ class TrainBuilder(PlanBuilder):
             dW = self.Gof(conv.weight)
             if kind == "first":
                 if w_live:
-                    self._use(x.buf, dy.buf)
-                    self._op(lib.pasn_first_conv_wgrad, B(x.buf), B(dy.buf), dW, dref, _lib.dtype_code(self.in_dtype), code)
+                    wsz = int(lib.pasn_first_conv_wgrad_workspace_bytes(dref, code))
+                    wsb = self._new_buf(wsz) if wsz else None
+                    self._use(x.buf, dy.buf, wsb)
+                    self._op(lib.pasn_first_conv_wgrad, B(x.buf), B(dy.buf), dW, dref, _lib.dtype_code(self.in_dtype), code, B(wsb))
                 return
             if kind == "dw":
                 if w_live:

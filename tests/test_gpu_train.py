@@ -193,8 +193,19 @@ def test_first_conv_wgrad(in_dtype):
     d.Cin_p = 3
     xd, dyd = x.to(DEV).to(in_dtype).contiguous(), _cl(dy)
     dw = torch.zeros(24, 27, device=DEV)
-    _lib.check(lib.pasn_first_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ctypes.byref(d), _lib.dtype_code(in_dtype), F32, _st()))
+    _lib.check(lib.pasn_first_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ctypes.byref(d), _lib.dtype_code(in_dtype), F32, 0, _st()))
     _rel(dw.view_as(wt), wt.grad, 1e-4, "dW")
+    # bf16 gradients: im2col rows + the LDS-transposed MFMA kernel (workspace given) == the gather kernel (no workspace)
+    dyb = _cl(dy.bfloat16().float(), dtype=torch.bfloat16)
+    wt2 = torch.zeros(24, 3, 1, 3, 3, requires_grad=True)
+    F.conv3d(x.bfloat16().float(), wt2, stride=(1, 2, 2), padding=(0, 1, 1)).backward(dy.bfloat16().float())
+    nbytes = lib.pasn_first_conv_wgrad_workspace_bytes(ctypes.byref(d), BF16)
+    assert nbytes == 2 * 3 * 9 * 8 * 32 * 2
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    for wsp in (ws.data_ptr(), 0):
+        dw.zero_()
+        _lib.check(lib.pasn_first_conv_wgrad(xd.data_ptr(), dyb.data_ptr(), dw.data_ptr(), ctypes.byref(d), _lib.dtype_code(in_dtype), BF16, wsp, _st()))
+        _rel(dw.view_as(wt2), wt2.grad, 2e-3 if in_dtype == torch.float32 else 1e-4, "dW (bf16 dy)")
 
 
 @pytest.mark.parametrize("c,k,s,p,shape", [(54, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 3, 6, 7)), (54, (3, 3, 3), (1, 2, 2), (1, 1, 1), (2, 3, 9, 8)),
