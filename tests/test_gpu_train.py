@@ -471,6 +471,21 @@ def test_ppnet_train_step_fp32_vs_oracle_autograd(cfg):
     _check_grads(m, sd, 1e-3)
 
 
+def test_video_x3d_train_step_ragged_shape():
+    """Odd frame count, non-square planes that leave ragged strips / odd halves in every stride-2 stage, a single clip."""
+    m = _train_model(kink_free=True)
+    shape, spatial = (1, 3, 5, 96, 80), (5, 3, 3)
+    x = synth.echo_clips(shape)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    wl, ws, wo = _loss_weights(1, 30, 3, spatial)
+    logits, sim, occ = m(x.to(DEV))
+    ((logits * wl.to(DEV)).sum() + (sim * ws.to(DEV)).sum() + (occ * wo.to(DEV)).sum()).backward()
+    ref, sd_ref, _ = _oracle_step(sd0, x, wl, ws, wo)
+    _rel(logits, ref["logits"], 1e-3, "logits")
+    _rel(occ, ref["occurrence_map"], 1e-3, "occurrence_map")
+    _check_grads(m, sd_ref, 1e-3)
+
+
 @pytest.mark.parametrize("phase", ["warm", "last_layer"])
 def test_frozen_parameter_phases(phase):
     """The reference's agents freeze the trunk (warm-up) or everything but the last layer (XProtoNet_Base.py:253-293): frozen
