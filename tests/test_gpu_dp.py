@@ -1,0 +1,63 @@
+"""GPU, 2 ranks sharing the one card over gloo (RCCL refuses two ranks on one device; the exchange itself is backend-agnostic):
+the data-parallel training step -- each rank runs the compiled forward + backward launch lists on ITS clips, then ONE all-reduce
+of the flat gradient bucket -- leaves every rank with the mean of the ranks' gradients, i.e. the gradient of the global batch
+loss under per-rank batch statistics (the reference's plain BatchNorm, no SyncBN)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _step(model, x, seed):
+    g = torch.Generator().manual_seed(seed)
+    logits, sim, occ = model(x)
+    w = torch.randn(logits.shape, generator=g).to(x.device)
+    ((logits * w).sum() + sim.sum() + 0.1 * occ.sum()).backward()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from protoasnet_amd import dp, synth
+    from util import CFG_VIDEO_X3D, synth_model
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    model = synth_model(CFG_VIDEO_X3D).to(dev).train()
+    x = synth.echo_clips((2, 3, 4, 64, 64), seed=100 + rank).to(dev)
+    _step(model, x, seed=rank)
+    local = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+    nbytes = dp.allreduce_gradients(model.parameters())
+    torch.cuda.synchronize()
+    reduced = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+    torch.save({"local": local, "reduced": reduced, "nbytes": nbytes}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_train_step_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    names = sorted(outs[0]["local"])
+    assert names == sorted(outs[1]["local"]) and outs[0]["nbytes"] == outs[1]["nbytes"] > 0
+    for n in names:
+        mean = (outs[0]["local"][n] + outs[1]["local"][n]) / 2
+        assert not torch.equal(outs[0]["local"][n], outs[1]["local"][n]) or float(mean.abs().max()) == 0.0, n  # different clips
+        for r in range(world):
+            assert torch.allclose(outs[r]["reduced"][n], mean, rtol=1e-6, atol=1e-7 * float(mean.abs().max() + 1e-30)), (n, r)
+        assert torch.equal(outs[0]["reduced"][n], outs[1]["reduced"][n]), n  # identical on every rank: no broadcast needed
