@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Measurements for the BASELINE.json configs that are not the headline bench line (run on the GPU box).
+"""Measurements for the BASELINE.json configs that are not the headline bench line (run on the GPU box).  Lives under tests/ because
+two of its legs use the oracle as the checker / CPU reference (tolerance table of config 5, CPU rate of config 1).
 
-    python tools/configs_bench.py sweep     # config 5: X3D-M, 32x312x312 clips, 60 prototypes -- fp32 vs bf16 vs CPU oracle
-    python tools/configs_bench.py push      # config 4: push_prototypes over 10k synthetic clips, 30 prototypes, 1 GPU
-    python tools/configs_bench.py r2p1d     # reference-faithful trunk: R(2+1)D-18[:-3], 32x112x112 and 16x224x224 clips
-    python tools/configs_bench.py image     # config 1: Image ProtoASNet (XProtoNet, ResNet-18, 40 prototypes, 224^2), batch 8: CPU oracle vs HIP
-    python tools/configs_bench.py train     # config 3 at N = 1: training step of every trunk (fwd + loss + bwd + Adam), bf16
+    python tests/configs_bench.py sweep     # config 5: X3D-M, 32x312x312 clips, 60 prototypes -- fp32 vs bf16 vs CPU oracle
+    python tests/configs_bench.py push      # config 4: push_prototypes over 10k synthetic clips, 30 prototypes, 1 GPU
+    python tests/configs_bench.py r2p1d     # reference-faithful trunk: R(2+1)D-18[:-3], 32x112x112 and 16x224x224 clips
+    python tests/configs_bench.py image     # config 1: Image ProtoASNet (XProtoNet, ResNet-18, 40 prototypes, 224^2), batch 8: CPU oracle vs HIP
+    python tests/configs_bench.py train     # config 3 at N = 1: training step of every trunk (fwd + loss + bwd + Adam), bf16
 """
 import json
 import os
