@@ -18,9 +18,11 @@
 
 namespace pasn {
 
-constexpr int G_BM = 128, G_BN = 128, G_BK = 32;
+constexpr int G_BK = 32;
 
-template <typename T, bool PW>
+// BN = 128: block tile 128 positions x 128 channels, waves 2 x 2.  BN = 64: 256 positions x 64 channels, waves 4 x 1 -- for layers with
+// at most 64 output channels (half of the wide tile's MFMA work was spent on zero rows there).
+template <typename T, bool PW, int G_BN>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         const T* __restrict__ res, const float* __restrict__ gate,
@@ -30,7 +32,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
     constexpr int KSTEP = Traits<T>::KSTEP;
     constexpr int ROW = G_BK + CH;               // padded LDS row (elements)
     constexpr int PIECES = G_BK / CH;            // 16-byte pieces per tile row
-    constexpr int PPT = G_BM * PIECES / 256;     // pieces per thread per tile (2 for bf16, 4 for fp32)
+    constexpr int G_BM = G_BN == 128 ? 128 : 256;
+    constexpr int WM = G_BM / 64;                // waves along the positions
+    constexpr int PPT = G_BM * PIECES / 256;     // X pieces per thread per tile
+    constexpr int PPW = G_BN * PIECES / 256;     // W pieces per thread per tile (>= 1)
     constexpr int RSTEP = 256 / PIECES;          // tile rows between a thread's consecutive pieces
     constexpr int OROW = G_BN + CH;              // output image row (elements)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
     T* os = reinterpret_cast<T*>(smem);                      // [G_BM][OROW]  (aliases the tiles after the K loop)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;                 // wave's 64-position / 64-channel quadrant
+    const int wm = wave % WM, wn = wave / WM;                // wave's 64-position / 64-channel quadrant
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const int S = d.To * d.Ho * d.Wo;
     const long m0 = (long)blockIdx.x * G_BM;
@@ -87,9 +92,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
         f_de = r2 - f_db * d.kw;
     }
 
-    uint4 xr[PPT], wr[PPT];  // slice being stashed next
+    uint4 xr[PPT], wr[PPW];  // slice being stashed next
     bool xok[PPT];
-    uint4 xr2[PPT], wr2[PPT];  // the slice after that: TWO slices of loads are in flight under the MFMAs
+    uint4 xr2[PPT], wr2[PPW];  // the slice after that: TWO slices of loads are in flight under the MFMAs
     bool xok2[PPT];
     // ISSUE ONLY: raw, unconditional loads from clamped addresses.  The masks (image border / K tail) are applied in
     // stash(), after the MFMAs of the current slice: a select on the loaded value right here makes hipcc wait
@@ -113,7 +118,11 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
             }
             xok2[i] = ok;
             xr2[i] = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));
-            const int n = n0 + row;  // weight rows are zero padded to a multiple of 128
+            (void)row;
+        }
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int n = n0 + prow0 + i * RSTEP;  // weight rows are zero padded to a multiple of 128
             wr2[i] = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
         }
         if (!PW) {  // advance (tap, ci) by one slice
@@ -135,24 +144,20 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             xr[i] = xr2[i];
-            wr[i] = wr2[i];
             xok[i] = xok2[i];
         }
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) wr[i] = wr2[i];
     };
     auto stash = [&](int kt, int buf) {  // registers -> LDS (applying the fused input transform to X once)
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int row = prow0 + i * RSTEP;
-            uint4 xv = xr[i], wv = wr[i];
-            const bool kin = kt * G_BK + pc * CH < Ktot;
+            uint4 xv = xr[i];
             xv.x = xok[i] ? xv.x : 0u;
             xv.y = xok[i] ? xv.y : 0u;
             xv.z = xok[i] ? xv.z : 0u;
             xv.w = xok[i] ? xv.w : 0u;
-            wv.x = kin ? wv.x : 0u;
-            wv.y = kin ? wv.y : 0u;
-            wv.z = kin ? wv.z : 0u;
-            wv.w = kin ? wv.w : 0u;
             if (PW && xform) {
                 const int k = kt * G_BK + pc * CH;
                 if (rv[i] && k < Cin_p) {
@@ -168,7 +173,16 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
                 }
             }
             *reinterpret_cast<uint4*>(xs + ((size_t)buf * G_BM + row) * ROW + pc * CH) = xv;
-            *reinterpret_cast<uint4*>(ws + ((size_t)buf * G_BN + row) * ROW + pc * CH) = wv;
+        }
+        const bool kin = kt * G_BK + pc * CH < Ktot;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            uint4 wv = wr[i];
+            wv.x = kin ? wv.x : 0u;
+            wv.y = kin ? wv.y : 0u;
+            wv.z = kin ? wv.z : 0u;
+            wv.w = kin ? wv.w : 0u;
+            *reinterpret_cast<uint4*>(ws + ((size_t)buf * G_BN + prow0 + i * RSTEP) * ROW + pc * CH) = wv;
         }
     };
 
@@ -257,7 +271,7 @@ bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype) {
     if (const char* e = getenv("PASN_NO_GEMM"))
         if (e[0] == '1') return false;
     (void)dtype;
-    if (d.w_rows % G_BN != 0 || d.w_kc % 8 != 0) return false;
+    if (d.w_rows % 128 != 0 || d.w_kc % 8 != 0) return false;
     if (is_pointwise(d)) return d.Cin_p >= 64;  // below that the register-resident kernel (pwconv.hip) wins
     if (d.in_swish) return false;               // the fused input transform exists on the pointwise paths only
     return d.Cin_p * d.kt * d.kh * d.kw >= 64;  // windowed dense convs with a real K
@@ -268,24 +282,34 @@ int launch_gemm_pw(const void* x, const void* w, const float* scale, const float
                    void* y, const pasn_conv_desc& d, hipStream_t s) {
     constexpr int CH = Traits<T>::CH;
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
-    const size_t tiles = (size_t)2 * (G_BM + G_BN) * (G_BK + CH) * sizeof(T);
-    const size_t image = (size_t)G_BM * (G_BN + CH) * sizeof(T);
+    // narrow tile only when ALL the output channels fit it (Cout <= 64: 216 -> 199 us on R(2+1)D's 144 -> 64 layers).  Splitting
+    // 144 / 288 / 576 channels into 64-wide tiles instead of a half-empty last 128-wide one was measured 10-19 % SLOWER: the kernel
+    // is bound by staging the activation tile (re-read once per channel tile), not by the MFMAs spent on zero rows.
+    static const bool no_narrow = getenv("PASN_NO_GEMM_BN64") != nullptr;
+    const bool narrow = !no_narrow && d.Cout_p <= 64;
+    const int BN = narrow ? 64 : 128, BM = narrow ? 256 : 128;
+    const size_t tiles = (size_t)2 * (BM + BN) * (G_BK + CH) * sizeof(T);
+    const size_t image = (size_t)BM * (BN + CH) * sizeof(T);
     const size_t lds = tiles > image ? tiles : image;
-    const dim3 grid(ceil_div(M, G_BM), ceil_div(d.Cout_p, G_BN)), block(256);
+    const dim3 grid(ceil_div(M, BM), ceil_div(d.Cout_p, BN)), block(256);
     const bool pw = is_pointwise(d);
     if (!pw) PASN_REQUIRE(gate == nullptr, "the SE gate transform is only fused into pointwise convs");
-#define PASN_GC(PW_)                                                                                                       \
+#define PASN_GC(PW_, BN_)                                                                                                  \
     do {                                                                                                                    \
         static bool attr = false;                                                                                           \
         if (!attr && lds > 64 * 1024) {                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<T, PW_>),                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<T, PW_, BN_>),                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        hipLaunchKernelGGL((gemm_conv_kernel<T, PW_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,          \
+        hipLaunchKernelGGL((gemm_conv_kernel<T, PW_, BN_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,     \
                            (const T*)res, gate, (T*)y, d);                                                                  \
     } while (0)
-    if (pw) PASN_GC(true); else PASN_GC(false);
+    if (pw) {
+        if (narrow) PASN_GC(true, 64); else PASN_GC(true, 128);
+    } else {
+        if (narrow) PASN_GC(false, 64); else PASN_GC(false, 128);
+    }
 #undef PASN_GC
     return check_launch("gemm_conv_kernel");
 }
