@@ -57,16 +57,23 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
 
     // this thread's tile rows (fixed over the K loop): row = prow0 + i * RSTEP, piece column pc
     const int pc = tid % PIECES, prow0 = tid / PIECES;
-    // Per row: the window ORIGIN (first tap) in input coordinates and as a flat position; per K slice only the tap offset
-    // is added.  (The first version redid the whole (n,t,h,w) x tap decode -- integer divisions and a 64-bit offset
-    // chain, ~200 VALU instructions -- for every 32-wide slice, against 256 cycles of MFMA.)
-    long rm[PPT], rbase[PPT];
-    int rt0[PPT], rh0[PPT], rw0[PPT];
+    // Per row, ONCE: the window origin as an element offset (x CHANNEL stride) and a bit mask of the taps that fall inside the image.
+    // Per K slice only a slice-uniform (tap, ci) offset is added and one mask bit is tested.  (PMC on the first version, R(2+1)D's
+    // 64 -> 144 (1,3,3) layer: 139 VALU instructions per slice and wave next to 8 MFMAs -- VALU 60 % busy, matrix pipe 26 %: the
+    // per-slice bounds compares, 64-bit offset chains, register-stage moves and masks were the kernel.)
+    long rm[PPT], robase[PPT];
+    unsigned tapmask[PPT];
     bool rv[PPT];
+    const int taps_ = d.kt * d.kh * d.kw;
+    const bool small_window = taps_ <= 32;  // the 32-bit tap mask covers every window of the trunks (27 taps at most)
+    int rt0[PPT], rh0[PPT], rw0[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         rm[i] = m0 + prow0 + i * RSTEP;
         rv[i] = rm[i] < M;
+        robase[i] = 0;
+        tapmask[i] = 0;
+        rt0[i] = rh0[i] = rw0[i] = 0;
         if (!PW) {
             const long mm = rv[i] ? rm[i] : 0;
             const int rw = (int)(mm % d.Wo);
@@ -78,7 +85,16 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
             rt0[i] = rt * d.st - d.pt;
             rh0[i] = rh * d.sh - d.ph;
             rw0[i] = rw * d.sw - d.pw;
-            rbase[i] = (((long)rn * d.Ti + rt0[i]) * d.Hi + rh0[i]) * d.Wi + rw0[i];
+            robase[i] = ((((long)rn * d.Ti + rt0[i]) * d.Hi + rh0[i]) * d.Wi + rw0[i]) * Cin_p;
+            if (small_window && rv[i]) {
+                int tp = 0;
+                for (int a = 0; a < d.kt; ++a)
+                    for (int b2 = 0; b2 < d.kh; ++b2)
+                        for (int e = 0; e < d.kw; ++e, ++tp)
+                            if ((unsigned)(rt0[i] + a) < (unsigned)d.Ti && (unsigned)(rh0[i] + b2) < (unsigned)d.Hi &&
+                                (unsigned)(rw0[i] + e) < (unsigned)d.Wi)
+                                tapmask[i] |= 1u << tp;
+            }
         }
     }
     // this thread's piece of slice kt is k = kt * G_BK + pc * CH = tap * kc + ci: decoded once, then advanced per slice
@@ -92,38 +108,38 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
         f_de = r2 - f_db * d.kw;
     }
 
-    uint4 xr[PPT], wr[PPW];  // slice being stashed next
-    bool xok[PPT];
-    uint4 xr2[PPT], wr2[PPW];  // the slice after that: TWO slices of loads are in flight under the MFMAs
-    bool xok2[PPT];
+    // Two register stages: B = the slice just requested, A = the one stashed next (moved B -> A once per slice; unrolling the K loop
+    // x2 to make the stages compile-time names doubled the accumulator registers -- the MFMA loop must stay ONE basic block).
+    uint4 xrA[PPT], wrA[PPW], xrB[PPT], wrB[PPW];
+    unsigned okA = 0, okB = 0;  // bit i: row i of the stage is inside the image / the K range
     // ISSUE ONLY: raw, unconditional loads from clamped addresses.  The masks (image border / K tail) are applied in
     // stash(), after the MFMAs of the current slice: a select on the loaded value right here makes hipcc wait
     // (vmcnt(0)) for the prefetch BEFORE the MFMAs it was meant to hide under.
-    auto fetch = [&](int kt) {  // global -> registers for K slice kt; called with kt = 0, 1, 2, ... in order
+    auto fetch = [&](int kt, uint4 (&xr)[PPT], uint4 (&wr)[PPW], unsigned& okbits) {  // called with kt = 0, 1, 2, ... in order
         const int k = kt * G_BK + pc * CH;  // flattened K index of this thread's piece
         const int ci = PW ? k : f_ci;
         const bool kvalid = (PW ? k < Ktot : f_tap < taps) && ci < Cin_p;
-        const long tapoff = PW ? 0 : ((long)f_da * d.Hi + f_db) * d.Wi + f_de;
+        const int tapoff = PW ? ci : (((f_da * d.Hi) + f_db) * d.Wi + f_de) * Cin_p + ci;  // slice-uniform per thread
+        okbits = 0;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const int row = prow0 + i * RSTEP;
             bool ok = rv[i] && kvalid;
             long off;
             if (PW) {
-                off = rm[i] * Cin_p + ci;
+                off = rm[i] * Cin_p + tapoff;
             } else {
-                ok = ok && (unsigned)(rt0[i] + f_da) < (unsigned)d.Ti && (unsigned)(rh0[i] + f_db) < (unsigned)d.Hi &&
-                     (unsigned)(rw0[i] + f_de) < (unsigned)d.Wi;
-                off = (rbase[i] + tapoff) * Cin_p + ci;
+                if (small_window) ok = ok && ((tapmask[i] >> (f_tap & 31)) & 1u);
+                else ok = ok && (unsigned)(rt0[i] + f_da) < (unsigned)d.Ti && (unsigned)(rh0[i] + f_db) < (unsigned)d.Hi &&
+                          (unsigned)(rw0[i] + f_de) < (unsigned)d.Wi;
+                off = robase[i] + tapoff;
             }
-            xok2[i] = ok;
-            xr2[i] = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));
-            (void)row;
+            okbits |= (ok ? 1u : 0u) << i;
+            xr[i] = *reinterpret_cast<const uint4*>(x + (ok ? off : 0));
         }
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int n = n0 + prow0 + i * RSTEP;  // weight rows are zero padded to a multiple of 128
-            wr2[i] = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
+            wr[i] = *reinterpret_cast<const uint4*>(w + (long)n * Ktot + (k < Ktot ? k : 0));
         }
         if (!PW) {  // advance (tap, ci) by one slice
             f_ci += G_BK;
@@ -140,24 +156,16 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
             }
         }
     };
-    auto shift = [&]() {  // stage 2 -> stage 1 (register moves; the loads keep flying)
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            xr[i] = xr2[i];
-            xok[i] = xok2[i];
-        }
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) wr[i] = wr2[i];
-    };
-    auto stash = [&](int kt, int buf) {  // registers -> LDS (applying the fused input transform to X once)
+    auto stash = [&](int kt, int buf, const uint4 (&xr)[PPT], const uint4 (&wr)[PPW], unsigned okbits) {  // registers -> LDS
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int row = prow0 + i * RSTEP;
             uint4 xv = xr[i];
-            xv.x = xok[i] ? xv.x : 0u;
-            xv.y = xok[i] ? xv.y : 0u;
-            xv.z = xok[i] ? xv.z : 0u;
-            xv.w = xok[i] ? xv.w : 0u;
+            const bool ok = (okbits >> i) & 1u;
+            xv.x = ok ? xv.x : 0u;
+            xv.y = ok ? xv.y : 0u;
+            xv.z = ok ? xv.z : 0u;
+            xv.w = ok ? xv.w : 0u;
             if (PW && xform) {
                 const int k = kt * G_BK + pc * CH;
                 if (rv[i] && k < Cin_p) {
@@ -174,14 +182,16 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
             }
             *reinterpret_cast<uint4*>(xs + ((size_t)buf * G_BM + row) * ROW + pc * CH) = xv;
         }
-        const bool kin = kt * G_BK + pc * CH < Ktot;
+        const bool kin = kt * G_BK + pc * CH < Ktot;  // only the last slice can run past the K extent
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             uint4 wv = wr[i];
-            wv.x = kin ? wv.x : 0u;
-            wv.y = kin ? wv.y : 0u;
-            wv.z = kin ? wv.z : 0u;
-            wv.w = kin ? wv.w : 0u;
+            if (kt == nk - 1) {
+                wv.x = kin ? wv.x : 0u;
+                wv.y = kin ? wv.y : 0u;
+                wv.z = kin ? wv.z : 0u;
+                wv.w = kin ? wv.w : 0u;
+            }
             *reinterpret_cast<uint4*>(ws + ((size_t)buf * G_BN + prow0 + i * RSTEP) * ROW + pc * CH) = wv;
         }
     };
@@ -194,15 +204,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
-    fetch(0);
-    shift();
-    if (nk > 1) fetch(1);
-    stash(0, 0);  // waits for slice 0 only (slice 1 was issued after it)
-    shift();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 2 < nk) fetch(kt + 2);  // slices kt+1 (stage 1) and kt+2 (stage 2) are in flight under the MFMAs below
+    auto mma_slice = [&](int buf) {
         const T* xb = xs + ((size_t)buf * G_BM + wm * 64 + c) * ROW + h * CH;
         const T* wb = ws + ((size_t)buf * G_BN + wn * 64 + c) * ROW + h * CH;
 #pragma unroll
@@ -218,7 +220,26 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const T* __restrict__ x,
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma32(acc[i][j], a[i], b[j]);
         }
-        if (kt + 1 < nk) stash(kt + 1, buf ^ 1);  // the other buffer was last read in iteration kt-1 (barrier below)
+    };
+
+    auto shift = [&]() {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) xrA[i] = xrB[i];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) wrA[i] = wrB[i];
+        okA = okB;
+    };
+    fetch(0, xrB, wrB, okB);
+    shift();
+    if (nk > 1) fetch(1, xrB, wrB, okB);
+    stash(0, 0, xrA, wrA, okA);  // waits for slice 0 only (slice 1 was issued after it)
+    shift();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 2 < nk) fetch(kt + 2, xrB, wrB, okB);  // slices kt+1 (stage A) and kt+2 (stage B) are in flight under the MFMAs
+        mma_slice(buf);
+        if (kt + 1 < nk) stash(kt + 1, buf ^ 1, xrA, wrA, okA);  // the other buffer was last read in iteration kt-1 (barrier below)
         shift();
         __syncthreads();
     }

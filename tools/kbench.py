@@ -4,6 +4,7 @@
     python tools/kbench.py pw 24 54 16 112 112          # pointwise conv  Cin Cout T H W   (N = 32, bf16)
     python tools/kbench.py pwres 54 24 16 56 56         # ... with residual
     python tools/kbench.py dw 54 1 16 56 56             # depthwise 3x3x3  C stride T H W
+    python tools/kbench.py c133 64 144 32 56 56 8       # dense (1,3,3) conv Cin Cout T H W [N]  (c311: (3,1,1)) -- R(2+1)D layers
 """
 import sys
 import os
@@ -33,6 +34,11 @@ def run(kind, a, b, T, H, W, N=32, dtype=torch.bfloat16, reps=20):
             res_t = torch.randn(N, T, H, W, round_up(b, 8), device=DEV).to(dtype)
             ra = Act(N, T, H, W, b, round_up(b, 8), pb._new_buf(res_t.numel() * es, external=True))
         y = pb.conv(xa, conv, bn, "relu", residual=ra)
+    elif kind in ("c133", "c311"):
+        k, p = ((1, 3, 3), (0, 1, 1)) if kind == "c133" else ((3, 1, 1), (1, 0, 0))
+        conv = nn.Conv3d(cin, b, k, 1, p, bias=False).to(DEV)
+        y = pb.conv(xa, conv, nn.BatchNorm3d(b).to(DEV).eval(), "relu")
+        ra = None
     elif kind.startswith("xd"):  # fused expand+dw: a = Cin, b = inner channels, stride from the name (xd1 / xd2)
         s = int(kind[2])
         ca = nn.Conv3d(cin, b, 1, bias=False).to(DEV)
@@ -65,4 +71,4 @@ def run(kind, a, b, T, H, W, N=32, dtype=torch.bfloat16, reps=20):
 if __name__ == "__main__":
     kind = sys.argv[1]
     a, b, T, H, W = (int(v) for v in sys.argv[2:7])
-    run(kind, a, b, T, H, W)
+    run(kind, a, b, T, H, W, N=int(sys.argv[7]) if len(sys.argv) > 7 else 32)
