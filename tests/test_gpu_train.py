@@ -449,7 +449,8 @@ def test_reference_trunks_train_step_fp32_vs_oracle_autograd(cfg, shape, spatial
             _rel(sd1[k_], v, 1e-4, k_)
 
 
-@pytest.mark.parametrize("cfg", [CFG_PPNET, CFG_PPNET_BOTTLENECK], ids=["regular", "bottleneck"])
+@pytest.mark.parametrize("cfg", [CFG_PPNET, CFG_PPNET_BOTTLENECK, dict(CFG_PPNET, prototype_activation_function="linear")],
+                         ids=["regular", "bottleneck", "linear_activation"])
 def test_ppnet_train_step_fp32_vs_oracle_autograd(cfg):
     """ProtoPNet (head A: distance map, min pooling, log activation, last layer; Sigmoid add-on) in train mode: logits,
     min_distances and every parameter gradient, with gradients entering through both outputs (cross entropy acts on the logits,
@@ -464,7 +465,7 @@ def test_ppnet_train_step_fp32_vs_oracle_autograd(cfg):
     assert logits.requires_grad and min_d.requires_grad
     ((logits * wl.to(DEV)).sum() + (min_d * wm.to(DEV)).sum()).backward()
     sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
-    ref = oracle.nets.ppnet_train_forward(sd, x, arch="resnet18")
+    ref = oracle.nets.ppnet_train_forward(sd, x, arch="resnet18", activation=cfg["prototype_activation_function"])
     ((ref["logits"] * wl).sum() + (ref["min_distances"] * wm).sum()).backward()
     _rel(logits, ref["logits"], 1e-3, "logits")
     _rel(min_d, ref["min_distances"], 1e-3, "min_distances")
