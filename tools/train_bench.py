@@ -138,6 +138,7 @@ def main(argv=None):
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (one flat fp32 gradient bucket all-reduced per step)"},
             "launches": {"forward": plan.n_fwd, "backward": len(plan.ops) - plan.n_fwd}, "arena_bytes": plan.arena_bytes,
             "naive_bytes": plan.naive_bytes, "grad_bucket_bytes": plan.gsize * 4, "loss": round(float(loss.detach()), 5),
+            "max_memory_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
         }))
     if world > 1:
         dist.destroy_process_group()
