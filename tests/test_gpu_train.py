@@ -604,3 +604,42 @@ def test_transform_loss_value_and_gradients_vs_oracle():
     head_only = {n for n, _ in m.named_parameters() if n.startswith("add_on_layers") or n in ("prototype_vectors", "last_layer.weight")}
     # |a - b| has its own kink at a == b; the maps differ everywhere here, so the strict bound holds
     _check_grads(m, sd, 2e-3, skip=head_only)
+
+
+# ------------------------------------------------------------------------------------------------- vs the REFERENCE's own train mode
+@pytest.mark.parametrize("tag,cfg", [("xproto", CFG_XPROTO), ("ppnet", CFG_PPNET)])
+def test_train_step_vs_reference_train_mode_golden(golden, tag, cfg):
+    """HIP training pass vs outputs / gradient summaries / running statistics recorded from the reference itself in train mode
+    (tests/golden/g7_train_resnet18.npz, made by tests/golden/make_golden_train.py)."""
+    import numpy as np
+
+    from train_cases import FULL_GRADS, SHAPE as GSHAPE, kink_sparse_, loss_weights
+
+    g = golden("g7_train_resnet18.npz")
+    m = kink_sparse_(synth_model(dict(cfg, img_size=GSHAPE[-1]))).to(DEV).train()
+    x = synth.echo_clips(GSHAPE).to(DEV)
+    if tag == "xproto":
+        logits, sim, occ = m(x)
+        wl, ws, wo = (t.to(DEV) for t in loss_weights(GSHAPE[0], 40, 4, tuple(occ.shape[3:])))
+        outs = {"logits": logits, "similarity": sim, "occurrence_map": occ}
+        loss = (logits * wl).sum() + (sim * ws).sum() + (occ * wo).sum()
+    else:
+        logits, min_d = m(x)
+        wl, wm, _ = (t.to(DEV) for t in loss_weights(GSHAPE[0], 30, 3, (1, 1)))
+        outs = {"logits": logits, "min_distances": min_d}
+        loss = (logits * wl).sum() + (min_d * wm).sum()
+    loss.backward()
+    for name, t in outs.items():
+        _rel(t, g[f"{tag}_{name}"], 1e-3, name)
+    params = dict(m.named_parameters())
+    for n, (gmax, gsum, gsq) in zip(g[f"{tag}_grad_names"], g[f"{tag}_grad_stats"]):
+        gr = params[str(n)].grad.double()
+        assert abs(float(gr.abs().max()) - gmax) <= 2e-3 * gmax + 1e-12, (str(n), float(gr.abs().max()), gmax)
+        assert abs(float((gr * gr).sum()) - gsq) <= 4e-3 * gsq + 1e-20, (str(n), "sum of squares")
+    for n in FULL_GRADS:
+        if f"{tag}_grad::{n}" in g.files:
+            _rel(params[n].grad, g[f"{tag}_grad::{n}"], 1e-3, f"grad of {n}")
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith(f"{tag}_buf::"):
+            _rel(sd[key.split("::", 1)[1]], g[key], 1e-4, key)

@@ -102,3 +102,70 @@ def test_trunk_shapes_and_unpinned_trunks_run():
     assert tuple(y.shape) == (1, 192, 4, 2, 2) == (1,) + oracle.backbones.trunk_out_shape("x3d_s", (3, 4, 64, 64))
     assert oracle.backbones.trunk_out_shape("x3d_s", (3, 16, 224, 224)) == (192, 16, 7, 7)
     assert [oracle.backbones.x3d_round_width(int(2.25 * w), 0.0625) for w in (24, 48, 96, 192)] == [8, 8, 16, 32]
+
+
+# ---- train mode: the oracle's batch-statistics passes + autograd vs the REFERENCE run in train mode (tests/golden/make_golden_train.py)
+def _train_sd(cfg):
+    import torch
+
+    from protoasnet_amd import model_builder, synth
+    from train_cases import kink_sparse_
+
+    m = model_builder.build(cfg)
+    synth.load_synth(m)
+    kink_sparse_(m)
+    return {k: (v.detach().clone().requires_grad_() if v.is_floating_point() and "running" not in k and k != "ones" else v.detach().clone())
+            for k, v in m.state_dict().items()}  # `ones` is a requires_grad=False Parameter in the reference (ProtoPNet.py:136)
+
+
+def _check_train_golden(g, tag, sd, outputs, loss):
+    import numpy as np
+    import torch
+
+    from train_cases import FULL_GRADS
+
+    loss.backward()
+    for name, t in outputs.items():
+        ref = g[f"{tag}_{name}"]
+        assert np.allclose(t.detach().numpy(), ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max())), name
+    names, stats = list(g[f"{tag}_grad_names"]), g[f"{tag}_grad_stats"]
+    assert sorted(names) == sorted(n for n, v in sd.items() if getattr(v, "grad", None) is not None)
+    for n, (gmax, gsum, gsq) in zip(names, stats):
+        gr = sd[str(n)].grad.double()
+        assert abs(float(gr.abs().max()) - gmax) <= 1e-3 * gmax + 1e-12, (n, float(gr.abs().max()), gmax)
+        assert abs(float((gr * gr).sum()) - gsq) <= 2e-3 * gsq + 1e-20, (n, "sum of squares")
+    for n in FULL_GRADS:
+        key = f"{tag}_grad::{n}"
+        if key in g:
+            ref = g[key]
+            assert np.allclose(sd[n].grad.numpy(), ref, rtol=0, atol=1e-4 * float(np.abs(ref).max())), n
+    for key in g.files:
+        if key.startswith(f"{tag}_buf::"):
+            n = key.split("::", 1)[1]
+            assert np.allclose(sd[n].numpy(), g[key], rtol=1e-5, atol=1e-6), n  # running estimates moved exactly like the reference's
+
+
+def test_oracle_train_mode_xprotonet_vs_reference_golden(golden):
+    from train_cases import SHAPE, loss_weights
+    from util import CFG_XPROTO
+
+    g = golden("g7_train_resnet18.npz")
+    sd = _train_sd(dict(CFG_XPROTO, img_size=SHAPE[-1]))
+    x = synth.echo_clips(SHAPE)
+    out = oracle.nets.xprotonet_train_forward(sd, x, arch="resnet18")
+    wl, ws, wo = loss_weights(SHAPE[0], 40, 4, tuple(out["occurrence_map"].shape[3:]))
+    loss = (out["logits"] * wl).sum() + (out["similarity"] * ws).sum() + (out["occurrence_map"] * wo).sum()
+    _check_train_golden(g, "xproto", sd, {"logits": out["logits"], "similarity": out["similarity"], "occurrence_map": out["occurrence_map"]}, loss)
+
+
+def test_oracle_train_mode_ppnet_vs_reference_golden(golden):
+    from train_cases import SHAPE, loss_weights
+    from util import CFG_PPNET
+
+    g = golden("g7_train_resnet18.npz")
+    sd = _train_sd(dict(CFG_PPNET, img_size=SHAPE[-1]))
+    x = synth.echo_clips(SHAPE)
+    out = oracle.nets.ppnet_train_forward(sd, x, arch="resnet18")
+    wl, wm, _ = loss_weights(SHAPE[0], 30, 3, (1, 1))
+    loss = (out["logits"] * wl).sum() + (out["min_distances"] * wm).sum()
+    _check_train_golden(g, "ppnet", sd, {"logits": out["logits"], "min_distances": out["min_distances"]}, loss)
