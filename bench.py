@@ -2,6 +2,7 @@
 """Headline benchmark: clips/sec forward of Video ProtoASNet on synthetic echo batches (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          # no launcher: this process starts N fresh rank processes itself (see spawn_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one eval-mode forward (logits, similarity, occurrence_map) of the whole model -- trunk + prototype layer --
@@ -17,6 +18,8 @@ The JSON line also carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +30,61 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling there is ~6300 GB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def spawn_ranks(gpus: int, script: str, argv) -> None:
+    """Make ``--gpus N`` self-contained and honest.
+
+    Under a launcher (WORLD_SIZE set) the world size must equal --gpus, otherwise the run is refused.  Without a launcher
+    and N > 1, THIS process -- which has not touched the GPU (importing torch and counting devices do not) -- starts
+    ``python -m torch.distributed.run`` with N fresh rank processes as a child, lets rank 0's JSON line through on stdout and
+    exits with the child's return code (non-zero if any rank failed).  Never an exec after GPU initialisation."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit(f"--gpus {gpus} but the launcher set WORLD_SIZE={ws}; start exactly one rank per requested GPU")
+        return
+    if gpus <= 1:
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def init_ranks(args_gpus: int):
+    """(world, rank, device, backend) of this rank; joins the process group when world > 1 and proves it with a collective."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args_gpus, f"world size {world} != --gpus {args_gpus}"
+    backend = os.environ.get("PASN_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) are visible (RCCL needs one device per rank; "
+                         "PASN_BENCH_BACKEND=gloo rehearses several ranks on one card)")
+    dev = torch.device("cuda", local_rank % max(ndev, 1)) if ndev else torch.device("cpu")
+    if ndev:
+        torch.cuda.set_device(dev)
+    ranks_seen = 1
+    if world > 1:
+        import torch.distributed as dist
+
+        # RCCL ("nccl") over xGMI on a real node.  PASN_BENCH_BACKEND=gloo rehearses the N > 1 code path with several
+        # ranks on ONE GPU (RCCL refuses two ranks on the same device); the forward data path has no collective either way.
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        ones = torch.ones(1, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)  # every rank contributes 1: the sum is the number of ranks that really joined
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"all-reduce saw {ranks_seen} ranks, expected {world}"
+    return world, rank, dev, backend, ranks_seen
 
 
 def parse():
@@ -49,11 +107,16 @@ def parse():
                     help="forward = the BASELINE.json headline metric (default); train = config 3's training step (tools/train_bench.py)")
     ap.add_argument("--train-loss", default="reference", choices=["reference", "simple"], help="--mode train: the reference's loss recipe "
                     "(incl. TransformLoss's second trunk pass) or a single-pass loss")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal for the CPU test suite: ranks, process group, "
+                    "barriers, MAX-over-ranks timing and the JSON line, with NO device work (the metric says so)")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if args.dry_run:
+        return dry_run(args)
     if args.mode == "train":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import train_bench
@@ -62,24 +125,9 @@ def main():
                                  "--frames", str(args.frames), "--size", str(args.size), "--arch", args.arch, "--dtype", args.dtype,
                                  "--loss", args.train_loss]
                                 + (["--per-op", args.per_op] if args.per_op else []))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ndev = max(torch.cuda.device_count(), 1)
-    dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU under the driver; the modulo only serves rehearsals
-    torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-
-        # RCCL ("nccl") over xGMI on a real node.  PASN_BENCH_BACKEND=gloo rehearses the N > 1 code path with several
-        # ranks on ONE GPU (RCCL refuses two ranks on the same device); the data path has no collective either way.
-        backend = os.environ.get("PASN_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    world, rank, dev, backend, ranks_seen = init_ranks(args.gpus)
+    if dev.type != "cuda":
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback (use --dry-run to rehearse the launcher)")
 
     from protoasnet_amd import model_builder, synth
 
@@ -162,7 +210,8 @@ def main():
     clips = args.batch * world * args.steps
     value = clips / elapsed
     result = {
-        "metric": "clips/sec forward", "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+        "metric": "clips/sec forward", "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "ranks_seen": ranks_seen,
+        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"Video ProtoASNet forward, {args.arch} trunk + prototype layer (P={args.prototypes}, D=256, "
@@ -235,6 +284,37 @@ def main():
     print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def dry_run(args):
+    """Launcher rehearsal (CPU test suite): everything around the step -- ranks, process group, barrier + MAX timing, JSON -- and
+    a step that does no device work.  Its line cannot be mistaken for a measurement: metric and data say "dry-run"."""
+    os.environ.setdefault("PASN_BENCH_BACKEND", "gloo")
+    world, rank, dev, backend, ranks_seen = init_ranks(args.gpus)
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher rehearsal, no device work)", "value": 0.0, "unit": "clips/s", "n_gpus": world,
+                          "ranks_seen": ranks_seen, "collective_backend": backend if world > 1 else None, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "dry-run",
+                          "config": {"workload": "none", "global_batch": args.batch * world}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

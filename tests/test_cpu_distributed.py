@@ -103,3 +103,41 @@ def test_gradient_bucket_allreduce_world2(tmp_path):
         assert o["grads"][3] is None and o["nbytes"] == sum(t.numel() for t in mean) * 4
         for got, ref in zip(o["grads"][:3], mean):
             assert torch.allclose(got, ref, atol=1e-6)
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes itself and the line says n_gpus 2
+    (round 1 silently ran one rank); the collective really saw both ranks.  --dry-run: no device work in this container."""
+    r, line = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["collective_backend"] == "gloo"
+    assert line["data"] == "dry-run" and line["metric"].startswith("dry-run")  # cannot be mistaken for a measurement
+
+
+@pytest.mark.timeout(120)
+def test_bench_refuses_world_size_mismatch():
+    r, line = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "4", "RANK": "0"})
+    assert r.returncode != 0 and line is None and "WORLD_SIZE=4" in r.stderr
+
+
+@pytest.mark.timeout(120)
+def test_bench_needs_the_gpu_and_says_so():
+    """No silent CPU fallback: without a GPU the real benchmark refuses to run."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r, line = _run_bench(["--steps", "1", "--warmup", "1"])
+    assert r.returncode != 0 and line is None

@@ -61,3 +61,23 @@ def test_data_parallel_train_step_world2(tmp_path):
         for r in range(world):
             assert torch.allclose(outs[r]["reduced"][n], mean, rtol=1e-6, atol=1e-7 * float(mean.abs().max() + 1e-30)), (n, r)
         assert torch.equal(outs[0]["reduced"][n], outs[1]["reduced"][n]), n  # identical on every rank: no broadcast needed
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_gpus2_real_forward_two_ranks_one_card():
+    """bench.py --gpus 2 without a launcher on the GPU box: two fresh rank processes (gloo between them: RCCL refuses two ranks
+    on one card), each running the real HIP forward on a small shape; the line reports both ranks."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PASN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--frames", "4", "--size", "64", "--cpu-clips", "0"], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["config"]["global_batch"] == 4
+    assert line["metric"] == "clips/sec forward" and line["value"] > 0

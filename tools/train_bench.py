@@ -36,13 +36,14 @@ def main(argv=None):
     ap.add_argument("--per-op", default="", help="write per-launch device times of one step to this file")
     ap.add_argument("--loss", default="reference", choices=["reference", "simple"])
     args = ap.parse_args(argv)
-    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(dev)
+    import bench  # repo root: the rank launcher / process-group set-up shared with the forward benchmark
+
+    if argv is None:  # stand-alone: --gpus N > 1 without a launcher starts its own ranks (bench.py does this for --mode train)
+        bench.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    world, rank, dev, backend, ranks_seen = bench.init_ranks(args.gpus)
+    if dev.type != "cuda":
+        raise SystemExit("train_bench.py needs a GPU: the HIP path has no CPU fallback")
     import torch.distributed as dist
-    if world > 1:
-        backend = os.environ.get("PASN_BENCH_BACKEND", "nccl")
-        dist.init_process_group("nccl", device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
 
     from protoasnet_amd import dp, model_builder, synth
 
@@ -130,7 +131,8 @@ def main(argv=None):
         plan = runner.plan
         print(json.dumps({
             "metric": "clips/sec train step", "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "n_gpus": world, "ranks_seen": ranks_seen, "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Video ProtoASNet train step (fwd + {'reference loss recipe incl. TransformLoss second pass' if args.loss == 'reference' else 'simple loss'}"
                                    f" + bwd + grad all-reduce + Adam), {args.arch} + head B, "
