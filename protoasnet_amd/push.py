@@ -76,18 +76,41 @@ def merge_ppnet(states: Sequence[Sequence[torch.Tensor]]):
     return dist, index, vec
 
 
+def _require_group(world_size: int) -> None:
+    """A sharded push (``world_size > 1``) needs the process group it will merge over; pushing from one shard only, silently,
+    would project the prototypes onto a fraction of the data."""
+    import torch.distributed as dist
+
+    if world_size <= 1:
+        return
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError(f"push with world_size={world_size} needs torch.distributed to be initialised (one process per GPU)")
+    if dist.get_world_size() != world_size:
+        raise RuntimeError(f"push: world_size={world_size} but the process group has {dist.get_world_size()} ranks")
+
+
 def _all_gather_states(state: PushState, merge):
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return state.tensors()
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("_all_gather_states needs an initialised process group")
     world = dist.get_world_size()
+    if world == 1:
+        return state.tensors()
     gathered = []
     for t in state.tensors():
+        t = _for_collective(t.contiguous())
         buf = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(buf, t.contiguous())
-        gathered.append(buf)
+        dist.all_gather(buf, t)
+        gathered.append([b.to(state.dist.device) for b in buf])
     return merge([(gathered[0][r], gathered[1][r], gathered[2][r]) for r in range(world)])
+
+
+def _for_collective(t: torch.Tensor) -> torch.Tensor:
+    """RCCL takes device tensors; the gloo rehearsal backend (several ranks on one card, CPU tests) takes host tensors."""
+    import torch.distributed as dist
+
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
 
 
 def shard_batches(num_batches: int, rank: int, world_size: int) -> range:
@@ -97,13 +120,31 @@ def shard_batches(num_batches: int, rank: int, world_size: int) -> range:
 
 
 def _iter_shard(dataloader, rank: int, world_size: int):
+    """Yields ``(batch index, global index of the batch's first clip, sample)`` for this rank's contiguous batch range.
+
+    A ``torch.utils.data.DataLoader`` is re-instantiated over the rank's slice of its ``batch_sampler`` (same dataset,
+    collate function and workers), so foreign batches are never loaded and the clip offsets come from a prefix sum of the
+    sampler's batch lengths.  Any other iterable of samples is walked from the start: batches before the range are consumed
+    to count their clips (the only way to know the offset of a ragged loader), batches after it are not touched."""
     n = len(dataloader)
     mine = shard_batches(n, rank, world_size)
+    if isinstance(dataloader, torch.utils.data.DataLoader) and dataloader.batch_sampler is not None:
+        index_lists = [list(b) for b in dataloader.batch_sampler]
+        offsets = np.concatenate([[0], np.cumsum([len(b) for b in index_lists])])
+        sub = torch.utils.data.DataLoader(dataloader.dataset, batch_sampler=index_lists[mine.start:mine.stop],
+                                          num_workers=dataloader.num_workers, collate_fn=dataloader.collate_fn,
+                                          pin_memory=dataloader.pin_memory)
+        for k, sample in enumerate(sub):
+            yield mine.start + k, int(offsets[mine.start + k]), sample
+        return
+    batch_size = getattr(dataloader, "batch_size", None)
+    seen = 0
     for i, sample in enumerate(dataloader):
         if i >= mine.stop:
             break
         if i >= mine.start:
-            yield i, sample
+            yield i, (i * batch_size if batch_size else seen), sample
+        seen += int(sample["cine"].shape[0])
 
 
 def _finish(model, state_tensors, prototype_shape, replace_prototypes: bool, log, start: float) -> Dict[str, torch.Tensor]:
@@ -125,6 +166,7 @@ def push_prototypes(dataloader, model, class_specific=True, abstain_class=True, 
                     prototype_self_act_filename_prefix=None, proto_bound_boxes_filename_prefix=None, replace_prototypes=True,
                     rank: int = 0, world_size: int = 1):
     """Reference signature of ``push_abs_revision.push_prototypes``; returns the winners as device tensors."""
+    _require_group(world_size)
     model.eval()
     log(f"############## push at epoch {epoch_number} #################")
     start = time.time()
@@ -134,14 +176,9 @@ def push_prototypes(dataloader, model, class_specific=True, abstain_class=True, 
     mask = xproto_class_mask(P, model.num_classes, class_specific, abstain_class).to(device)
     state = PushState(P, D, device)
     lib = _lib.lib()
-    batch_size = getattr(dataloader, "batch_size", None)
-    seen = 0
     save = root_dir_for_saving_prototypes is not None
-    if save and world_size > 1:
-        raise NotImplementedError("prototype artefacts (prototypes_info.pickle) are written by a single-process push; "
-                                  "run the sharded sweep without root_dir_for_saving_prototypes")
     rec, names, ar = None, {}, torch.arange(P, device=device)
-    for i, sample in _iter_shard(dataloader, rank, world_size):
+    for i, base, sample in _iter_shard(dataloader, rank, world_size):
         x = sample["cine"]
         if preprocess_input_function is not None:
             x = preprocess_input_function(x)
@@ -150,7 +187,6 @@ def push_prototypes(dataloader, model, class_specific=True, abstain_class=True, 
         with torch.no_grad():
             feats, proto_dist, occ, logits = model.push_forward(xdev)
         B = int(x.shape[0])
-        base = i * batch_size if batch_size else seen
         feats, proto_dist = feats.contiguous(), proto_dist.contiguous()
         _lib.check(lib.pasn_push_xproto_update(
             proto_dist.data_ptr(), feats.data_ptr(), labels.data_ptr(), proto_class.data_ptr(), mask.data_ptr(),
@@ -165,11 +201,42 @@ def push_prototypes(dataloader, model, class_specific=True, abstain_class=True, 
             if rec is None:
                 rec = [torch.zeros_like(t) for t in new]
             rec = [torch.where(here.view((P,) + (1,) * (t.dim() - 1)), t, r) for t, r in zip(new, rec)]
-        seen += B
+    local_index = state.index.clone()
     merged = _all_gather_states(state, merge_xproto) if world_size > 1 else state.tensors()
-    if save and rec is not None:
-        _save_xproto_artefacts(root_dir_for_saving_prototypes, epoch_number, merged, rec, names, log)
+    if save:
+        if world_size > 1:
+            rec, names = _reduce_records(rec, names, local_index, merged[1], device)
+        if rank == 0 and rec is not None:
+            _save_xproto_artefacts(root_dir_for_saving_prototypes, epoch_number, merged, rec, names, log)
     return _finish(model, merged, model.prototype_shape, replace_prototypes, log, start)
+
+
+def _reduce_records(rec, names, local_index, merged_index, device):
+    """Sharded push: the records of a prototype live on the rank whose shard holds its final winner.  Every rank zeroes the
+    records it does not own, ONE sum-reduce per record tensor brings them to rank 0 (exact: all other addends are zeros), the
+    file names travel as objects.  Shapes are agreed on first (a rank with an empty shard has no records yet)."""
+    import torch.distributed as dist
+
+    shapes = [None] * dist.get_world_size()
+    dist.all_gather_object(shapes, None if rec is None else [(tuple(t.shape), str(t.dtype)) for t in rec])
+    proto = next((sh for sh in shapes if sh is not None), None)
+    if proto is None:
+        return None, names
+    if rec is None:
+        rec = [torch.zeros(sh, dtype=getattr(torch, dt.split(".")[1]), device=device) for sh, dt in proto]
+    own = (local_index >= 0) & (local_index == merged_index)
+    out = []
+    for t in rec:
+        t = torch.where(own.view((-1,) + (1,) * (t.dim() - 1)), t, torch.zeros_like(t))
+        t = _for_collective(t.contiguous())
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        out.append(t.to(device))
+    all_names = [None] * dist.get_world_size()
+    dist.all_gather_object(all_names, names)
+    merged_names = {}
+    for d in all_names:
+        merged_names.update(d)
+    return out, merged_names
 
 
 def _save_xproto_artefacts(root: str, epoch_number, merged, rec, names, log) -> str:
@@ -178,8 +245,6 @@ def _save_xproto_artefacts(root: str, epoch_number, merged, rec, names, log) -> 
     (plots, GIFs) is not part of this package."""
     import os
     import pickle
-
-    import numpy as np
 
     proto_epoch_dir = os.path.join(root, "epoch-" + str(epoch_number)) if epoch_number is not None else root
     os.makedirs(proto_epoch_dir, exist_ok=True)
@@ -207,14 +272,30 @@ def _save_xproto_artefacts(root: str, epoch_number, merged, rec, names, log) -> 
 
 
 # ------------------------------------------------------------------------------------------------- PPNet
+def find_high_activation_crop(activation_map: np.ndarray, percentile: float = 95):
+    """(y0, y1, x0, x1) of the rows / columns holding a value at or above the percentile (src/utils/utils.py:259-280)."""
+    mask = activation_map >= np.percentile(activation_map, percentile)
+    rows, cols = np.nonzero(mask.any(axis=1))[0], np.nonzero(mask.any(axis=0))[0]
+    if rows.size == 0:
+        return 0, 1, 0, 1
+    return int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1
+
+
 def push_prototypes_ppnet(dataloader, model, class_specific=True, preprocess_input_function=None, prototype_layer_stride=1,
                           root_dir_for_saving_prototypes=None, epoch_number=None, prototype_img_filename_prefix=None,
                           prototype_self_act_filename_prefix=None, proto_bound_boxes_filename_prefix=None,
                           save_prototype_class_identity=True, log=print, prototype_activation_function_in_numpy=None,
                           replace_prototypes=True, rank: int = 0, world_size: int = 1):
-    """Reference signature of ``push_ProtoPNet.push_prototypes``; ``proto_index`` rows are (dataset image index, h*W + w)."""
+    """Reference signature of ``push_ProtoPNet.push_prototypes``; ``proto_index`` rows are (dataset image index, h*W + w).
+
+    With a saving directory, the box files of the reference are written (push_ProtoPNet.py:121-135):
+    ``<prefix>-receptive_field<epoch>.npy`` and ``<prefix><epoch>.npy`` (rows ``[dataset image index, y0, y1, x0, x1, label x K]``,
+    -1 where a prototype was never updated) and, with ``prototype_self_act_filename_prefix``, the winners' activation maps
+    ``<prefix><j>.npy``.  The winner's distance map and label stay on the device during the sweep (one ``torch.where`` per
+    batch, no per-batch copy to the host); the boxes are derived once at the end.  The PNG renderings are out of scope."""
     if prototype_layer_stride != 1:
         raise NotImplementedError("prototype_layer_stride != 1 is never used by the reference configs")
+    _require_group(world_size)
     model.eval()
     log("\tpush")
     start = time.time()
@@ -224,7 +305,9 @@ def push_prototypes_ppnet(dataloader, model, class_specific=True, preprocess_inp
     state = PushState(P, D, device, ppnet=True)
     lib = _lib.lib()
     search_batch_size = dataloader.batch_size
-    for i, sample in _iter_shard(dataloader, rank, world_size):
+    save = root_dir_for_saving_prototypes is not None
+    rec, hw, img_side = None, None, None
+    for i, _, sample in _iter_shard(dataloader, rank, world_size):
         x = sample["cine"]
         if preprocess_input_function is not None:
             x = preprocess_input_function(x)
@@ -232,9 +315,82 @@ def push_prototypes_ppnet(dataloader, model, class_specific=True, preprocess_inp
         with torch.no_grad():
             z, (n, h, w) = model._conv_rows(x.to(device))
             _, _, dist = model._head(z, n, h * w, want_dist=True)
+        base = int(i * search_batch_size)  # push_ProtoPNet.py:92
         _lib.check(lib.pasn_push_ppnet_update(
             dist.data_ptr(), z.data_ptr(), labels.data_ptr(), proto_class.data_ptr(), int(bool(class_specific)),
             state.dist.data_ptr(), state.index.data_ptr(), state.vec.data_ptr(), n, P, h * w, D, z.shape[-1],
-            _lib.dtype_code(z.dtype), int(i * search_batch_size), _lib.current_stream()))
+            _lib.dtype_code(z.dtype), base, _lib.current_stream()))
+        if save:
+            hw, img_side = (h, w), int(x.shape[2])
+            img = state.index[:, 0]
+            here = (img >= base) & (img < base + n)
+            b = (img - base).clamp(0, n - 1)
+            new = (dist[b, torch.arange(P, device=device)], labels[b])  # (P, h*w) distance map of the winner image, (P,) its label
+            if rec is None:
+                rec = [torch.zeros_like(t) for t in new]
+            rec = [torch.where(here.view((P,) + (1,) * (t.dim() - 1)), t, r) for t, r in zip(new, rec)]
+    local_index = state.index.clone()
     merged = _all_gather_states(state, merge_ppnet) if world_size > 1 else state.tensors()
+    if save:
+        if world_size > 1:
+            import torch.distributed as dist_
+
+            meta = [None] * world_size
+            dist_.all_gather_object(meta, (hw, img_side))
+            hw, img_side = next((m for m in meta if m[0] is not None), (None, None))
+            own_index, merged_img = local_index[:, 0], merged[1][:, 0]
+            rec, _ = _reduce_records(rec, {}, torch.where((local_index == merged[1]).all(1), own_index, torch.full_like(own_index, -1)),
+                                     merged_img, device)
+        if rank == 0 and rec is not None:
+            _save_ppnet_artefacts(model, root_dir_for_saving_prototypes, epoch_number, merged, rec, hw, img_side, search_batch_size,
+                                  save_prototype_class_identity, proto_bound_boxes_filename_prefix,
+                                  prototype_self_act_filename_prefix, prototype_activation_function_in_numpy, log)
     return _finish(model, merged, model.prototype_shape, replace_prototypes, log, start)
+
+
+def _save_ppnet_artefacts(model, root, epoch_number, merged, rec, hw, img_side, batch_size, with_class, box_prefix, act_prefix,
+                          act_fn_numpy, log) -> None:
+    import os
+
+    from .receptive_field import compute_rf_prototype
+
+    proto_epoch_dir = os.path.join(root, "epoch-" + str(epoch_number)) if epoch_number is not None else root
+    os.makedirs(proto_epoch_dir, exist_ok=True)
+    _, index, _ = merged
+    index = index.detach().cpu().numpy().astype(np.int64)
+    dmaps = rec[0].detach().float().cpu().numpy().reshape(index.shape[0], hw[0], hw[1])
+    labels = rec[1].detach().cpu().numpy()
+    P, K = index.shape[0], model.num_classes
+    cols = 5 + K if with_class else 5
+    rf_boxes = np.full((P, cols), -1)
+    bound_boxes = np.full((P, cols), -1)
+    D = model.prototype_shape[1] * model.prototype_shape[2] * model.prototype_shape[3]
+    for j in range(P):
+        if index[j, 0] < 0:
+            continue
+        h, w = divmod(int(index[j, 1]), hw[1])
+        box = compute_rf_prototype(img_side, [int(index[j, 0]) % batch_size, h, w], model.proto_layer_rf_info)
+        rf_boxes[j, 0] = index[j, 0]
+        rf_boxes[j, 1:5] = box[1:]
+        d = dmaps[j]
+        if model.prototype_activation_function == "log":
+            act = np.log((d + 1) / (d + model.epsilon))
+        elif model.prototype_activation_function == "linear":
+            act = D - d
+        else:
+            act = act_fn_numpy(d)
+        # the reference upsamples with cv2.resize(INTER_CUBIC); torch's bicubic uses the same a = -0.75 kernel, half-pixel
+        # centres and edge replication (a box edge can differ by a pixel where the percentile threshold is met marginally)
+        up = torch.nn.functional.interpolate(torch.from_numpy(np.ascontiguousarray(act, dtype=np.float32))[None, None],
+                                             size=(img_side, img_side), mode="bicubic", align_corners=False)[0, 0].numpy()
+        bound_boxes[j, 0] = index[j, 0]
+        bound_boxes[j, 1:5] = find_high_activation_crop(up)
+        if with_class:
+            rf_boxes[j, 5:] = labels[j]
+            bound_boxes[j, 5:] = labels[j]
+        if act_prefix is not None:
+            np.save(os.path.join(proto_epoch_dir, act_prefix + str(j) + ".npy"), act)
+    if box_prefix is not None:
+        np.save(os.path.join(proto_epoch_dir, box_prefix + "-receptive_field" + str(epoch_number) + ".npy"), rf_boxes)
+        np.save(os.path.join(proto_epoch_dir, box_prefix + str(epoch_number) + ".npy"), bound_boxes)
+        log(f"\tprototype boxes saved in {proto_epoch_dir}")

@@ -47,7 +47,16 @@ def _worker(rank, world, port, out_dir):
     sp.index.copy_(torch.tensor([[4, 1], [9, 0]]) if rank == 0 else torch.tensor([[2, 7], [9, 3]]))
     sp.vec.fill_(float(rank))
     pd, pi, pv = _all_gather_states(sp, merge_ppnet)
-    torch.save({"dist": md, "index": mi, "vec": mv, "pindex": pi, "pvec": pv}, os.path.join(out_dir, f"r{rank}.pt"))
+    # the winners' records (occurrence maps, clips, ...) of a sharded push: each prototype's record comes from the rank that owns its
+    # final winner, one sum-reduce to rank 0; rank 1 has seen no batch that saves records for prototype 0 ...
+    from protoasnet_amd.push import _reduce_records
+
+    local = torch.tensor([3, -1, 7]) if rank == 0 else torch.tensor([12, 11, 9])
+    merged_idx = torch.tensor([3, 11, 9])  # prototype 0 won by rank 0, prototypes 1 and 2 by rank 1
+    rec = [torch.full((3, 2, 2), float(rank + 1)), torch.tensor([10, 20, 30]) * (rank + 1)]
+    rr, names = _reduce_records(rec, {0: ["a", "b"]} if rank == 0 else {8: ["c"]}, local, merged_idx, "cpu")
+    torch.save({"dist": md, "index": mi, "vec": mv, "pindex": pi, "pvec": pv, "rec0": rr[0], "rec1": rr[1], "names": names},
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,6 +74,42 @@ def test_sharded_push_merge_world2(tmp_path):
         assert torch.equal(o["vec"], torch.stack([torch.from_numpy(v) for v in full_f]))
         assert np.array_equal(o["dist"].numpy(), full_d.astype(np.float32))
         assert o["pindex"].tolist() == [[2, 7], [9, 0]] and o["pvec"].tolist() == [[1.0, 1.0], [0.0, 0.0]]
+        assert o["names"] == {0: ["a", "b"], 8: ["c"]}
+    assert outs[0]["rec0"][:, 0, 0].tolist() == [1.0, 2.0, 2.0] and outs[0]["rec1"].tolist() == [10, 40, 60]  # on rank 0, the writer
+
+
+def test_sharded_push_without_a_process_group_is_refused():
+    """world_size > 1 with no initialised group used to push from the local shard only, silently."""
+    from protoasnet_amd.push import _require_group
+
+    with pytest.raises(RuntimeError, match="torch.distributed"):
+        _require_group(2)
+    _require_group(1)
+
+
+def test_shard_iteration_offsets_come_from_the_sampler_not_the_rank():
+    """A torch DataLoader is re-instantiated over the rank's slice of its batch_sampler: foreign batches are never loaded and the
+    global clip offsets are the sampler's prefix sums (ragged batches included), identical on every rank."""
+    from protoasnet_amd.push import _iter_shard
+
+    loaded = []
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            loaded.append(i)
+            return {"cine": torch.full((1,), float(i)), "target_AS": torch.tensor(i % 3), "filename": str(i)}
+
+    sampler = [[0, 1, 2], [3, 4], [5, 6, 7, 8], [9], [10]]  # ragged on purpose
+    dl = torch.utils.data.DataLoader(DS(), batch_sampler=sampler)
+    got = {r: [(i, base, s["cine"].flatten().tolist()) for i, base, s in _iter_shard(dl, r, 2)] for r in range(2)}
+    assert [g[:2] for g in got[0]] == [(0, 0), (1, 3), (2, 5)] and [g[:2] for g in got[1]] == [(3, 9), (4, 10)]
+    assert got[1][0][2] == [9.0]
+    loaded.clear()
+    list(_iter_shard(dl, 1, 2))
+    assert sorted(loaded) == [9, 10]  # rank 1 loaded only its own clips
 
 
 def _dp_worker(rank, world, port, out_dir):

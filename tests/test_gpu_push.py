@@ -188,3 +188,128 @@ def test_push_prototypes_ppnet_end_to_end():
     W = recorded[0][1].shape[3]
     assert np.array_equal(idx[:, 0], ref_i[:, 0]) and np.array_equal(idx[:, 1], ref_i[:, 1] * W + ref_i[:, 2])
     assert np.array_equal(m.prototype_vectors.detach().cpu().numpy(), ref_p.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# G4: the winners the REFERENCE'S OWN push loops chose when run in the build container (tests/golden/make_golden_push.py)
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["ximg_cs_abstain", "ximg_cs", "ximg_all", "xvid_cs_abstain"])
+def test_xproto_push_kernel_vs_reference_run(golden, tag):
+    """pasn_push_xproto_update fed the reference's per-batch push_forward outputs: index-, distance- and vector-exact winners,
+    incl. a repeated batch (the later one must win: '<=', push_abs_revision.py:299) and a repeated image inside a batch."""
+    g = golden("g4_push.npz")
+    cs, ab, B, K = (int(v) for v in g[f"{tag}_cfg"])
+    feats, dist, labels = g[f"{tag}_batch_feats"], g[f"{tag}_batch_dist"], g[f"{tag}_labels"]
+    P, D = feats.shape[2], feats.shape[3]
+    ident = oracle.heads.prototype_class_identity(P, K).numpy()
+    d, idx, vec = _xproto_sweep([(feats[i], dist[i], labels[i]) for i in range(feats.shape[0])], ident, K, bool(cs), bool(ab), P, D, B)
+    w = g[f"{tag}_winners"]
+    assert idx.tolist() == (w[:, 0] * B + w[:, 1]).tolist()
+    assert np.array_equal(vec.reshape(g[f"{tag}_prototypes_after"].shape), g[f"{tag}_prototypes_after"])
+    assert np.array_equal(np.float32(1) - d, g[f"{tag}_pickle_prototypes_similarity_to_src_ROIs"].astype(np.float32))
+
+
+@pytest.mark.parametrize("tag", ["ppnet_cs", "ppnet_all"])
+def test_ppnet_push_kernel_vs_reference_run(golden, tag):
+    """pasn_push_ppnet_update fed the reference's per-batch (conv_output, distances): (image, h, w) exact, the first of two
+    identical batches wins (strict '<', push_ProtoPNet.py:210), patches bit-exact."""
+    g = golden("g4_push.npz")
+    cs, B, K = (int(v) for v in g[f"{tag}_cfg"])
+    conv, dist, labels = g[f"{tag}_batch_conv"], g[f"{tag}_batch_dist"], g[f"{tag}_labels"]
+    P, D, H, W = dist.shape[2], conv.shape[2], dist.shape[3], dist.shape[4]
+    ident = oracle.heads.prototype_class_identity(P, K).numpy()
+    d, idx, vec = _ppnet_sweep([(conv[i], dist[i], labels[i]) for i in range(conv.shape[0])], ident, K, bool(cs), P, D, H * W, B)
+    assert idx[:, 0].tolist() == g[f"{tag}_rf_boxes"][:, 0].tolist()
+    assert idx[:, 1].tolist() == [int(np.argmax(g[f"{tag}_self_act"][j])) for j in range(P)]
+    assert np.array_equal(vec.reshape(P, D, 1, 1), g[f"{tag}_prototypes_after"])
+
+
+def _safe(dist_all, winners_flat, masks, tol=2e-6):
+    """Prototypes whose reference winner beats every other candidate by more than fp32 noise (the whole-model tests run the HIP
+    trunk, whose distances differ from the reference's in the last bits; the kernel-level tests above are exact)."""
+    ok = []
+    for j in range(dist_all.shape[1]):
+        c = dist_all[:, j][masks[j]]
+        best = dist_all[winners_flat[j], j]
+        ok.append(np.sum(np.abs(c - best) <= tol) == np.sum(c == best))
+    return np.array(ok)
+
+
+def test_push_prototypes_ximg_whole_model_vs_reference_run(golden, tmp_path):
+    """The product's push_prototypes (HIP ResNet-18 trunk + head B + device sweep + pickle) over the fixture's loader against what
+    the reference's push_prototypes did on the same loader and weights: winners, projected prototypes, every pickle entry."""
+    import pickle
+
+    from protoasnet_amd.push import push_prototypes
+    from util import CFG_PUSH_XIMG, push_loader
+
+    g = golden("g4_push.npz")
+    tag = "ximg_cs_abstain"
+    m = synth_model(CFG_PUSH_XIMG).to(DEV).eval()
+    loader = push_loader("image", (3, 64, 64))
+    out = push_prototypes(loader, m, class_specific=True, abstain_class=True, replace_prototypes=True, log=lambda *_: None,
+                          root_dir_for_saving_prototypes=str(tmp_path), epoch_number=7)
+    w = g[f"{tag}_winners"]
+    B, P = 4, w.shape[0]
+    want_idx = w[:, 0] * B + w[:, 1]
+    dist_all = g[f"{tag}_batch_dist"].reshape(-1, P)
+    labels = g[f"{tag}_labels"].reshape(-1)
+    cls = np.arange(P) // (P // 4)
+    masks = [(labels == cls[j]) if cls[j] < 3 else np.ones_like(labels, bool) for j in range(P)]
+    # an exact tie (the repeated batch) is decided by the rule, not by noise: count as safe when the tied set is the repeated pair
+    safe = _safe(dist_all, want_idx, masks)
+    idx = out["proto_index"].cpu().numpy()
+    assert safe.sum() >= P - 2, "fixture should separate almost all winners"
+    assert idx[safe].tolist() == want_idx[safe].tolist()
+    got = m.prototype_vectors.detach().cpu().numpy()
+    ref = g[f"{tag}_prototypes_after"]
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref)[safe].max() <= 1e-5 * scale
+    assert np.abs(out["proto_dist"].cpu().numpy() - (1 - g[f"{tag}_pickle_prototypes_similarity_to_src_ROIs"]))[safe].max() <= 2e-6
+    with open(tmp_path / "epoch-7" / "prototypes_info.pickle", "rb") as fh:
+        info = pickle.load(fh)
+    assert sorted(info) == list(g[f"{tag}_pickle_keys"])
+    assert [info["prototypes_filenames"][j] for j in np.nonzero(safe)[0]] == [f"b{w[j, 0]}_{w[j, 1]}" for j in np.nonzero(safe)[0]]
+    assert np.array_equal(info["prototypes_gts"][safe], g[f"{tag}_pickle_prototypes_gts"][safe])
+    assert np.abs(info["prototypes_preds"] - g[f"{tag}_pickle_prototypes_preds"])[safe].max() <= 1e-5
+    occ_ref = g[f"{tag}_pickle_prototypes_occurrence_maps"]
+    assert info["prototypes_occurrence_maps"].shape == occ_ref.shape
+    assert np.abs(info["prototypes_occurrence_maps"] - occ_ref)[safe].max() <= 1e-5 * max(1.0, np.abs(occ_ref).max())
+    sums = info["prototypes_src_imgs"].astype(np.float64).reshape(P, -1).sum(1)
+    assert np.allclose(sums[safe], g[f"{tag}_pickle_src_imgs_sum"][safe], rtol=0, atol=1e-6)
+
+
+def test_push_prototypes_ppnet_whole_model_vs_reference_run(golden, tmp_path):
+    """push_prototypes_ppnet (HIP trunk + head A + device sweep + box files) vs the reference's run: dataset image index, (h, w),
+    projected prototypes, bb-receptive_field<epoch>.npy, bb<epoch>.npy and the self-activation maps (push_ProtoPNet.py:121-135)."""
+    from protoasnet_amd.push import push_prototypes_ppnet
+    from util import CFG_PUSH_PPNET, push_loader
+
+    g = golden("g4_push.npz")
+    tag = "ppnet_cs"
+    m = synth_model(CFG_PUSH_PPNET).to(DEV).eval()
+    loader = push_loader("image", (3, 64, 64))
+    out = push_prototypes_ppnet(loader, m, class_specific=True, replace_prototypes=True, log=lambda *_: None,
+                                root_dir_for_saving_prototypes=str(tmp_path), epoch_number=3, proto_bound_boxes_filename_prefix="bb",
+                                prototype_self_act_filename_prefix="self_act")
+    dist = g[f"{tag}_batch_dist"]  # (nb, B, P, H, W)
+    nb, B, P, H, W = dist.shape
+    labels = g[f"{tag}_labels"].reshape(-1)
+    flat = dist.transpose(0, 1, 3, 4, 2).reshape(nb * B * H * W, P)
+    want_img = g[f"{tag}_rf_boxes"][:, 0]
+    want_s = np.array([int(np.argmax(g[f"{tag}_self_act"][j])) for j in range(P)])
+    cls = np.arange(P) // (P // 3)
+    masks = [np.repeat(labels == cls[j], H * W) for j in range(P)]
+    safe = _safe(flat, want_img * H * W + want_s, masks, tol=2e-5)
+    assert safe.sum() >= P - 1
+    idx = out["proto_index"].cpu().numpy()
+    assert idx[safe, 0].tolist() == want_img[safe].tolist() and idx[safe, 1].tolist() == want_s[safe].tolist()
+    ref = g[f"{tag}_prototypes_after"]
+    assert np.abs(m.prototype_vectors.detach().cpu().numpy() - ref)[safe].max() <= 1e-5
+    ep = tmp_path / "epoch-3"
+    assert np.array_equal(np.load(ep / "bb-receptive_field3.npy")[safe], g[f"{tag}_rf_boxes"][safe])
+    bb, bb_ref = np.load(ep / "bb3.npy"), g[f"{tag}_bound_boxes_torch_bicubic"]
+    assert np.array_equal(bb[safe][:, [0, 5, 6, 7]], bb_ref[safe][:, [0, 5, 6, 7]])
+    assert np.abs(bb[safe][:, 1:5] - bb_ref[safe][:, 1:5]).max() <= 1  # percentile threshold met marginally -> one pixel
+    for j in np.nonzero(safe)[0]:
+        assert np.allclose(np.load(ep / f"self_act{j}.npy"), g[f"{tag}_self_act"][j], atol=1e-3, rtol=1e-4)

@@ -44,3 +44,44 @@ CFG_VIDEO_R2P1D = dict(checkpoint_path="", name="Video_XProtoNet", base_architec
                        pretrained=False, prototype_shape="(40, 256, 1, 1, 1)", num_classes=4, img_size=112)
 CFG_VIDEO_X3D = dict(checkpoint_path="", name="Video_XProtoNet", base_architecture="x3d_s", backbone_last_layer_num=-3,
                      pretrained=False, prototype_shape="(30, 256, 1, 1, 1)", num_classes=3, img_size=224)
+
+
+# ---- push loaders of the G4 fixtures: the table in tests/golden/make_golden_push.py::push_recipe, restated as data --------
+PUSH_RECIPE = {
+    "image": ([[10, 11, 12, 13], [20, 21, 22, 23], [30, 31, 32, 30], [40, 41, 42, 43], [20, 21, 22, 23], [50, 51, 52, 53]],
+              [[0, 1, 2, 0], [1, 2, 0, 1], [2, 2, 1, 2], [1, 1, 1, 1], [1, 2, 0, 1], [0, 0, 2, 1]]),
+    "video": ([[110, 111, 112], [120, 121, 122], [130, 131, 130], [120, 121, 122], [140, 141, 142]],
+              [[0, 1, 2], [2, 0, 1], [1, 1, 1], [2, 0, 1], [0, 2, 2]]),
+}
+
+
+class PushLoader:
+    """len / iteration over dict samples / ``batch_size``: all the push routines need of a DataLoader."""
+
+    def __init__(self, batches, batch_size):
+        self.batches, self.batch_size = batches, batch_size
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def push_loader(kind, shape):
+    seeds, labels = PUSH_RECIPE[kind]
+    out = []
+    for bi, (ss, ls) in enumerate(zip(seeds, labels)):
+        if kind == "video":
+            x = torch.stack([video_features(shape, s) for s in ss])
+        else:
+            x = torch.cat([synth.echo_clips((1,) + tuple(shape), seed=s) for s in ss])
+        out.append({"cine": x, "target_AS": torch.tensor(ls, dtype=torch.int64), "filename": [f"b{bi}_{a}" for a in range(len(ss))]})
+    return PushLoader(out, len(seeds[0]))
+
+
+CFG_PUSH_XIMG = dict(checkpoint_path="", name="XProtoNet", base_architecture="resnet18", pretrained=False,
+                     prototype_shape="(12, 32, 1, 1)", num_classes=4, img_size=64, add_on_layers_type="regular")
+CFG_PUSH_PPNET = dict(checkpoint_path="", name="ProtoPNet", base_architecture="resnet18", pretrained=False,
+                      prototype_shape="(6, 32, 1, 1)", num_classes=3, img_size=64, add_on_layers_type="regular",
+                      prototype_activation_function="log")
