@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 
 #include "../../include/protoasnet_amd.h"
@@ -28,6 +29,22 @@ int check_launch(const char* what);
     } while (0)
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Raise a kernel instance's dynamic-LDS limit once per (call site, DEVICE).  hipFuncAttributeMaxDynamicSharedMemorySize is a per-device
+// attribute: a process-wide "done" flag left every launch needing > 64 KB failing on a second GPU driven by the same process.  The
+// flag is an atomic bit mask indexed by the current device, so concurrent callers are fine too.  Usage: PASN_MAX_LDS(bytes, kernel<...>).
+#define PASN_MAX_LDS(bytes, ...)                                                                                              \
+    do {                                                                                                                      \
+        static std::atomic<unsigned long long> pasn_lds_done_{0ull};                                                          \
+        int pasn_lds_dev_ = 0;                                                                                                \
+        (void)hipGetDevice(&pasn_lds_dev_);                                                                                   \
+        const unsigned long long pasn_lds_bit_ = 1ull << (pasn_lds_dev_ & 63);                                                \
+        if (!(pasn_lds_done_.load(std::memory_order_acquire) & pasn_lds_bit_)) {                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (bytes));                                                                               \
+            pasn_lds_done_.fetch_or(pasn_lds_bit_, std::memory_order_release);                                                \
+        }                                                                                                                     \
+    } while (0)
 
 // pointwise-conv kernel (pwconv.hip): row tile, LDS row stride, channel chunk, LDS bytes; TM == 0 -> not applicable
 struct PwGeom {

@@ -317,12 +317,7 @@ int launch_gemm_pw(const void* x, const void* w, const float* scale, const float
     if (!pw) PASN_REQUIRE(gate == nullptr, "the SE gate transform is only fused into pointwise convs");
 #define PASN_GC(PW_, BN_)                                                                                                  \
     do {                                                                                                                    \
-        static bool attr = false;                                                                                           \
-        if (!attr && lds > 64 * 1024) {                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<T, PW_, BN_>),                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
-            attr = true;                                                                                                    \
-        }                                                                                                                   \
+        if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, gemm_conv_kernel<T, PW_, BN_>);                                      \
         hipLaunchKernelGGL((gemm_conv_kernel<T, PW_, BN_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,     \
                            (const T*)res, gate, (T*)y, d);                                                                  \
     } while (0)

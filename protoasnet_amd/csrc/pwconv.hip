@@ -244,20 +244,19 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
     const dim3 block(256);
 #define PASN_PW2(KS_, NT_, RES_)                                                                                                   \
     do {                                                                                                                      \
-        int per_cu = 0;                                                                                                       \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pwconv_persist_kernel<T, KS_, NT_, RES_>, 256, lds) !=      \
-                hipSuccess || per_cu < 1)                                                                                     \
-            per_cu = 2;                                                                                                       \
+        if (lds > 64 * 1024) PASN_MAX_LDS(80 * 1024, pwconv_persist_kernel<T, KS_, NT_, RES_>); /* BEFORE the occupancy query */ \
+        static std::atomic<long> cached_{-1}; /* (device << 40 | lds << 8 | per_cu) of the last query of this instance */          \
+        const long key_ = ((long)dev << 40) | ((long)lds << 8);                                                               \
+        long c_ = cached_.load(std::memory_order_relaxed);                                                                    \
+        int per_cu = (c_ >= 0 && (c_ & ~0xffL) == key_) ? (int)(c_ & 0xff) : 0;                                               \
+        if (per_cu == 0) {                                                                                                    \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pwconv_persist_kernel<T, KS_, NT_, RES_>, 256, lds) !=  \
+                    hipSuccess || per_cu < 1)                                                                                 \
+                per_cu = 2;                                                                                                   \
+            cached_.store(key_ | (per_cu & 0xff), std::memory_order_relaxed);                                                 \
+        }                                                                                                                     \
         long blocks = want_blocks < (long)n_cu * per_cu ? want_blocks : (long)n_cu * per_cu;                                  \
         const dim3 grid((unsigned)blocks, 1);                                                                                 \
-        if (lds > 64 * 1024) {                                                                                                \
-            static bool attr = false;                                                                                         \
-            if (!attr) {                                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_persist_kernel<T, KS_, NT_, RES_>),           \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                             \
-                attr = true;                                                                                                  \
-            }                                                                                                                 \
-        }                                                                                                                     \
         hipLaunchKernelGGL((pwconv_persist_kernel<T, KS_, NT_, RES_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,   \
                            (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gate_rows); \
     } while (0)

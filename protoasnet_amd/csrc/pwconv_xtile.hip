@@ -280,12 +280,7 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
     if (geo.on) PASN_REQUIRE(gate == nullptr, "the SE gate transform is only fused into stride-1 pointwise convs");
 #define PASN_XT2(KS_, XF_, RES_)                                                                                                  \
     do {                                                                                                                    \
-        static bool attr = false;                                                                                           \
-        if (!attr) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_xtile_kernel<T, KS_, XF_, RES_>),               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
-            attr = true;                                                                                                    \
-        }                                                                                                                   \
+        PASN_MAX_LDS(96 * 1024, pwconv_xtile_kernel<T, KS_, XF_, RES_>);                                                  \
         hipLaunchKernelGGL((pwconv_xtile_kernel<T, KS_, XF_, RES_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias, \
                            (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gy, d.w_frag, geo); \
     } while (0)

@@ -251,12 +251,7 @@ int launch_x3d_front(const void* x, const void* wa, const float* sa, const float
     const dim3 grid((unsigned)d.N * g.nT * g.ctiles), block(256);
 #define PASN_XF(KS_)                                                                                                        \
     do {                                                                                                                    \
-        static bool attr = false;                                                                                           \
-        if (!attr) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&x3d_front_kernel<KS_, 7>),                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
-            attr = true;                                                                                                    \
-        }                                                                                                                   \
+        PASN_MAX_LDS(160 * 1024, x3d_front_kernel<KS_, 7>);                                                               \
         hipLaunchKernelGGL((x3d_front_kernel<KS_, 7>), grid, block, (size_t)g.lds, s, (const __bf16*)x, (const __bf16*)wa, sa, \
                            ba, wb, sb, bb, (__bf16*)y, pool, d, g.nT, g.ctiles);                                            \
     } while (0)

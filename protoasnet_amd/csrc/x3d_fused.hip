@@ -370,12 +370,7 @@ static int launch_xd(const void* x, const void* wa, const float* sa, const float
     const dim3 grid(d.N * g.tilesH * g.tilesW * g.chunks), block(g.threads);
 #define PASN_XD(SW_, WT_)                                                                                                   \
     do {                                                                                                                    \
-        static bool attr = false;                                                                                           \
-        if (!attr) {                                                                                                        \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&x3d_expand_dw_kernel<T, SW_, WT_>),                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
-            attr = true;                                                                                                    \
-        }                                                                                                                   \
+        PASN_MAX_LDS(160 * 1024, x3d_expand_dw_kernel<T, SW_, WT_>);                                                      \
         hipLaunchKernelGGL((x3d_expand_dw_kernel<T, SW_, WT_>), grid, block, (size_t)g.lds, s, (const T*)x, (const T*)wa, sa, \
                            ba, wb, sb, bb, (T*)y, pool, d, g);                                                              \
     } while (0)

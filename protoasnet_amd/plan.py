@@ -517,6 +517,14 @@ class HipTrunk(nn.Module):
     def _signature(self) -> tuple:
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
+    def invalidate_plans(self) -> None:
+        """Drop every cached launch list (and its packed weights).  The cache key is (storage address, autograd version counter) of
+        every parameter / buffer, which sees optimizer steps, ``load_state_dict``, ``.to()`` and any in-place op on the parameter --
+        but NOT a write through ``param.data`` or a raw pointer, which bumps no counter.  Code that does that to a trunk calls this
+        afterwards.  (The reference writes through ``.data`` only to ``prototype_vectors`` and ``last_layer.weight``
+        (push_abs_revision.py:346, ProtoPNet.py:308-311); neither is packed or cached here.)"""
+        self._plans = {}
+
     def plan_for(self, x: torch.Tensor) -> Plan:
         p0 = next(self.parameters())
         dtype = self.compute_dtype or p0.dtype

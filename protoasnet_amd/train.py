@@ -519,7 +519,7 @@ class _TrainFn(torch.autograd.Function):
     def forward(ctx, runner, x, *params):
         outs = runner.alloc_outputs(x)
         arena = runner.plan.forward(x, outs)
-        ctx.runner, ctx.names = runner, tuple(outs)
+        ctx.runner, ctx.names, ctx.consumed = runner, tuple(outs), False
         ctx.save_for_backward(x, arena, *outs.values())
         ctx.set_materialize_grads(False)
         return tuple(outs[n] for n in runner.out_names)
@@ -527,6 +527,14 @@ class _TrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         runner = ctx.runner
+        if ctx.consumed:
+            # the backward launch list runs IN the forward's arena: activations are overwritten as soon as their last reader has
+            # run and gradient buffers are rewritten in place, so a second replay would read clobbered data and return wrong
+            # gradients silently (retain_graph=True, or autograd.grad followed by backward)
+            raise RuntimeError("protoasnet_amd: this training pass was already differentiated once; its activations were reused as "
+                               "backward scratch.  retain_graph / a second backward through the same forward is not supported -- "
+                               "run the forward again")
+        ctx.consumed = True
         x, arena, *saved = ctx.saved_tensors
         outs = dict(zip(ctx.names, saved))
         tensors: Dict[str, Optional[torch.Tensor]] = dict(outs)

@@ -43,12 +43,34 @@ def _built_library():
     yield
 
 
+# Tolerances of the comparisons with the REFERENCE'S golden outputs (fp32 HIP path).  Round 1 asserted 1e-3 where the two golden
+# samples differ by only 4e-4 ... 2e-3 (the check could not tell the samples apart); observed errors are ~1e-7 ... 1e-6, so the
+# gates sit two orders above the noise and one to two below the sample-to-sample differences (assert_discriminates proves it).
+TOL_SIM = 2e-5      # similarities / 1 - similarity, values in [0, 1]
+TOL_LOGITS = 5e-5   # logits of the golden cases, |values| <= 3
+
+
+def assert_discriminates(golden_array, atol, rtol=0.0, factor=5.0, name=""):
+    """The tolerance must be able to tell the fixture's samples apart: swapping sample 0 and 1 has to FAIL the comparison."""
+    g = torch.as_tensor(golden_array).float()
+    diff = (g[0] - g[1]).abs()
+    tol = atol + rtol * g[1].abs()
+    assert bool((diff > factor * tol).any()), f"{name}: samples differ by {float(diff.max()):.3g} only; tolerance {atol:.3g} cannot discriminate"
+    with pytest.raises(AssertionError):
+        assert_close(g[[1, 0]], g[:2], atol, rtol, name + " (swapped)")
+
+
 def assert_close(actual, expected, atol, rtol=0.0, name=""):
     a = torch.as_tensor(actual).detach().float().cpu()
     e = torch.as_tensor(expected).detach().float().cpu()
     assert a.shape == e.shape, f"{name}: shape {tuple(a.shape)} != {tuple(e.shape)}"
     err = (a - e).abs()
     tol = atol + rtol * e.abs()
+    log = os.environ.get("PASN_PARITY_LOG")
+    if log:  # observed error next to the gate, for DESIGN.md section 5 (never changes the verdict)
+        with open(log, "a") as fh:
+            fh.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]}\t{name}\tmax_err={float(err.max()):.3g}\t"
+                     f"atol={atol:.3g}\trtol={rtol:.3g}\tmax|ref|={float(e.abs().max()):.3g}\n")
     bad = err > tol
     if bad.any():
         i = int(torch.argmax(err - tol))

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import assert_close
+from conftest import TOL_LOGITS, TOL_SIM, assert_close, assert_discriminates
 from util import head_b_state, video_features
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +56,7 @@ def test_l2_head_matches_reference_golden(golden, tag, P, D):
     dist, mind, amin, logits = _l2_head(z, protos, fcw, "log", torch.float32)
     assert_close(dist.view(2, P, 7, 7), g[f"{tag}_distances"], 1e-3, 0, "distances")
     assert_close(mind, g[f"{tag}_min_distances"], 1e-3, 0, "min_distances")
-    assert_close(logits, g[f"{tag}_logits"], 1e-3, 0, "logits")
+    assert_close(logits, g[f"{tag}_logits"], TOL_LOGITS, 0, "logits")
     ref_arg = torch.from_numpy(g[f"{tag}_distances"]).reshape(2, P, 49).argmin(dim=2)
     # bit-exact patch index, except where the reference's own top-2 gap is below fp32 reduction noise
     srt = torch.from_numpy(g[f"{tag}_distances"]).reshape(2, P, 49).sort(dim=2).values
@@ -150,9 +150,11 @@ def test_xproto_head_matches_reference_golden(golden, tag):
     sd = head_b_state(shape[1], 256, P, K, video=True)
     x = video_features(shape, seed=1234 + shape[0])
     occ, feat, sim, logits = _xproto_head(x, sd, P, 256, K, torch.float32)
-    assert_close(sim, g[f"{tag}_similarity"], 1e-3, 0, "similarity")
-    assert_close(1 - sim, g[f"{tag}_proto_dist"], 1e-3, 0, "prototype distances")
-    assert_close(logits, g[f"{tag}_logits"], 1e-3, 0, "logits")
+    assert_close(sim, g[f"{tag}_similarity"], TOL_SIM, 0, "similarity")
+    assert_close(1 - sim, g[f"{tag}_proto_dist"], TOL_SIM, 0, "prototype distances")
+    assert_close(logits, g[f"{tag}_logits"], TOL_LOGITS, 0, "logits")
+    assert_discriminates(g[f"{tag}_similarity"], TOL_SIM, name="similarity")
+    assert_discriminates(g[f"{tag}_logits"], TOL_LOGITS, name="logits")
     scale = float(np.abs(g[f"{tag}_features_extracted"]).max())
     assert_close(feat, g[f"{tag}_features_extracted"], 1e-5 * scale + 1e-3, 1e-4, "features_extracted")
     occ = occ.view((shape[0], P, 1) + shape[2:])
@@ -172,8 +174,8 @@ def test_xproto_head_image_matches_reference_golden(golden):
     sd = synth_model(CFG_XPROTO).state_dict()
     feats = oracle.backbones.resnet18_features(sd, "cnn_backbone.", synth.echo_clips((2, 3, 224, 224)))
     occ, feat, sim, logits = _xproto_head(feats, sd, 40, 512, 4, torch.float32)
-    assert_close(sim, g["similarity"], 1e-3, 0, "similarity")
-    assert_close(logits, g["logits"], 1e-3, 0, "logits")
+    assert_close(sim, g["similarity"], TOL_SIM, 0, "similarity")
+    assert_close(logits, g["logits"], TOL_LOGITS, 0, "logits")
     assert_close(occ.view(2, 40, 1, 7, 7), g["occurrence_map"], 1e-3, 1e-4, "occurrence_map")
     assert_close(feat, g["features_extracted"], 0.2, 1e-4, "features_extracted (|F| ~ 1e4)")
 

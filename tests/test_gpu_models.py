@@ -3,7 +3,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import assert_close
+from conftest import TOL_LOGITS, TOL_SIM, assert_close, assert_discriminates
 from protoasnet_amd import synth
 from util import (CFG_PPNET, CFG_PPNET_BOTTLENECK, CFG_VIDEO_R2P1D, CFG_VIDEO_X3D, CFG_XPROTO, synth_model)
 
@@ -30,7 +30,9 @@ def test_ppnet_resnet18_vs_reference_golden(golden, tag, cfg):
     assert_close(conv_out, g[f"{tag}_conv_features"], 1e-3, 0, "conv_features")
     assert_close(dist, g[f"{tag}_distances"], 1e-3 * float(g[f"{tag}_distances"].max()) / 10, 0, "distances")
     assert_close(min_d, g[f"{tag}_min_distances"], 1e-3 * float(g[f"{tag}_distances"].max()) / 10, 0, "min_distances")
-    assert_close(logits, g[f"{tag}_logits"], 1e-3, 0, "logits")
+    assert_close(logits, g[f"{tag}_logits"], TOL_LOGITS, 0, "logits")
+    assert_discriminates(g[f"{tag}_logits"], TOL_LOGITS, name="ppnet logits")
+    assert_discriminates(g[f"{tag}_min_distances"], 1e-3 * float(g[f"{tag}_distances"].max()) / 10, name="ppnet min_distances")
 
 
 def test_xprotonet_resnet18_vs_reference_golden(golden):
@@ -42,9 +44,11 @@ def test_xprotonet_resnet18_vs_reference_golden(golden):
         feats, pdist, occ2, logits2 = m.push_forward(x)
         occ3 = m.compute_occurence_map(x)
     assert tuple(occ.shape) == (2, 40, 1, 7, 7) and tuple(feats.shape) == (2, 40, 512)
-    assert_close(sim, g["similarity"], 1e-3, 0, "similarity")
-    assert_close(pdist, g["proto_dist"], 1e-3, 0, "1 - similarity")
-    assert_close(logits, g["logits"], 1e-3, 0, "logits")
+    assert_close(sim, g["similarity"], TOL_SIM, 0, "similarity")
+    assert_close(pdist, g["proto_dist"], TOL_SIM, 0, "1 - similarity")
+    assert_close(logits, g["logits"], TOL_LOGITS, 0, "logits")
+    for key, tol in (("similarity", TOL_SIM), ("logits", TOL_LOGITS)):
+        assert_discriminates(g[key], tol, name=key)  # swapping the two clips must fail (round 1's 1e-3 could not tell them apart)
     assert_close(occ, g["occurrence_map"], 2e-3, 1e-3, "occurrence_map")
     assert_close(feats, g["features_extracted"], 1.0, 1e-3, "features_extracted (|F| ~ 1e4)")
     assert torch.equal(occ, occ2) and torch.equal(logits, logits2)
@@ -114,6 +118,62 @@ def test_x3d_production_routes_vs_oracle(dtype):
         assert_close(logits, ref["logits"], 1e-3, 0, "logits")
 
 
+CFG_VIDEO_X3D_M = dict(CFG_VIDEO_X3D, base_architecture="x3d_m", prototype_shape="(60, 256, 1, 1, 1)", img_size=312)
+
+
+@pytest.mark.timeout(900)
+def test_cfg5_x3d_m_312_p60_fp32_vs_bf16_tolerance_table():
+    """BASELINE config 5: X3D-M trunk, 32 x 312 x 312 clips, 60 prototypes (K = 3).  fp32 is the parity path (<= 1e-3 against the
+    oracle, north_star); bf16 activations / weights with fp32 accumulation are held to the stated tolerance table."""
+    m = _gpu(CFG_VIDEO_X3D_M)
+    x = synth.echo_clips((1, 3, 32, 312, 312))
+    ref = oracle.nets.xprotonet_forward({k: v.cpu() for k, v in m.state_dict().items()}, x, arch="x3d_m")
+    assert tuple(ref["occurrence_map"].shape) == (1, 60, 1, 32, 10, 10) and tuple(ref["similarity"].shape) == (1, 60)
+    with torch.no_grad():
+        logits, sim, occ = m(x.to(DEV))
+        feats, pdist, _, _ = m.push_forward(x.to(DEV))
+    occ_scale = max(1.0, float(ref["occurrence_map"].max()))
+    assert_close(sim, ref["similarity"], 1e-3, 0, "cfg5 fp32 similarity")
+    assert_close(pdist, ref["proto_dist"], 1e-3, 0, "cfg5 fp32 prototype distances")
+    assert_close(logits, ref["logits"], 1e-3, 0, "cfg5 fp32 logits")
+    assert_close(occ, ref["occurrence_map"], 1e-3 * occ_scale, 1e-3, "cfg5 fp32 occurrence_map")
+    assert_close(feats, ref["features_extracted"], 1e-3 * float(ref["features_extracted"].abs().max()), 1e-3, "cfg5 fp32 features_extracted")
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        logits16, sim16, occ16 = m(x.to(DEV).bfloat16())
+    table = {  # quantity: (bf16 vs fp32-oracle error, bound)
+        "similarity max abs": (float((sim16.cpu() - ref["similarity"]).abs().max()), 2e-2),
+        "logits max abs": (float((logits16.cpu() - ref["logits"]).abs().max()), 0.25),
+        "occurrence map mean rel": (float((occ16.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()), 0.05),
+        "fp32 similarity max abs": (float((sim.cpu() - ref["similarity"]).abs().max()), 1e-3),
+    }
+    print("cfg5 tolerance table:", {k: f"{v[0]:.3g} (<= {v[1]:g})" for k, v in table.items()})
+    for k, (err, bound) in table.items():
+        assert err <= bound, f"cfg5 {k}: {err:.3g} > {bound:g}"
+    assert table["similarity max abs"][0] > table["fp32 similarity max abs"][0]  # the sweep really ran two precisions
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cfg2_full_shape_vs_oracle(dtype):
+    """BASELINE config 2 at its FULL clip shape (3,16,224,224), X3D-S, P=30 -- two clips (the oracle's broadcast product bounds N)."""
+    m = _gpu(CFG_VIDEO_X3D)
+    if dtype == torch.bfloat16:
+        m.set_compute_dtype(torch.bfloat16)
+    x = synth.echo_clips((2, 3, 16, 224, 224))
+    ref = oracle.nets.xprotonet_forward({k: v.cpu() for k, v in m.state_dict().items()}, x, arch="x3d_s")
+    with torch.no_grad():
+        logits, sim, occ = m(x.to(DEV).to(dtype))
+    assert tuple(occ.shape) == (2, 30, 1, 16, 7, 7)
+    if dtype == torch.float32:
+        assert_close(sim, ref["similarity"], 1e-3, 0, "cfg2 fp32 similarity")
+        assert_close(logits, ref["logits"], 1e-3, 0, "cfg2 fp32 logits")
+        assert_close(occ, ref["occurrence_map"], 1e-3 * max(1.0, float(ref["occurrence_map"].max())), 1e-3, "cfg2 fp32 occurrence_map")
+    else:
+        assert_close(sim, ref["similarity"], 2e-2, 0, "cfg2 bf16 similarity")
+        assert_close(logits, ref["logits"], 0.25, 0.05, "cfg2 bf16 logits")
+
+
 def test_module_surface_and_errors():
     m = _gpu(CFG_VIDEO_X3D)
     assert m.num_prototypes == 30 and m.num_classes == 3 and tuple(m.prototype_class_identity.shape) == (30, 3)
@@ -138,6 +198,30 @@ def test_module_surface_and_errors():
         c = m(x)[0]
     assert_close(b, 2 * a, 1e-5, 1e-5, "last layer refresh")
     assert not torch.allclose(b, c)
+
+
+def test_data_writes_and_cache_invalidation():
+    """Writes through ``.data`` bump no version counter.  The two the reference performs (prototype projection,
+    push_abs_revision.py:346; last-layer reset, ProtoPNet.py:308-311) hit tensors that are read afresh on every call; a ``.data`` write
+    into a TRUNK weight is served from the packed copy until ``invalidate_plans()`` -- documented, and pinned here."""
+    m = _gpu(CFG_VIDEO_X3D)
+    x = synth.echo_clips((1, 3, 4, 64, 64)).to(DEV)
+    with torch.no_grad():
+        l0, s0, _ = (t.clone() for t in m(x))
+        m.prototype_vectors.data.copy_(torch.flip(m.prototype_vectors.data, dims=(0,)))
+        l1, s1, _ = (t.clone() for t in m(x))
+        assert_close(s1, torch.flip(s0, dims=(1,)), 1e-6, 0, "prototype_vectors.data write is seen at once")
+        m.last_layer.weight.data.mul_(3.0)
+        l2 = m(x)[0].clone()
+        assert_close(l2, 3 * l1, 1e-5, 1e-5, "last_layer.weight.data write is seen at once")
+        v = m.cnn_backbone.stem.conv_xy.weight._version
+        m.cnn_backbone.stem.conv_xy.weight.data.mul_(1.5)
+        assert m.cnn_backbone.stem.conv_xy.weight._version == v  # no counter moved: the cache cannot know
+        stale = m(x)[0].clone()
+        assert torch.equal(stale, l2)
+        m.cnn_backbone.invalidate_plans()
+        fresh = m(x)[0]
+        assert not torch.allclose(fresh, l2)
 
 
 def test_arena_reuse_on_gpu():

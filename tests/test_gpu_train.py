@@ -556,6 +556,19 @@ def test_train_bf16_activations_track_fp32(cfg, shape, spatial):
     assert cos > 0.95, f"bf16-activation gradients drifted from fp32: cosine {cos:.4f}; lowest per tensor {per[:5]}"
 
 
+def test_second_backward_through_one_forward_is_refused():
+    """The backward launch list reuses the forward's activations as scratch: a second replay (retain_graph=True) would return wrong
+    gradients silently, so it raises instead."""
+    m = synth_model(CFG_VIDEO_X3D).to(DEV).train()
+    logits, sim, occ = m(synth.echo_clips((2, 3, 4, 64, 64)).to(DEV))
+    loss = logits.sum() + sim.sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already differentiated"):
+        loss.backward()
+    logits, sim, occ = m(synth.echo_clips((2, 3, 4, 64, 64)).to(DEV))  # a fresh forward differentiates fine
+    (logits.sum() + occ.sum()).backward()
+
+
 def test_training_guards():
     m = synth_model(CFG_VIDEO_X3D).to(DEV).train()
     with pytest.raises(RuntimeError):

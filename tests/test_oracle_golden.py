@@ -169,3 +169,20 @@ def test_oracle_train_mode_ppnet_vs_reference_golden(golden):
     wl, wm, _ = loss_weights(SHAPE[0], 30, 3, (1, 1))
     loss = (out["logits"] * wl).sum() + (out["min_distances"] * wm).sum()
     _check_train_golden(g, "ppnet", sd, {"logits": out["logits"], "min_distances": out["min_distances"]}, loss)
+
+
+def test_golden_tolerances_discriminate_between_samples(golden):
+    """The gates used against the reference's golden outputs (conftest.TOL_*) must fail when two samples are swapped -- round 1's
+    1e-3 did not (similarities of the two golden clips differ by 2e-3, logits by 4e-4 ... 1e-3)."""
+    from conftest import TOL_LOGITS, TOL_SIM, assert_discriminates
+
+    g1, g2, g3 = golden("g1_ppnet_resnet18.npz"), golden("g2_xprotonet_resnet18.npz"), golden("g3_video_head.npz")
+    assert_discriminates(g2["similarity"], TOL_SIM, name="g2 similarity")
+    assert_discriminates(g2["logits"], TOL_LOGITS, name="g2 logits")
+    for tag in ("regular", "bottleneck"):
+        assert_discriminates(g1[f"{tag}_logits"], TOL_LOGITS, name=f"g1 {tag} logits")
+    for tag in ("small", "refcfg", "p30"):
+        assert_discriminates(g3[f"{tag}_similarity"], TOL_SIM, name=f"g3 {tag} similarity")
+        assert_discriminates(g3[f"{tag}_logits"], TOL_LOGITS, name=f"g3 {tag} logits")
+    with pytest.raises(AssertionError):  # ... and round 1's gate indeed could not
+        assert_discriminates(g1["regular_logits"], 1e-3, name="g1 logits at 1e-3")
