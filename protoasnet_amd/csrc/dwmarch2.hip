@@ -1,0 +1,329 @@
+// T-marching depthwise 3x3x3 stencil, second generation (round 2): the X3D conv_b of every block, bf16 activations.
+//
+// What round 1's kernel (dwmarch.hip) spent its time on, from its ISA and the VALU issue-rate probe (tools/valu_probe.hip:
+// v_pk_fma_f32 costs the same per FMA as v_fma_f32; v_dot2c_f32_bf16 / v_perm_b32 cost 1.6x an FMA instruction, so neither a
+// packed-bf16 dot product nor fp16 packed math buys anything here -- the 27 fp32 FMAs per output element are the floor):
+//   * 9 x (6 ds_read_b128 of weights -> s_waitcnt lgkmcnt -> 72 FMAs) per frame: the LDS round trip is exposed nine times per
+//     frame with two waves per SIMD to cover it;
+//   * zero padding by v_cndmask on the loaded words, a divergent branch per input row, accumulator re-zeroing by v_mov.
+// This kernel
+//   * double-buffers the weight registers: the reads of tap group g+1 are issued before the FMAs of group g (PF);
+//   * pads with the buffer-load range check: an out-of-image column / row adds 2^30 / 2^31 to the byte offset, past num_records, and
+//     the hardware returns zeros -- no select on the data, no branch around a row;
+//   * initialises an accumulator set with a multiply in its first tap instead of zeroing it after the emit;
+//   * takes the channels per thread as a parameter: CH = 4 halves the weight registers per tap group and the accumulator count per
+//     output, which pays for wider strips (each weight read then feeds WT = 4..6 outputs instead of 3) at the same or a higher
+//     occupancy.  The instance per layer is picked by a cost model (dw_march2_geom) and can be forced for A/B runs
+//     (PASN_DWM2="CH,WT[,Tc]"; PASN_DWM2=0 keeps round 1's kernel).
+// Arithmetic per output element is unchanged (fp32 FMAs in tap order kt-major within (kh, kw) order of arrival), so results are
+// bit-identical to dwmarch.hip's for the same (WT-independent) summation order.
+#include "common.h"
+
+namespace pasn {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int DW2_ROWS = 29;          // 27 taps + scale + bias
+constexpr int DW2_ROW_FLOATS = 512;   // LDS floats per row = max channels
+static size_t dw2_lds_bytes(int R, int Cp) { return (size_t)(DW2_ROWS * DW2_ROW_FLOATS + R * Cp) * sizeof(float); }
+
+template <int CH>
+struct RawVec;
+template <>
+struct RawVec<8> {
+    using type = u32x4;
+    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    }
+};
+template <>
+struct RawVec<4> {
+    using type = u32x2;
+    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    }
+};
+
+template <int CH>
+__device__ __forceinline__ void raw_to_f(const typename RawVec<CH>::type& r, float (&v)[CH]) {
+#pragma unroll
+    for (int i = 0; i < CH / 2; ++i) {
+        v[2 * i] = __uint_as_float(r[i] << 16);
+        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+}
+
+template <int CH>
+__device__ __forceinline__ void store_bf16(__bf16* p, const float (&v)[CH]) {
+    if constexpr (CH == 8) store8(p, v);
+    else store4(p, v);
+}
+
+// weights of one tap for this thread's CH channels: LDS row `tap`, CH consecutive floats at channel offset ch0
+template <int CH>
+__device__ __forceinline__ void read_w(const float* wl, int row, float (&w)[CH]) {
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+        // CH = 8: two planes [q][group][4] so that consecutive lanes read consecutive 16-byte slots (conflict-free)
+        const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * DW2_ROW_FLOATS + q * (DW2_ROW_FLOATS / 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[4 * q + j] = t[j];
+    }
+}
+
+template <int SW, int WT, int CH, int OCC>
+__global__ __launch_bounds__(256, OCC) void dwconv3d_march2_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                  __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
+                                                                  int CG, int R, int strips, int Tc, int bpc, unsigned xbytes) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NC = (WT - 1) * SW + 3;  // input columns a strip touches
+    using Raw = typename RawVec<CH>::type;
+    const int Cp = d.Cout_p;
+    float* red = lds + DW2_ROWS * DW2_ROW_FLOATS;
+    // stage weights | scale | bias: batches of independent 16-byte loads, THEN the LDS writes
+    {
+        constexpr int PL = CH / 4;
+        const int total = DW2_ROWS * PL * CG;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 8 * blockDim.x) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * (int)blockDim.x, total - 1);
+                const int row = i / (PL * CG), rem = i - row * PL * CG, q = rem / CG, g = rem - q * CG;
+                const float* src = row < 27 ? w + (long)row * Cp : (row == 27 ? scale : bias);
+                v[u] = *reinterpret_cast<const f32x4*>(src + g * CH + q * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * (int)blockDim.x;
+                if (i < total) {
+                    const int row = i / (PL * CG), rem = i - row * PL * CG, q = rem / CG, g = rem - q * CG;
+                    *reinterpret_cast<f32x4*>(lds + row * DW2_ROW_FLOATS + q * (DW2_ROW_FLOATS / 2) + g * 4) = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int cg = threadIdx.x % CG, r = threadIdx.x / CG;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);  // whole clips per XCD: halo rows of neighbouring items share an L2
+    const int n = lb / bpc, bx = lb % bpc;
+    const int nT = (d.To + Tc - 1) / Tc;
+    const int items = nT * d.Ho * strips;
+    const int item = bx * R + r;
+    float psum[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) psum[j] = 0.0f;
+
+    if (item < items) {
+        const int strip = item % strips;
+        const int ho = (item / strips) % d.Ho;
+        const int t0 = (item / (strips * d.Ho)) * Tc;
+        const int t1 = min(t0 + Tc, d.To);
+        const int wo0 = strip * WT;
+        const int wi0 = wo0 * SW - 1;
+        const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, xbytes, 0x00020000);
+        // per-thread column byte offsets; a column outside the image carries 2^30 (beyond num_records <= 2^30: the load returns 0)
+        unsigned colofs[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int wi = wi0 + c;
+            colofs[c] = (wi >= 0 && wi < Wi) ? (unsigned)(wi * Cp * 2 + cg * CH * 2) : 0x40000000u;
+        }
+        const unsigned rowbytes = (unsigned)(Wi * Cp * 2);
+        Raw raw[NC];
+        auto issue = [&](int ti, int kh) {  // a row outside the clip carries 2^31: every column of it reads as zeros
+            const int hi = ho * SW - 1 + kh;
+            const bool ok = ti >= 0 && ti < Ti && hi >= 0 && hi < Hi;
+            const unsigned base = ok ? (unsigned)((n * Ti + ti) * Hi + hi) * rowbytes : 0x80000000u;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) raw[c] = RawVec<CH>::load(rsrc, base + colofs[c]);
+        };
+
+        float A0[WT][CH], A1[WT][CH], A2[WT][CH];  // set A1 / A2 start as "current" / "next": their first frame multiplies in
+#pragma unroll
+        for (int o = 0; o < WT; ++o)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) A0[o][j] = A1[o][j] = A2[o][j] = 0.0f;
+
+        // one input frame ti: P = output ti-1 (kt = 2), C = output ti (kt = 1), N = output ti+1 (kt = 0).
+        // FRESH: N holds no partial sum yet (its first contributions arrive here: kh = 0, e = 0 multiplies instead of adding).
+        auto frame = [&](int ti, float (&P)[WT][CH], float (&C)[WT][CH], float (&N)[WT][CH]) {
+            // opaque per-frame zero: keeps the weight reads of a frame INSIDE the loop (hoisted they are 27 * CH registers)
+            int zo = 0;
+            asm volatile("" : "+v"(zo));
+            const float* wl = lds + cg * 4 + zo;
+            float wv[2][3][CH];  // double-buffered tap group (kh, kt): 3 kw taps x CH channels
+            auto load_group = [&](int g, float (&dst)[3][CH]) {  // g = kh * 3 + kt
+                const int kh = g / 3, kt = g % 3;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) read_w<CH>(wl, (kt * 3 + kh) * 3 + e, dst[e]);
+            };
+            load_group(0, wv[0]);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                float xr[NC][CH];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) raw_to_f<CH>(raw[c], xr[c]);
+                // refill the raw registers with the next row; it lands under this row's FMAs
+                __builtin_amdgcn_sched_barrier(0);  // the refill must not be hoisted above the conversion (a second raw row live)
+                if (kh < 2) issue(ti, kh + 1);
+                else issue(ti + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const int g = kh * 3 + kt;
+                    if (g + 1 < 9) load_group(g + 1, wv[(g + 1) & 1]);  // next group's weights fly under this group's FMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    float (&T_)[WT][CH] = kt == 0 ? N : kt == 1 ? C : P;
+                    const float (&wg)[3][CH] = wv[g & 1];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            if ((c - e) >= 0 && (c - e) % SW == 0 && (c - e) / SW < WT) {  // resolved at compile time
+                                const int o = (c - e) / SW;
+                                if (kt == 0 && kh == 0 && e == 0) {
+#pragma unroll
+                                    for (int j = 0; j < CH; ++j) T_[o][j] = xr[c][j] * wg[e][j];
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < CH; ++j) T_[o][j] = fmaf(xr[c][j], wg[e][j], T_[o][j]);
+                                }
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // output frame ti-1 has now seen frames ti-2, ti-1, ti
+            const int to = ti - 1;
+            if (to >= t0 && to < t1) {
+                float sc[CH], bs[CH];
+                read_w<CH>(wl, 27, sc);
+                read_w<CH>(wl, 28, bs);
+                __bf16* yrow = y + ((((long)n * d.To + to) * d.Ho + ho) * d.Wo) * Cp + cg * CH;
+#pragma unroll
+                for (int o = 0; o < WT; ++o) {
+                    const int wo = wo0 + o;
+                    if (wo >= d.Wo) continue;
+                    float v[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        v[j] = P[o][j] * sc[j] + bs[j];
+                        psum[j] += v[j];
+                    }
+                    act_vec(v, d.act);
+                    if (d.Cout - cg * CH < CH) mask_tail(v, d.Cout - cg * CH);  // only the last channel group has padding
+                    store_bf16<CH>(yrow + (long)wo * Cp, v);
+                }
+            }
+        };
+
+        issue(t0 - 1, 0);
+#pragma unroll 1
+        for (int ti = t0 - 1; ti <= t1; ti += 3) {
+            frame(ti, A0, A1, A2);
+            if (ti + 1 <= t1) frame(ti + 1, A1, A2, A0);
+            if (ti + 2 <= t1) frame(ti + 2, A2, A0, A1);
+        }
+    }
+    if (pool) {  // block-uniform; squeeze-excite partial sums reduced over the R items in fixed order
+#pragma unroll
+        for (int j = 0; j < CH; ++j) red[r * Cp + cg * CH + j] = psum[j];
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+            float s = 0.0f;
+            for (int q = 0; q < R; ++q) s += red[q * Cp + ch];
+            pool[((long)n * bpc + bx) * Cp + ch] = s;
+        }
+    }
+}
+
+// ---- instance table: (CH, WT) per stride; OCC = waves per SIMD the register budget is held to ------------------------------
+struct Dw2Inst {
+    int ch, wt, occ;
+};
+static const Dw2Inst kInst1[] = {{8, 3, 2}, {8, 2, 2}, {4, 4, 3}, {4, 6, 2}, {4, 3, 3}};  // stride 1
+static const Dw2Inst kInst2[] = {{8, 2, 2}, {4, 3, 2}, {4, 2, 3}};                        // stride 2
+
+Dw2Geom dw_march2_geom(const pasn_conv_desc& d, int dtype) {
+    Dw2Geom g = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (dtype != PASN_BF16) return g;
+    const char* env = getenv("PASN_DWM2");
+    if (env && env[0] == '0') return g;
+    const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == d.sw && (d.sw == 1 || d.sw == 2) && d.pt == 1 &&
+                       d.ph == 1 && d.pw == 1 && d.To == d.Ti && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0 && d.Cout_p <= DW2_ROW_FLOATS;
+    if (!shape) return g;
+    if (d.Ho != (d.Hi + 2 - 3) / d.sh + 1 || d.Wo != (d.Wi + 2 - 3) / d.sw + 1) return g;
+    // byte offsets are 32-bit and the padding trick needs every valid offset below 2^30
+    if ((long)d.N * d.Ti * d.Hi * d.Wi * d.Cin_p * 2 > (1L << 30)) return g;
+    int force_ch = 0, force_wt = 0, force_tc = 0;
+    if (env) sscanf(env, "%d,%d,%d", &force_ch, &force_wt, &force_tc);
+    const Dw2Inst* tab = d.sw == 1 ? kInst1 : kInst2;
+    const int ntab = d.sw == 1 ? (int)(sizeof(kInst1) / sizeof(kInst1[0])) : (int)(sizeof(kInst2) / sizeof(kInst2[0]));
+    double best = 1e30;
+    for (int i = 0; i < ntab; ++i) {
+        const Dw2Inst& in = tab[i];
+        if (force_ch && (in.ch != force_ch || in.wt != force_wt)) continue;
+        if (d.Cout_p % in.ch != 0 || d.Cout_p / in.ch > 128 || d.Cout_p / in.ch > 256) continue;
+        const int cgn = d.Cout_p / in.ch, rn = 256 / cgn;
+        if (rn < 1) continue;
+        const int nc = (in.wt - 1) * d.sw + 3;
+        // issue slots per thread-frame: FMAs (a packed pair per two channels), conversions, weight reads, loads, emit
+        const double per_frame = 27.0 * in.wt * in.ch / 2 * 2.0 + 3.0 * nc * in.ch + 27.0 * (in.ch / 4) * 1.5 + 3.0 * nc * 2 +
+                                 in.wt * in.ch * 3.0 + 40;
+        const int resident = 256 * in.occ;  // blocks resident on the chip (1 wave per SIMD per block)
+        for (int tc = force_tc ? (force_tc < d.To ? force_tc : d.To) : d.To; tc >= 1; tc = (tc + 1) / 2) {
+            const int nT = ceil_div(d.To, tc), strips = ceil_div(d.Wo, in.wt);
+            const long threads = (long)nT * d.Ho * strips;
+            const long blocks = (long)d.N * ceil_div(threads, rn);
+            const double rounds = (double)ceil_div(blocks, resident);
+            const double frames = tc + 2.0;
+            // a round costs its thread-frames at the issue rate the occupancy sustains (more waves hide more latency)
+            const double t = rounds * frames * per_frame * (in.occ >= 3 ? 0.85 : 1.0) * in.occ;
+            if (t < best) {
+                best = t;
+                g.CH = in.ch;
+                g.WT = in.wt;
+                g.OCC = in.occ;
+                g.Tc = tc;
+            }
+            if (force_tc || tc <= 4) break;
+        }
+    }
+    if (g.WT == 0) return Dw2Geom{0, 0, 0, 0, 0, 0, 0, 0};
+    g.CG = d.Cout_p / g.CH;
+    g.R = 256 / g.CG;
+    g.strips = ceil_div(d.Wo, g.WT);
+    g.bpc = ceil_div((long)ceil_div(d.To, g.Tc) * d.Ho * g.strips, g.R);
+    if (dw2_lds_bytes(g.R, d.Cout_p) > 64 * 1024) return Dw2Geom{0, 0, 0, 0, 0, 0, 0, 0};
+    return g;
+}
+
+int launch_dw_march2(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
+                     const pasn_conv_desc& d, const Dw2Geom& g, hipStream_t s) {
+    const dim3 grid(g.bpc * d.N), block(g.CG * g.R);
+    const size_t lds = dw2_lds_bytes(g.R, d.Cout_p);
+    const unsigned xbytes = (unsigned)((long)d.N * d.Ti * d.Hi * d.Wi * d.Cin_p * 2);
+#define PASN_DW2(SW_, WT_, CH_, OCC_)                                                                                           \
+    if (d.sw == SW_ && g.WT == WT_ && g.CH == CH_) {                                                                              \
+        hipLaunchKernelGGL((dwconv3d_march2_kernel<SW_, WT_, CH_, OCC_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
+                           (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, xbytes);                                       \
+        return check_launch("dwconv3d_march2_kernel");                                                                           \
+    }
+    PASN_DW2(1, 3, 8, 2)
+    PASN_DW2(1, 2, 8, 2)
+    PASN_DW2(1, 4, 4, 3)
+    PASN_DW2(1, 6, 4, 2)
+    PASN_DW2(1, 3, 4, 3)
+    PASN_DW2(2, 2, 8, 2)
+    PASN_DW2(2, 3, 4, 2)
+    PASN_DW2(2, 2, 4, 3)
+#undef PASN_DW2
+    set_error("launch_dw_march2: no instance for this geometry");
+    return PASN_ERR_ARG;
+}
+
+}  // namespace pasn

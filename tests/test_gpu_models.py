@@ -207,10 +207,11 @@ def test_data_writes_and_cache_invalidation():
     m = _gpu(CFG_VIDEO_X3D)
     x = synth.echo_clips((1, 3, 4, 64, 64)).to(DEV)
     with torch.no_grad():
-        l0, s0, _ = (t.clone() for t in m(x))
+        feats = m.push_forward(x)[0].clone()  # (N, P, D): what the prototypes are compared with
         m.prototype_vectors.data.copy_(torch.flip(m.prototype_vectors.data, dims=(0,)))
         l1, s1, _ = (t.clone() for t in m(x))
-        assert_close(s1, torch.flip(s0, dims=(1,)), 1e-6, 0, "prototype_vectors.data write is seen at once")
+        want = (torch.nn.functional.cosine_similarity(feats, m.prototype_vectors.data.flatten(1)[None], dim=2) + 1) / 2
+        assert_close(s1, want, 1e-6, 0, "prototype_vectors.data write is seen at once")
         m.last_layer.weight.data.mul_(3.0)
         l2 = m(x)[0].clone()
         assert_close(l2, 3 * l1, 1e-5, 1e-5, "last_layer.weight.data write is seen at once")
