@@ -82,6 +82,13 @@ struct DwMarchGeom {
 DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
                     const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s);
+// dwmarch2.hip: second-generation T-marching stencil (weight double buffer, buffer-load padding, 4 or 8 channels per thread)
+struct Dw2Geom {
+    int CH, WT, OCC, CG, R, strips, Tc, bpc;
+};
+Dw2Geom dw_march2_geom(const pasn_conv_desc& d, int dtype);
+int launch_dw_march2(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
+                     const pasn_conv_desc& d, const Dw2Geom& g, hipStream_t s);
 template <typename T>
 int launch_gemm_pw(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                    void* y, const pasn_conv_desc& d, hipStream_t s);

@@ -808,6 +808,8 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int has_g
 
 extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    const Dw2Geom m2 = dw_march2_geom(*d, dtype);
+    if (m2.WT) return 40000 + m2.CH * 1000 + m2.WT * 10 + d->sw;  // dwconv3d_march2_kernel<SW, WT, CH>
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return 3000 + m.WT * 10 + d->sw;  // dwconv3d_march_kernel<SW, WT>
     const DwGeom g = dw_geom(*d);
@@ -816,6 +818,8 @@ extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
 
 extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    const Dw2Geom m2 = dw_march2_geom(*d, dtype);
+    if (m2.WT) return m2.bpc;
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return m.bpc;
     return dw_geom(*d).blocks;
@@ -827,6 +831,8 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     PASN_REQUIRE(conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
     PASN_REQUIRE(d->Cin == d->Cout && d->Cin_p == d->Cout_p, "depthwise conv keeps the channel count");
     hipStream_t s = (hipStream_t)stream;
+    const Dw2Geom m2 = dw_march2_geom(*d, dtype);
+    if (m2.WT) return launch_dw_march2(x, w, scale, bias, y, pool_partial, *d, m2, s);
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return launch_dw_march(x, w, scale, bias, y, pool_partial, *d, m, s);
     if (dtype == PASN_F32) return launch_dwconv3d<float>(x, w, scale, bias, y, pool_partial, *d, s);

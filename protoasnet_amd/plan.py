@@ -317,7 +317,9 @@ class PlanBuilder:
         self._use(xb, yb, pb)
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
-        if dv >= 3000:
+        if dv >= 40000:
+            kname = f"dwconv3d_march2_kernel<{dv % 10},{dv // 10 % 100},{dv // 1000 % 10}>"
+        elif dv >= 3000:
             kname = f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>"
         elif dv:
             kname = f"dwconv3d_strip_kernel<{self.tname},{dv // 100},{dv // 10 % 10},{dv % 10}>"

@@ -348,12 +348,70 @@ DW_CASES = [
 ]
 
 
+def _march_case(stride, c, dtype=torch.bfloat16):
+    torch.manual_seed(11)
+    n, thw = 2, (9, 11, 13) if stride == 1 else (9, 14, 22)
+    x = torch.randn(n, c, *thw)
+    conv = nn.Conv3d(c, c, 3, (1, stride, stride), 1, groups=c, bias=False)
+    bn = nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    pre = bn(conv(_rt(x, dtype))).detach()
+    return x, conv, bn, pre
+
+
+def _run_march(x, conv, bn, act, dtype=torch.bfloat16):
+    pb = _pb(dtype)
+    xa, xs = _cl_input(pb, x, dtype)
+    y, pooled = pb.dwconv(xa, conv.to(DEV), bn.to(DEV), act, pool=True)
+    pool_buf, pool_blocks, _ = pooled
+    pb.bufs[pool_buf].external = True
+    plan = pb.finish(xa, y)
+    part = torch.empty(x.shape[0], pool_blocks, y.Cp, dtype=torch.float32, device=DEV)
+    plan.ptrs[pool_buf] = part.data_ptr()
+    out = plan.run(xs)
+    torch.cuda.synchronize()
+    return out, part, pb.meta[-1]["kernel"]
+
+
+@pytest.mark.parametrize("c", [56, 108, 432])
+@pytest.mark.parametrize("inst", ["1:8,3", "1:8,2", "1:4,4", "1:4,6", "1:4,3", "2:8,2", "2:4,3", "2:4,2"])
+@pytest.mark.parametrize("tc", [4, 16])
+def test_dwconv3d_march2_instances(inst, tc, c, monkeypatch):
+    """Second-generation T-marching stencil: every (channels per thread, outputs per strip) instance, with and without T chunks, on
+    ragged shapes (T = 9, W not a multiple of any strip width), 56 / 108 / 432 channels (weight-row strides 64 / 128 / 512, a channel
+    count that is not a multiple of 8 values per group included), Swish epilogue and SE partial sums -- against torch, and
+    BIT-IDENTICAL to round 1's kernel (same fp32 summation order per output element)."""
+    stride, chwt = inst.split(":")
+    stride = int(stride)
+    x, conv, bn, pre = _march_case(stride, c)
+    ref = pre * torch.sigmoid(pre)
+    monkeypatch.setenv("PASN_DWM2", f"{chwt},{tc}")
+    out, part, kernel = _run_march(x, conv, bn, "swish")
+    ch, wt = chwt.split(",")
+    assert kernel == f"dwconv3d_march2_kernel<{stride},{wt},{ch}>", kernel
+    atol, rtol = _tols(torch.bfloat16)
+    assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"march2 {inst} tc{tc} c{c}")
+    want = pre.sum(dim=(2, 3, 4))
+    assert_close(part.sum(dim=1)[:, :c].cpu(), want, 2e-2 * float(want.abs().max()), 0, "SE partial sums")
+    assert float(out[..., c:].abs().max() if out.shape[-1] > c else 0.0) == 0.0, "padded channels must stay zero"
+    monkeypatch.setenv("PASN_DWM2", "0")
+    out1, _, kernel1 = _run_march(x, conv, bn, "swish")
+    assert kernel1.startswith("dwconv3d_march_kernel<")
+    assert torch.equal(out, out1), "march2 must reproduce round 1's stencil bit for bit"
+
+
 @pytest.mark.parametrize("wt", [2, 3])
 @pytest.mark.parametrize("tc", [4, 8, 16])
 @pytest.mark.parametrize("stride", [1, 2])
 def test_dwconv3d_march_variants(stride, tc, wt, monkeypatch):
     """T-marching stencil: every (outputs per strip, T chunk) instance on a shape with T = 9 (chunk halos, a partial last
     chunk), ragged W for both strip widths and SE partial sums; the cost model's own choice is covered by DW_CASES."""
+    monkeypatch.delenv("PASN_DWM2", raising=False)  # the default kernel (the second-generation one is opt-in)
     monkeypatch.setenv("PASN_DWM_WT", str(wt))
     monkeypatch.setenv("PASN_DWM_TC", str(tc))
     dtype = torch.bfloat16
