@@ -107,6 +107,9 @@ def parse():
                     help="forward = the BASELINE.json headline metric (default); train = config 3's training step (tools/train_bench.py)")
     ap.add_argument("--train-loss", default="reference", choices=["reference", "simple"], help="--mode train: the reference's loss recipe "
                     "(incl. TransformLoss's second trunk pass) or a single-pass loss")
+    ap.add_argument("--input", default="clip3", choices=["clip3", "grey"], help="clip3 = the reference's (N,3,T,H,W) clip (the headline "
+                    "metric); grey = the single-channel clip of the device-side input pipeline (protoasnet_amd.data): an extra, "
+                    "labelled as such in config.workload")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal for the CPU test suite: ranks, process group, "
                     "barriers, MAX-over-ranks timing and the JSON line, with NO device work (the metric says so)")
     return ap.parse_args()
@@ -143,6 +146,8 @@ def main():
     shape = (args.batch, 3, args.frames, args.size, args.size)
     x_cpu = synth.echo_clips(shape, seed=synth.DEFAULT_SEED + rank)
     x = x_cpu.to(dev).to(dtype)  # resident in HBM before the timed region
+    if args.input == "grey":  # one (already normalised) channel: the first layer runs with weights summed over the input channels
+        x = x[:, :1].contiguous()
     trunk = model.cnn_backbone
 
     def step():
@@ -215,7 +220,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"Video ProtoASNet forward, {args.arch} trunk + prototype layer (P={args.prototypes}, D=256, "
-                               f"K={args.classes}), {args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU",
+                               f"K={args.classes}), {args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU"
+                               + (" [single-channel grey input: device-side input pipeline, NOT the headline configuration]" if args.input == "grey" else ""),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent clips, no collective)"},
     }
 

@@ -32,7 +32,7 @@ extern "C" {
 
 #define PASN_VERSION 100 /* round 1 */
 
-enum { PASN_F32 = 0, PASN_BF16 = 1 };
+enum { PASN_F32 = 0, PASN_BF16 = 1, PASN_U8 = 2 /* input clips of the *_gray_fwd entry points only */ };
 enum { PASN_ACT_NONE = 0, PASN_ACT_RELU = 1, PASN_ACT_SIGMOID = 2, PASN_ACT_SWISH = 3, PASN_ACT_ABS = 4 };
 enum { PASN_OK = 0, PASN_ERR_ARG = 1, PASN_ERR_LAUNCH = 2, PASN_ERR_UNSUPPORTED = 3 };
 
@@ -80,6 +80,20 @@ int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const
 int pasn_x3d_stem_supported(const pasn_conv_desc* d);
 int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias, void* y,
                       const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream);
+
+/*
+ * Device side of the input pipeline.  The reference dataloader resizes a single-channel cine on the host,
+ * normalises it ((x - 0.099) / 0.171, as_dataloader.py:180-182), repeats it to 3 identical channels (:168-170) and ships fp32
+ * (N,3,T,H,W).  These two entry points take the SINGLE channel instead -- planar [N][1][Ti][Hi][Wi], fp32 / bf16 / uint8 -- apply
+ * x' = x * in_a + in_b while loading (in_a = 1/std or 1/(255 std), in_b = -mean/std; 1, 0 for an already normalised clip) and use
+ * first-conv weights summed over the three input channels: w [kh*kw][Cout_p] / w_xy [9][24].  Zero padding pads the normalised
+ * tensor, as in the reference.  Same outputs as the 3-channel entry points fed the expanded clip, up to fp32 summation order.
+ * d->Cin must be 1.
+ */
+int pasn_first_conv_gray_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                             const pasn_conv_desc* d, int in_dtype, int out_dtype, float in_a, float in_b, void* stream);
+int pasn_x3d_stem_gray_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias, void* y,
+                           const pasn_conv_desc* d, int in_dtype, int out_dtype, float in_a, float in_b, void* stream);
 
 /*
  * Dense convolution as an implicit GEMM on the matrix cores (MFMA), channels-last, groups=1, any

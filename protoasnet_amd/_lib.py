@@ -9,7 +9,7 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_long, c_size_t, c_void_p
 
-F32, BF16 = 0, 1
+F32, BF16, U8 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "swish": 3, "abs": 4}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libprotoasnet_amd.so")
@@ -31,6 +31,8 @@ SIGNATURES = {
     "pasn_version": (c_int, []),
     "pasn_last_error": (c_char_p, []),
     "pasn_first_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
+    "pasn_first_conv_gray_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_float, c_float, c_void_p]),
+    "pasn_x3d_stem_gray_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_float, c_float, c_void_p]),
     "pasn_x3d_stem_supported": (c_int, [POINTER(ConvDesc)]),
     "pasn_x3d_stem_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
     "pasn_conv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
@@ -113,6 +115,8 @@ def dtype_code(dtype) -> int:
         return F32
     if dtype == torch.bfloat16:
         return BF16
+    if dtype == torch.uint8:
+        return U8  # input clips of the grey first-layer entry points only
     raise TypeError(f"protoasnet_amd kernels compute in float32 or bfloat16, not {dtype}")
 
 

@@ -15,9 +15,12 @@ namespace pasn {
 template <typename TIN, typename TOUT, int COP>
 __global__ __launch_bounds__(256) void first_conv_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
-                                                         TOUT* __restrict__ y, pasn_conv_desc d) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [3*kh*kw][COP]
-    const int taps = 3 * d.kh * d.kw;
+                                                         TOUT* __restrict__ y, pasn_conv_desc d, float in_a, float in_b) {
+    // d.Cin planar input channels: 3 (the reference dataloader's clip) or 1 (a grey clip whose three channels would be identical:
+    // the caller passes weights summed over the input channels).  Every loaded value goes through x' = x * in_a + in_b (the device
+    // side of as_dataloader.py:180-182's normalisation; 1, 0 = none); zero padding pads the NORMALISED tensor, as the reference does.
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cin*kh*kw][COP]
+    const int taps = d.Cin * d.kh * d.kw;
     for (int i = threadIdx.x; i < taps * COP; i += blockDim.x) wl[i] = w[i];
     __syncthreads();
 
@@ -36,15 +39,15 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const TIN* __restrict__
     for (int c = 0; c < COP; ++c) acc[c] = 0.0f;
 
     const long plane = (long)d.Hi * d.Wi;
-    for (int ci = 0; ci < 3; ++ci) {
-        const TIN* xp = x + (((long)n * 3 + ci) * d.Ti + t) * plane;
+    for (int ci = 0; ci < d.Cin; ++ci) {
+        const TIN* xp = x + (((long)n * d.Cin + ci) * d.Ti + t) * plane;
         for (int kr = 0; kr < d.kh; ++kr) {
             const int hi = ho * d.sh - d.ph + kr;
             if (hi < 0 || hi >= d.Hi) continue;
             for (int ks = 0; ks < d.kw; ++ks) {
                 const int wi = wo * d.sw - d.pw + ks;
                 if (wi < 0 || wi >= d.Wi) continue;
-                const float xv = (float)xp[(long)hi * d.Wi + wi];
+                const float xv = fmaf((float)xp[(long)hi * d.Wi + wi], in_a, in_b);
                 const float* wr = wl + ((ci * d.kh + kr) * d.kw + ks) * COP;
 #pragma unroll
                 for (int c = 0; c < COP; c += 4) {
@@ -71,14 +74,14 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const TIN* __restrict__
 
 template <typename TIN, typename TOUT>
 static int launch_first_conv(const void* x, const float* w, const float* scale, const float* bias, void* y,
-                             const pasn_conv_desc& d, hipStream_t s) {
+                             const pasn_conv_desc& d, float in_a, float in_b, hipStream_t s) {
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const dim3 grid(ceil_div(M, 256)), block(256);
-    const size_t lds = (size_t)3 * d.kh * d.kw * d.Cout_p * sizeof(float);
+    const size_t lds = (size_t)d.Cin * d.kh * d.kw * d.Cout_p * sizeof(float);
 #define PASN_FC(COP)                                                                                          \
     case COP:                                                                                                  \
         hipLaunchKernelGGL((first_conv_kernel<TIN, TOUT, COP>), grid, block, lds, s, (const TIN*)x, w, scale, \
-                           bias, (TOUT*)y, d);                                                                 \
+                           bias, (TOUT*)y, d, in_a, in_b);                                                     \
         break;
     switch (d.Cout_p) {
         PASN_FC(8)
@@ -734,19 +737,34 @@ static bool prefer_xtile(const pasn_conv_desc& d, int dtype, bool has_gate) {
     return (d.Cout_p + 31) / 32 >= 2;
 }
 
-extern "C" int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
-                                   const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream) {
+static int first_conv_dispatch(const void* x, const float* w, const float* scale, const float* bias, void* y, const pasn_conv_desc* d,
+                               int in_dtype, int out_dtype, float in_a, float in_b, void* stream) {
     PASN_REQUIRE(x && w && scale && bias && y && d, "null pointer");
-    PASN_REQUIRE(d->N > 0 && d->Cin == 3 && d->kt == 1 && d->st == 1 && d->pt == 0 && d->To == d->Ti, "first conv is (1,kh,kw) over 3 planar channels");
+    PASN_REQUIRE(d->N > 0 && (d->Cin == 3 || d->Cin == 1) && d->kt == 1 && d->st == 1 && d->pt == 0 && d->To == d->Ti,
+                 "first conv is (1,kh,kw) over 3 (or 1, grey) planar channels");
     PASN_REQUIRE(d->Cout_p % 8 == 0 && d->Cout_p >= d->Cout, "Cout_p must be a multiple of 8");
-    PASN_REQUIRE((size_t)3 * d->kh * d->kw * d->Cout_p * 4 <= 64 * 1024, "first conv weights exceed the LDS tile");
+    PASN_REQUIRE((size_t)d->Cin * d->kh * d->kw * d->Cout_p * 4 <= 64 * 1024, "first conv weights exceed the LDS tile");
     hipStream_t s = (hipStream_t)stream;
-    if (in_dtype == PASN_F32 && out_dtype == PASN_F32) return launch_first_conv<float, float>(x, w, scale, bias, y, *d, s);
-    if (in_dtype == PASN_F32 && out_dtype == PASN_BF16) return launch_first_conv<float, __bf16>(x, w, scale, bias, y, *d, s);
-    if (in_dtype == PASN_BF16 && out_dtype == PASN_BF16) return launch_first_conv<__bf16, __bf16>(x, w, scale, bias, y, *d, s);
-    if (in_dtype == PASN_BF16 && out_dtype == PASN_F32) return launch_first_conv<__bf16, float>(x, w, scale, bias, y, *d, s);
+    if (in_dtype == PASN_F32 && out_dtype == PASN_F32) return launch_first_conv<float, float>(x, w, scale, bias, y, *d, in_a, in_b, s);
+    if (in_dtype == PASN_F32 && out_dtype == PASN_BF16) return launch_first_conv<float, __bf16>(x, w, scale, bias, y, *d, in_a, in_b, s);
+    if (in_dtype == PASN_BF16 && out_dtype == PASN_BF16) return launch_first_conv<__bf16, __bf16>(x, w, scale, bias, y, *d, in_a, in_b, s);
+    if (in_dtype == PASN_BF16 && out_dtype == PASN_F32) return launch_first_conv<__bf16, float>(x, w, scale, bias, y, *d, in_a, in_b, s);
+    if (in_dtype == PASN_U8 && out_dtype == PASN_F32) return launch_first_conv<unsigned char, float>(x, w, scale, bias, y, *d, in_a, in_b, s);
+    if (in_dtype == PASN_U8 && out_dtype == PASN_BF16) return launch_first_conv<unsigned char, __bf16>(x, w, scale, bias, y, *d, in_a, in_b, s);
     set_error("pasn_first_conv_fwd: unknown dtype");
     return PASN_ERR_ARG;
+}
+
+extern "C" int pasn_first_conv_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                                   const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream) {
+    PASN_REQUIRE(d && d->Cin == 3, "pasn_first_conv_fwd reads 3 planar channels (pasn_first_conv_gray_fwd reads one)");
+    return first_conv_dispatch(x, w, scale, bias, y, d, in_dtype, out_dtype, 1.0f, 0.0f, stream);
+}
+
+extern "C" int pasn_first_conv_gray_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
+                                        const pasn_conv_desc* d, int in_dtype, int out_dtype, float in_a, float in_b, void* stream) {
+    PASN_REQUIRE(d && d->Cin == 1, "pasn_first_conv_gray_fwd reads ONE planar channel");
+    return first_conv_dispatch(x, w, scale, bias, y, d, in_dtype, out_dtype, in_a, in_b, stream);
 }
 
 extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,

@@ -11,10 +11,14 @@
 
 namespace pasn {
 
-template <typename TIN, typename T, int COP>
+// CIN = 3: the reference's clip.  CIN = 1: a grey clip (the three channels of an echo clip are identical, as_dataloader.py:168-170), w_xy
+// holds the 9 taps summed over the input channels: a third of the input bytes and of the spatial FMAs.  x' = x * in_a + in_b is applied
+// to every loaded value (device-side normalisation, as_dataloader.py:180-182; 1, 0 = none); padding pads the normalised tensor.
+template <typename TIN, typename T, int COP, int CIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void x3d_stem_kernel(const TIN* __restrict__ x, const float* __restrict__ wxy,
                                                        const float* __restrict__ wt, const float* __restrict__ scale,
-                                                       const float* __restrict__ bias, T* __restrict__ y, pasn_conv_desc d) {
+                                                       const float* __restrict__ bias, T* __restrict__ y, pasn_conv_desc d,
+                                                       float in_a, float in_b) {
     // The 27 x COP spatial weights are wave-uniform with compile-time offsets: read with s_load through the scalar cache
     // and fed to v_pk_fma as SGPR operands -- no LDS traffic, no vector registers.  The temporal weights + scale + bias
     // (7 x COP floats) come from LDS as broadcast reads instead: as scalars they did not fit next to the spatial ones, and
@@ -60,13 +64,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void x
 #pragma unroll
         for (int c = 0; c < COP; ++c) acc[c] = 0.0f;
         if (t < T_) {
-            float xv[27];
+            float xv[9 * CIN];
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const TIN* xp = x + (((long)n * 3 + ci) * T_ + t) * plane;
+            for (int ci = 0; ci < CIN; ++ci) {
+                const TIN* xp = x + (((long)n * CIN + ci) * T_ + t) * plane;
 #pragma unroll
                 for (int q = 0; q < 9; ++q) {  // unconditional load (clamped), select after: no per-tap branches
-                    const float v = (float)xp[off[q] >= 0 ? off[q] : 0];
+                    const float v = fmaf((float)xp[off[q] >= 0 ? off[q] : 0], in_a, in_b);
                     xv[ci * 9 + q] = off[q] >= 0 ? v : 0.0f;
                 }
             }
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void x
 #pragma unroll
             for (int c = 0; c < COP; ++c) wc[c] = wq[c];
 #pragma unroll
-            for (int q = 0; q < 27; ++q) {
-                if (q + 1 < 27) {
+            for (int q = 0; q < 9 * CIN; ++q) {
+                if (q + 1 < 9 * CIN) {
 #pragma unroll
                     for (int c = 0; c < COP; ++c) wn[c] = wq[(q + 1) * COP + c];
                 }
@@ -138,27 +142,48 @@ extern "C" int pasn_x3d_stem_supported(const pasn_conv_desc* d) {
     if (!d) return 0;
     if (const char* e = getenv("PASN_NO_STEM"))
         if (e[0] == '1') return 0;
-    return d->Cin == 3 && d->kt == 1 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 0 &&
+    return (d->Cin == 3 || d->Cin == 1) && d->kt == 1 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 0 &&
            d->ph == 1 && d->pw == 1 && d->To == d->Ti && d->Cout_p == 24 && d->Cout <= 24;
 }
 
-extern "C" int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias,
-                                 void* y, const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream) {
+static int stem_dispatch(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias, void* y,
+                         const pasn_conv_desc* d, int in_dtype, int out_dtype, float in_a, float in_b, void* stream) {
     PASN_REQUIRE(x && w_xy && w_t && scale && bias && y && d, "null pointer");
     PASN_REQUIRE(pasn_x3d_stem_supported(d), "geometry is not the X3D stem ((1,3,3) s(1,2,2) p(0,1,1), 24 channels)");
     const long P = (long)d->N * d->Ho * d->Wo;
     const dim3 grid(ceil_div(P, 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define PASN_ST(TIN, T) \
-    hipLaunchKernelGGL((x3d_stem_kernel<TIN, T, 24>), grid, block, 0, s, (const TIN*)x, w_xy, w_t, scale, bias, (T*)y, *d)
-    if (in_dtype == PASN_F32 && out_dtype == PASN_F32) PASN_ST(float, float);
-    else if (in_dtype == PASN_F32 && out_dtype == PASN_BF16) PASN_ST(float, __bf16);
-    else if (in_dtype == PASN_BF16 && out_dtype == PASN_BF16) PASN_ST(__bf16, __bf16);
-    else if (in_dtype == PASN_BF16 && out_dtype == PASN_F32) PASN_ST(__bf16, float);
+#define PASN_ST(TIN, T, CIN) \
+    hipLaunchKernelGGL((x3d_stem_kernel<TIN, T, 24, CIN>), grid, block, 0, s, (const TIN*)x, w_xy, w_t, scale, bias, (T*)y, *d, in_a, in_b)
+#define PASN_ST2(TIN, T)         \
+    do {                         \
+        if (d->Cin == 3) PASN_ST(TIN, T, 3); \
+        else PASN_ST(TIN, T, 1); \
+    } while (0)
+    if (in_dtype == PASN_F32 && out_dtype == PASN_F32) PASN_ST2(float, float);
+    else if (in_dtype == PASN_F32 && out_dtype == PASN_BF16) PASN_ST2(float, __bf16);
+    else if (in_dtype == PASN_BF16 && out_dtype == PASN_BF16) PASN_ST2(__bf16, __bf16);
+    else if (in_dtype == PASN_BF16 && out_dtype == PASN_F32) PASN_ST2(__bf16, float);
+    else if (in_dtype == PASN_U8 && out_dtype == PASN_BF16 && d->Cin == 1) PASN_ST(unsigned char, __bf16, 1);
+    else if (in_dtype == PASN_U8 && out_dtype == PASN_F32 && d->Cin == 1) PASN_ST(unsigned char, float, 1);
     else {
         set_error("pasn_x3d_stem_fwd: unknown dtype");
         return PASN_ERR_ARG;
     }
+#undef PASN_ST2
 #undef PASN_ST
     return check_launch("x3d_stem_kernel");
+}
+
+extern "C" int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias,
+                                 void* y, const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream) {
+    PASN_REQUIRE(d && d->Cin == 3, "pasn_x3d_stem_fwd reads 3 planar channels (pasn_x3d_stem_gray_fwd reads one)");
+    return stem_dispatch(x, w_xy, w_t, scale, bias, y, d, in_dtype, out_dtype, 1.0f, 0.0f, stream);
+}
+
+extern "C" int pasn_x3d_stem_gray_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias,
+                                      void* y, const pasn_conv_desc* d, int in_dtype, int out_dtype, float in_a, float in_b,
+                                      void* stream) {
+    PASN_REQUIRE(d && d->Cin == 1, "pasn_x3d_stem_gray_fwd reads ONE planar channel");
+    return stem_dispatch(x, w_xy, w_t, scale, bias, y, d, in_dtype, out_dtype, in_a, in_b, stream);
 }

@@ -258,6 +258,9 @@ class PPNet(nn.Module):
 
         if not x.is_cuda:
             raise RuntimeError("protoasnet_amd models run on the GPU only; there is no CPU fallback")
+        if x.shape[1] != 3:
+            raise NotImplementedError("the training pass takes the reference's 3-channel clip; single-channel (grey) input is an "
+                                      "eval-mode path (protoasnet_amd.data.DeviceClipPipeline)")
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         x = x.contiguous()
@@ -323,6 +326,9 @@ class _XProtoHeadMixin:
 
         if not x.is_cuda:
             raise RuntimeError("protoasnet_amd models run on the GPU only; there is no CPU fallback")
+        if x.shape[1] != 3:
+            raise NotImplementedError("the training pass takes the reference's 3-channel clip; single-channel (grey) input is an "
+                                      "eval-mode path (protoasnet_amd.data.DeviceClipPipeline)")
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         x = x.contiguous()

@@ -94,8 +94,9 @@ def pack_conv_weight(w: torch.Tensor, cin_p: int, dtype: torch.dtype) -> Tuple[t
 
 
 class PlanBuilder:
-    def __init__(self, device: torch.device, dtype: torch.dtype, in_dtype: torch.dtype):
+    def __init__(self, device: torch.device, dtype: torch.dtype, in_dtype: torch.dtype, in_affine: Tuple[float, float] = (1.0, 0.0)):
         self.device, self.dtype, self.in_dtype = device, dtype, in_dtype
+        self.in_affine = (float(in_affine[0]), float(in_affine[1]))  # x' = x * a + b on a grey (1-channel) input clip
         self.es = 2 if dtype == torch.bfloat16 else 4
         self.code = _lib.dtype_code(dtype)
         self.bufs: List[_Buf] = []
@@ -121,8 +122,14 @@ class PlanBuilder:
             t = 1
         else:
             n, c, t, h, w = shape
-        in_es = 2 if self.in_dtype == torch.bfloat16 else 4
+        in_es = self._in_es()
         return Act(n, t, h, w, c, c, self._new_buf(n * c * t * h * w * in_es, external=True), planar=True)
+
+    def _in_es(self) -> int:
+        return {torch.bfloat16: 2, torch.uint8: 1}.get(self.in_dtype, 4)
+
+    def _in_name(self) -> str:
+        return {torch.bfloat16: "bf16", torch.uint8: "u8"}.get(self.in_dtype, "f32")
 
     def _out_act(self, x: Act, cout: int, k, s, p) -> Act:
         to = (x.T + 2 * p[0] - k[0]) // s[0] + 1
@@ -159,27 +166,34 @@ class PlanBuilder:
 
     # ---- ops -------------------------------------------------------------------------------------
     def first_conv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str) -> Act:
-        assert x.planar and x.C == 3, "the first conv reads the planar 3-channel clip"
+        assert x.planar and x.C in (1, 3), "the first conv reads the planar 3-channel clip (or its single grey channel)"
         k, s, p = _triple(conv.kernel_size, 1), _triple(conv.stride, 1), _triple(conv.padding, 0)
         assert k[0] == 1 and s[0] == 1 and p[0] == 0, "first conv must be (1, kh, kw)"
         y = self._out_act(x, conv.out_channels, k, s, p)
         w = conv.weight.detach().float()
         if w.dim() == 5:
             w = w[:, :, 0]
-        wp = torch.zeros(3 * k[1] * k[2], y.Cp, dtype=torch.float32, device=self.device)
-        wp[:, : y.C] = w.permute(1, 2, 3, 0).reshape(3 * k[1] * k[2], y.C)
+        if x.C == 1:  # grey clip: the three input channels would be identical, so their taps are summed once here
+            w = w.sum(dim=1, keepdim=True)
+        wp = torch.zeros(x.C * k[1] * k[2], y.Cp, dtype=torch.float32, device=self.device)
+        wp[:, : y.C] = w.permute(1, 2, 3, 0).reshape(x.C * k[1] * k[2], y.C)
         scale, bias = fold_norm(norm, conv.bias, y.C, y.Cp, self.device)
         d = self._desc(x, y, k, s, p, act)
         self.keep += [wp, scale, bias]
-        fn, code_in, code_out = self.lib.pasn_first_conv_fwd, _lib.dtype_code(self.in_dtype), self.code
+        code_in, code_out = _lib.dtype_code(self.in_dtype), self.code
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
         self._use(xb, yb)
-        in_es = 2 if self.in_dtype == torch.bfloat16 else 4
+        in_es = self._in_es()
         out_pos = y.N * y.positions
-        self._note("first_conv", f"first_conv_kernel<{'bf16' if in_es == 2 else 'f32'},{self.tname},{y.Cp}>",
-                   self._touched(x, y, k, s) * 3 * in_es + out_pos * y.C * self.es, 2 * out_pos * y.C * 3 * k[1] * k[2])
-        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, code_out, st)))
+        self._note("first_conv", f"first_conv_kernel<{self._in_name()},{self.tname},{y.Cp}>" + ("[grey]" if x.C == 1 else ""),
+                   self._touched(x, y, k, s) * x.C * in_es + out_pos * y.C * self.es, 2 * out_pos * y.C * x.C * k[1] * k[2])
+        if x.C == 1:
+            fn, (ia, ib) = self.lib.pasn_first_conv_gray_fwd, self.in_affine
+            self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, code_out, ia, ib, st)))
+        else:
+            fn = self.lib.pasn_first_conv_fwd
+            self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, code_out, st)))
         return y
 
     def x3d_stem(self, x: Act, conv_xy: nn.Module, conv_t: nn.Module, norm: nn.Module) -> Act:
@@ -189,27 +203,35 @@ class PlanBuilder:
         c = conv_xy.out_channels
         y = self._out_act(x, c, k, s, p)
         d = self._desc(x, y, k, s, p, "relu")
-        fusable = (x.planar and x.C == 3 and kt == (5, 1, 1) and st_ == (1, 1, 1) and pt_ == (2, 0, 0) and conv_t.groups == c
+        fusable = (x.planar and x.C in (1, 3) and kt == (5, 1, 1) and st_ == (1, 1, 1) and pt_ == (2, 0, 0) and conv_t.groups == c
                    and conv_xy.bias is None and conv_t.bias is None and bool(self.lib.pasn_x3d_stem_supported(ctypes.byref(d))))
         if not fusable:
             self.bufs[y.buf].nbytes = ALIGN  # the buffer reserved above stays unused
             e = self.first_conv(x, conv_xy, None, act="none")
             return self.dwconv(e, conv_t, norm, act="relu")
-        wxy = torch.zeros(27, y.Cp, dtype=torch.float32, device=self.device)
-        wxy[:, :c] = conv_xy.weight.detach().float()[:, :, 0].permute(1, 2, 3, 0).reshape(27, c)
+        wsrc = conv_xy.weight.detach().float()[:, :, 0]
+        if x.C == 1:  # grey clip: taps summed over the three identical input channels (9 instead of 27)
+            wsrc = wsrc.sum(dim=1, keepdim=True)
+        wxy = torch.zeros(9 * x.C, y.Cp, dtype=torch.float32, device=self.device)
+        wxy[:, :c] = wsrc.permute(1, 2, 3, 0).reshape(9 * x.C, c)
         wt = torch.zeros(5, y.Cp, dtype=torch.float32, device=self.device)
         wt[:, :c] = conv_t.weight.detach().float().reshape(c, 5).t()
         scale, bias = fold_norm(norm, None, c, y.Cp, self.device)
         self.keep += [wxy, wt, scale, bias, d]
-        fn, code_in, code_out = self.lib.pasn_x3d_stem_fwd, _lib.dtype_code(self.in_dtype), self.code
+        code_in, code_out = _lib.dtype_code(self.in_dtype), self.code
         a = (wxy.data_ptr(), wt.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
         self._use(xb, yb)
-        in_es = 2 if self.in_dtype == torch.bfloat16 else 4
+        in_es = self._in_es()
         out_pos = y.N * y.positions
-        self._note("stem", f"x3d_stem_kernel<{'bf16' if in_es == 2 else 'f32'},{self.tname},{y.Cp}>",
-                   x.N * 3 * x.positions * in_es + out_pos * c * self.es, 2 * out_pos * c * (27 + 5))
-        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], ptrs[yb], dref, code_in, code_out, st)))
+        self._note("stem", f"x3d_stem_kernel<{self._in_name()},{self.tname},{y.Cp}{',grey' if x.C == 1 else ''}>",
+                   x.N * x.C * x.positions * in_es + out_pos * c * self.es, 2 * out_pos * c * (9 * x.C + 5))
+        if x.C == 1:
+            fn, (ia, ib) = self.lib.pasn_x3d_stem_gray_fwd, self.in_affine
+            self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], ptrs[yb], dref, code_in, code_out, ia, ib, st)))
+        else:
+            fn = self.lib.pasn_x3d_stem_fwd
+            self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], ptrs[yb], dref, code_in, code_out, st)))
         return y
 
     def conv(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, residual: Optional[Act] = None,
@@ -507,6 +529,14 @@ class HipTrunk(nn.Module):
         super().__init__()
         self._plans: Dict[tuple, Tuple[tuple, Plan]] = {}
         self.compute_dtype: Optional[torch.dtype] = None  # None: follow the parameter dtype
+        self.input_affine: Tuple[float, float] = (1.0, 0.0)  # x' = x * a + b applied to a GREY (1-channel) input while loading
+
+    def set_input_normalization(self, mean: Optional[float] = None, std: Optional[float] = None, scale: float = 1.0) -> "HipTrunk":
+        """Device-side normalisation of grey (N,1,...) input clips: x' = (x * scale - mean) / std, fused into the first layer's loads
+        (reference: host-side ``bin_to_norm``, as_dataloader.py:173-182, mean 0.099 / std 0.171; ``scale`` = 1/255 for uint8 clips).
+        ``mean=None`` switches it off (the clip is already normalised).  3-channel inputs are never transformed."""
+        self.input_affine = (1.0, 0.0) if mean is None else (float(scale) / float(std), -float(mean) / float(std))
+        return self
 
     def build_plan(self, pb: PlanBuilder, x: Act) -> Act:  # pragma: no cover - overridden
         raise NotImplementedError
@@ -530,12 +560,12 @@ class HipTrunk(nn.Module):
     def plan_for(self, x: torch.Tensor) -> Plan:
         p0 = next(self.parameters())
         dtype = self.compute_dtype or p0.dtype
-        key = (tuple(x.shape), x.dtype, dtype, x.device)
+        key = (tuple(x.shape), x.dtype, dtype, x.device, self.input_affine if x.shape[1] == 1 else None)
         sig = self._signature()
         hit = self._plans.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
-        pb = PlanBuilder(x.device, dtype, x.dtype)
+        pb = PlanBuilder(x.device, dtype, x.dtype, self.input_affine)
         x_in = pb.input(tuple(x.shape))
         with torch.no_grad():
             y_out = self.build_plan(pb, x_in)
@@ -556,9 +586,12 @@ class HipTrunk(nn.Module):
             )
         if not x.is_cuda:
             raise RuntimeError("protoasnet_amd trunks run on the GPU only (input is on %s); there is no CPU fallback" % x.device)
-        if x.dim() not in (4, 5) or x.shape[1] != 3:
-            raise ValueError("expected (N,3,H,W) or (N,3,T,H,W) input, got %s" % (tuple(x.shape),))
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dim() not in (4, 5) or x.shape[1] not in (1, 3):
+            raise ValueError("expected (N,3,H,W) / (N,3,T,H,W) input -- or the single grey channel (N,1,...) of an echo clip -- got %s"
+                             % (tuple(x.shape),))
+        if x.dtype == torch.uint8 and x.shape[1] != 1:
+            raise ValueError("uint8 clips are accepted as single-channel (N,1,...) input only")
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
             x = x.float()
         x = x.contiguous()
         plan = self.plan_for(x)

@@ -238,3 +238,20 @@ def test_merge_rules_equal_single_sweep():
     b = (torch.tensor([.5, .25]), torch.tensor([[2, 7], [9, 3]]), torch.zeros(2, 2))
     d, idx, vec = merge_ppnet([a, b])
     assert idx.tolist() == [[2, 7], [9, 0]] and vec.tolist() == [[0, 0], [1, 1]]
+
+
+def test_grey_first_layer_identity_on_the_oracle():
+    """Why the grey path is exact: a conv over three identical channels equals the conv of the one channel with the weights summed
+    over the input channels (zero padding included), and the device normalisation x*a+b reproduces bin_to_norm."""
+    import torch.nn.functional as F
+
+    from protoasnet_amd.data import ECHO_MEAN, ECHO_STD, bin_to_norm, gray_to_gray3
+
+    g = torch.Generator().manual_seed(3)
+    u = torch.rand(2, 1, 4, 20, 20, generator=g)
+    w = torch.randn(24, 3, 1, 3, 3, generator=g)
+    x3 = torch.stack([gray_to_gray3(bin_to_norm(c)) for c in u])
+    want = F.conv3d(x3, w, stride=(1, 2, 2), padding=(0, 1, 1))
+    got = F.conv3d(u * (1 / ECHO_STD) + (-ECHO_MEAN / ECHO_STD), w.sum(1, keepdim=True), stride=(1, 2, 2), padding=(0, 1, 1))
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
+    assert tuple(gray_to_gray3(u[0]).shape) == (3, 4, 20, 20) and gray_to_gray3(u[0]).stride(0) == 0  # a view, like the reference's expand

@@ -232,3 +232,45 @@ def test_arena_reuse_on_gpu():
         m(x)
     plan = m.cnn_backbone.plan_for(x)
     assert plan.arena_bytes < 0.25 * plan.naive_bytes, (plan.arena_bytes, plan.naive_bytes)
+
+
+@pytest.mark.parametrize("cfg,shape", [(CFG_VIDEO_X3D, (2, 3, 8, 96, 96)), (CFG_VIDEO_R2P1D, (2, 3, 8, 48, 48)), (CFG_XPROTO, (2, 3, 128, 128))])
+def test_grey_input_pipeline_equals_three_channel_path(cfg, shape):
+    """the single grey channel (fp32, already normalised / raw [0,1] with device-side normalisation / uint8) through the
+    pre-summed first layer == the reference's expanded, host-normalised 3-channel clip.  fp32: <= 1e-6 of the output scale (only
+    the summation order of the first conv differs)."""
+    import numpy as np
+
+    from protoasnet_amd.data import DeviceClipPipeline, bin_to_norm, gray_to_gray3
+
+    m = _gpu(cfg)
+    grey_shape = (shape[0], 1) + tuple(shape[2:])
+    u = torch.from_numpy(np.random.default_rng(5).random(grey_shape, dtype=np.float32))  # [0,1) pixels, one channel
+    x3 = torch.stack([gray_to_gray3(bin_to_norm(c)) for c in u]).float()  # the reference's host pipeline (as_dataloader.py:217-222)
+    assert tuple(x3.shape) == tuple(shape)
+    with torch.no_grad():
+        want = m(x3.to(DEV))
+        pipe = DeviceClipPipeline(m, normalize=True)
+        got = m(pipe(u))                       # raw [0,1] clip, normalised while loading
+        pipe_n = DeviceClipPipeline(m, normalize=False)
+        got_n = m(pipe_n(bin_to_norm(u)))      # already normalised single channel
+    for name, a, b, c in zip(("logits", "similarity", "occurrence_map"), want, got, got_n):
+        scale = max(1.0, float(a.abs().max()))
+        assert_close(b, a, 2e-6 * scale, 2e-6, f"grey+device-normalised {name}")
+        assert_close(c, a, 1e-6 * scale, 1e-6, f"grey pre-normalised {name}")
+    kernels = [meta["kernel"] for meta in m.cnn_backbone.plan_for(pipe_n(bin_to_norm(u))).meta]
+    assert "grey" in kernels[0], kernels[0]
+    # uint8 clips (what a cine is on disk): quantise, compare with the float path fed the same quantised values
+    u8 = (u * 255).round().to(torch.uint8)
+    with torch.no_grad():
+        want8 = m(torch.stack([gray_to_gray3(bin_to_norm(c.float() / 255)) for c in u8]).float().to(DEV))
+        got8 = m(DeviceClipPipeline(m, normalize=True)(u8))
+    for name, a, b in zip(("logits", "similarity"), want8, got8):
+        assert_close(b, a, 5e-6 * max(1.0, float(a.abs().max())), 5e-6, f"uint8 {name}")
+    # the 3-channel path is untouched by the trunk's input normalisation setting
+    with torch.no_grad():
+        again = m(x3.to(DEV))
+    assert torch.equal(again[0], want[0])
+    m.train()
+    with pytest.raises(NotImplementedError, match="3-channel"):
+        m(pipe_n(bin_to_norm(u)))
