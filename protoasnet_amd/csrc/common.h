@@ -82,6 +82,10 @@ struct DwMarchGeom {
 DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
                     const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s);
+// igemm.hip: windowed dense convs (bf16) as an implicit GEMM with direct-to-LDS staging; NT = 0: not covered
+int igemm_nt(const pasn_conv_desc& d, int dtype);
+int launch_igemm(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,
+                 const pasn_conv_desc& d, int nt, hipStream_t s);
 // dwmarch2.hip: second-generation T-marching stencil (weight double buffer, buffer-load padding, 4 or 8 channels per thread)
 struct Dw2Geom {
     int CH, WT, OCC, CG, R, strips, Tc, bpc;

@@ -788,6 +788,8 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
         if (dtype == PASN_F32) return launch_pw_xtile<float>(x, w, scale, bias, residual, gate, y, *d, s);
         return launch_pw_xtile<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
     }
+    if (const int nt = (gate == nullptr && d->w_frag == 0) ? igemm_nt(*d, dtype) : 0)  // windowed dense convs, bf16: direct-to-LDS implicit GEMM
+        return launch_igemm(x, w, scale, bias, residual, y, *d, nt, s);
     if (gemm_pw_applicable(*d, dtype)) {  // large K / N pointwise: LDS-tiled GEMM
         if (dtype == PASN_F32) return launch_gemm_pw<float>(x, w, scale, bias, residual, gate, y, *d, s);
         return launch_gemm_pw<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
@@ -817,6 +819,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int has_g
     if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
     if (pw_xtile_applicable(*d, dtype))               // pwconv_xtile_kernel<dtype, input transform?>
         return 2500 + 2 * pw_xtile_ks(*d, dtype) + ((d->in_swish != 0) ? 1 : 0);
+    if (const int nt = has_gate ? 0 : igemm_nt(*d, dtype)) return 6000 + nt;  // igemm_glds_kernel<NT>
     if (gemm_pw_applicable(*d, dtype))                // gemm_conv_kernel<dtype, pointwise?>
         return 2000 + ((d->kt * d->kh * d->kw == 1 && d->st * d->sh * d->sw == 1) ? 0 : 1);
     int NT, MT;

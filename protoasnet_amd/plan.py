@@ -250,7 +250,7 @@ class PlanBuilder:
         xb, yb, rb, gb, dref = x.buf, y.buf, (residual.buf if residual is not None else None), in_gate, ctypes.byref(d)
         self._use(xb, yb, rb, gb)
         variant = int(self.lib.pasn_conv3d_variant(dref, self.code, int(in_gate is not None)))
-        if variant >= 2500:
+        if 2500 <= variant < 6000:
             # pwconv_xtile_kernel reads its weights as MFMA fragments: store them fragment-major, so a wave's fragment
             # load is one contiguous 1 KB run instead of a 32-row gather (the gather saturated the CU's address unit)
             kstep, ch = (16, 8) if self.dtype == torch.bfloat16 else (8, 4)
@@ -259,7 +259,7 @@ class PlanBuilder:
             a = (wf.data_ptr(), a[1], a[2])
             d.w_frag = 1
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if variant >= 2500 else
+        self._note("conv", f"igemm_glds_kernel<{(variant - 6000) % 10},{(variant - 6000) // 10}>" if variant >= 6000 else f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if 2500 <= variant < 6000 else
                    f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
                    f"pwconv_persist_kernel<{self.tname},{(variant - 1000) // 10},{variant % 10},{'true' if residual is not None else 'false'}>" if variant >= 1000 else
                    f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
