@@ -143,6 +143,15 @@ int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype);
 /* Kernel instance for this geometry: 3000 + WT*10 + SW = dwconv3d_march_kernel<SW, WT> (bf16, 3x3x3, stride (1,s,s));
  * WT*100 + KW*10 + SW = dwconv3d_strip_kernel<dtype, WT, KW, SW>; 0 = generic kernel. */
 int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype);
+/* The same stencil with the squeeze-excite gate of the block fused into the launch (X3D conv_b + SE: global average pool ->
+ * fc1 + ReLU -> fc2 + sigmoid): every block writes its pool partial row, the clip's last-arriving block reduces them and computes
+ * gate[n][:].  Same results as pasn_dwconv3d_fwd followed by pasn_se_gate_fwd up to fp32 summation order (fixed: repeat runs are
+ * bitwise equal).  counter: int32 [N], zero before the FIRST launch (the kernel leaves it zero).  Supported only where
+ * pasn_dwconv3d_se_supported returns 1 (bf16 3x3x3 layers on the T-marching kernel). */
+int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse);
+int pasn_dwconv3d_se_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool_partial,
+                         const pasn_conv_desc* d, int dtype, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                         const float* fc2_b, int Cse, float* gate, int32_t* counter, void* stream);
 int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                       float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream);
 

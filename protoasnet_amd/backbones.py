@@ -15,6 +15,8 @@ buffers -- and replays it.  There is no torch / CPU fallback.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Tuple
 
 import torch
@@ -284,16 +286,21 @@ class X3DFeatures(_plan.HipTrunk):
                 if blk.shortcut is not None:
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
                 act_b = "none" if blk.se is not None else "swish"  # no gate between BN and Swish: the stencil applies Swish
-                if pre is not None:
-                    r = pb.dwconv(pre, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
-                else:  # (an opt-in fused launch keeps the 2.25x-wide tensor between the two convs out of HBM)
-                    r = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
+                fused_front = os.environ.get("PASN_FUSED") == "1" or os.environ.get("PASN_FRONT") == "1"  # opt-in expand+stencil kernels
                 gate = None
-                if blk.se is not None:
-                    y, pooled = r
-                    gate = pb.se_gate(pooled, blk.se.fc1, blk.se.fc2)
+                if blk.se is not None and not fused_front:
+                    e = pre if pre is not None else pb.conv(x, blk.conv_a, blk.bn_a, act="relu")
+                    y, gate = pb.dwconv_se(e, blk.conv_b, blk.bn_b, blk.se.fc1, blk.se.fc2)  # stencil + gate in one launch
                 else:
-                    y = r
+                    if pre is not None:
+                        r = pb.dwconv(pre, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
+                    else:  # (an opt-in fused launch keeps the 2.25x-wide tensor between the two convs out of HBM)
+                        r = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
+                    if blk.se is not None:
+                        y, pooled = r
+                        gate = pb.se_gate(pooled, blk.se.fc1, blk.se.fc2)
+                    else:
+                        y = r
                 # project conv; where the geometry allows, chained in ONE launch with the next block's expand conv
                 nxt = blocks[i + 1] if i + 1 < len(blocks) else None
                 pair = None

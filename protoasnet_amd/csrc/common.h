@@ -80,8 +80,15 @@ struct DwMarchGeom {
     int WT, CG, R, strips, Tc, bpc;  // outputs per strip, channel groups, items per block, strips per row, T chunk, blocks per clip
 };
 DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype);
+// fused squeeze-excite gate (gate == nullptr: off): fc1 [cse][C] + bias, fc2 [C][cse] + bias, gate out [N][Cp], counter [N] ints (zero)
+struct DwSeArgs {
+    const float *w1, *b1, *w2, *b2;
+    float* gate;
+    int* counter;
+    int cse;
+};
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
-                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s);
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
 // igemm.hip: windowed dense convs (bf16) as an implicit GEMM with direct-to-LDS staging; NT = 0: not covered
 int igemm_nt(const pasn_conv_desc& d, int dtype);
 int launch_igemm(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,

@@ -862,6 +862,28 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     return PASN_ERR_ARG;
 }
 
+// Depthwise stencil + squeeze-excite gate in ONE launch (the clip's last-arriving block computes the gate); only where the T-marching
+// stencil covers the layer -- pasn_dwconv3d_se_supported says so, the caller otherwise issues pasn_dwconv3d_fwd + pasn_se_gate_fwd.
+extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse) {
+    if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0 || Cse <= 0) return 0;
+    if (const char* e = getenv("PASN_NO_SE_FUSE"))
+        if (e[0] == '1') return 0;
+    if (dw_march2_geom(*d, dtype).WT) return 0;  // the opt-in second-generation kernel has no fused gate
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    return m.WT != 0 && m.R * d->Cout_p >= d->Cout_p + Cse + 8;  // the gate's LDS scratch is the pool scratch
+}
+
+extern "C" int pasn_dwconv3d_se_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool_partial,
+                                    const pasn_conv_desc* d, int dtype, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                                    const float* fc2_b, int Cse, float* gate, int32_t* counter, void* stream) {
+    PASN_REQUIRE(x && w && scale && bias && y && pool_partial && fc1_w && fc1_b && fc2_w && fc2_b && gate && counter, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(d) && d->Cin == d->Cout && d->Cin_p == d->Cout_p, "depthwise conv keeps the channel count");
+    PASN_REQUIRE(pasn_dwconv3d_se_supported(d, dtype, Cse), "layer not covered by the fused stencil + gate launch");
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    const DwSeArgs se = {fc1_w, fc1_b, fc2_w, fc2_b, gate, counter, Cse};
+    return launch_dw_march(x, w, scale, bias, y, pool_partial, *d, m, (hipStream_t)stream, se);
+}
+
 // Fast path of the gate (C <= 512, Cse <= 32, Cse % 4 == 0 -- every X3D width): the kernel is three dependent round trips
 // (pool partials -> fc1 weights -> fc2 weights) of a few KB each, one block per clip.  Here BOTH weight matrices are
 // requested into registers at kernel entry, before the pool reduction, so the three trips overlap; arithmetic and

@@ -26,7 +26,7 @@ template <int SW, int WT>
 __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
-                                                             int CG, int R, int strips, int Tc, int bpc) {
+                                                             int CG, int R, int strips, int Tc, int bpc, DwSeArgs se) {
     // [27 taps + scale + bias][2 halves][DWM_CGS slots][4] fp32 (fixed slot stride: every tap is an immediate ds_read
     // offset), then [R][Cp] pool scratch
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -220,7 +220,70 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
         for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
             float s = 0.0f;
             for (int q = 0; q < R; ++q) s += red[q * Cp + ch];
-            pool[((long)n * bpc + bx) * Cp + ch] = s;
+            // write-through (sc1) store: with the fused gate below another workgroup reads this row inside the launch
+            __hip_atomic_store(pool + ((long)n * bpc + bx) * Cp + ch, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (se.gate) {
+            // ---- fused squeeze-excite gate: the LAST block of a clip to arrive computes the clip's gate (15 stand-alone 9-13 us
+            // launches per X3D-S forward otherwise).  Placement-independent hand-off (cdna_hip_programming.md Guideline 16, counter
+            // form): partial rows stored write-through, every storing wave drains its stores, the block's barrier, ONE lane adds to
+            // the clip's agent-scope counter; the block that draws bpc - 1 acquires and reads all rows with agent-scope loads.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(red);  // the partial-sum scratch is free again
+            if (threadIdx.x == 0) {
+                const int old = __hip_atomic_fetch_add(se.counter + n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == bpc - 1;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(se.counter + n, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                }
+                *flag = last;
+            }
+            __syncthreads();
+            const int last = *flag;
+            __syncthreads();  // everyone has read the flag before the scratch is reused
+            if (last) {       // block-uniform
+                float* mean = red;
+                float* hid = red + Cp;
+                const int C = d.Cout, Cse = se.cse;
+                const float inv_positions = 1.0f / (float)(d.To * d.Ho * d.Wo);
+                for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {  // fixed order over the clip's partial rows: bitwise reproducible
+                    float s = 0.0f;
+                    const float* pp = pool + (long)n * bpc * Cp + ch;
+                    for (int q0 = 0; q0 < bpc; q0 += 8) {
+                        float t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            t[u] = __hip_atomic_load(pp + (long)min(q0 + u, bpc - 1) * Cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) s += (q0 + u < bpc) ? t[u] : 0.0f;
+                    }
+                    mean[ch] = s * inv_positions;
+                }
+                __syncthreads();
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;  // full waves only
+                if (wave < nw) {
+                    for (int j = wave; j < Cse; j += nw) {
+                        float t = 0.0f;
+                        for (int ch = lane; ch < C; ch += 64) t = fmaf(se.w1[(long)j * C + ch], mean[ch], t);
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+                        if (lane == 0) hid[j] = fmaxf(t + se.b1[j], 0.0f);
+                    }
+                }
+                __syncthreads();
+                for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+                    float g = 0.0f;
+                    if (ch < C) {
+                        float sacc = se.b2[ch];
+                        for (int j = 0; j < Cse; ++j) sacc = fmaf(se.w2[(long)ch * Cse + j], hid[j], sacc);
+                        g = sigmoidf_(sacc);
+                    }
+                    se.gate[(long)n * Cp + ch] = g;
+                }
+            }
         }
     }
 }
@@ -272,12 +335,12 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
 }
 
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
-                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s) {
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se) {
     const dim3 grid(g.bpc * d.N), block(g.CG * g.R);
     const size_t lds = dwm_lds_bytes(g.R, d.Cout_p);
 #define PASN_DWM(SW_, WT_)                                                                                           \
     hipLaunchKernelGGL((dwconv3d_march_kernel<SW_, WT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
-                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc)
+                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, se)
     if (d.sw == 1 && g.WT == 3) PASN_DWM(1, 3);
     else if (d.sw == 1) PASN_DWM(1, 2);
     else if (g.WT == 3) PASN_DWM(2, 3);

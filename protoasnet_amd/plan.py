@@ -357,6 +357,48 @@ class PlanBuilder:
             return y, (pool_buf, pool_blocks, y)
         return y
 
+    def dwconv_se(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], fc1: nn.Module, fc2: nn.Module):
+        """Depthwise 3x3x3 conv + BN (no activation: the gate comes first) + the block's squeeze-excite gate in ONE launch where the
+        T-marching stencil covers the layer (the clip's last-arriving block computes the gate); otherwise the stencil launch followed
+        by the stand-alone gate launch.  Returns (y, gate buffer id)."""
+        assert not x.planar and conv.groups == conv.in_channels == conv.out_channels == x.C
+        k, s, p = _triple(conv.kernel_size, 1), _triple(conv.stride, 1), _triple(conv.padding, 0)
+        probe = ConvDesc(N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=x.C, Cin_p=x.Cp, To=(x.T + 2 * p[0] - k[0]) // s[0] + 1,
+                         Ho=(x.H + 2 * p[1] - k[1]) // s[1] + 1, Wo=(x.W + 2 * p[2] - k[2]) // s[2] + 1, Cout=x.C, Cout_p=x.Cp,
+                         kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2], act=_lib.ACT["none"])
+        cse = fc1.out_channels
+        if not int(self.lib.pasn_dwconv3d_se_supported(ctypes.byref(probe), self.code, cse)):
+            y, pooled = self.dwconv(x, conv, norm, act="none", pool=True)
+            return y, self.se_gate(pooled, fc1, fc2)
+        y = self._out_act(x, x.C, k, s, p)
+        taps = k[0] * k[1] * k[2]
+        wp = torch.zeros(taps, y.Cp, dtype=torch.float32, device=self.device)
+        wp[:, : y.C] = conv.weight.detach().float().reshape(y.C, taps).t()
+        scale, bias = fold_norm(norm, conv.bias, y.C, y.Cp, self.device)
+        d = self._desc(x, y, k, s, p, "none")
+        c = y.C
+        w1 = fc1.weight.detach().float().reshape(cse, c).contiguous()
+        b1 = fc1.bias.detach().float().contiguous()
+        w2 = fc2.weight.detach().float().reshape(c, cse).contiguous()
+        b2 = fc2.bias.detach().float().contiguous()
+        counter = torch.zeros(y.N, dtype=torch.int32, device=self.device)  # zero before the first launch; the kernel leaves it zero
+        self.keep += [wp, scale, bias, w1, b1, w2, b2, counter]
+        pool_blocks = int(self.lib.pasn_dwconv3d_pool_blocks(ctypes.byref(d), self.code))
+        pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4)
+        gate = self._new_buf(y.N * y.Cp * 4)
+        fn, code = self.lib.pasn_dwconv3d_se_fwd, self.code
+        a = tuple(t.data_ptr() for t in (wp, scale, bias, w1, b1, w2, b2, counter))
+        xb, yb, pb_, dref = x.buf, y.buf, pool_buf, ctypes.byref(d)
+        self._use(xb, yb, pb_, gate)
+        out_pos = y.N * y.positions
+        dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
+        self._note("dwconv", f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>+se",
+                   (self._touched(x, y, k, s) + out_pos) * y.C * self.es + (y.N * pool_blocks * y.C * 8 + y.N * c * 4 + 2 * c * cse * 4),
+                   2 * out_pos * y.C * taps + 4 * y.N * c * cse)
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], ptrs[pb_], dref, code, a[3], a[4], a[5], a[6],
+                                                       cse, ptrs[gate], a[7], st)))
+        return y, gate
+
     def expand_dw(self, x: Act, conv_a: nn.Module, norm_a: nn.Module, conv_b: nn.Module, norm_b: nn.Module, act: str,
                   pool: bool = False):
         """X3D front half (1x1x1 expand + BN + ReLU -> depthwise 3x3x3 + BN [+Swish] [+SE partial sums]) as ONE launch;

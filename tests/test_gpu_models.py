@@ -274,3 +274,35 @@ def test_grey_input_pipeline_equals_three_channel_path(cfg, shape):
     m.train()
     with pytest.raises(NotImplementedError, match="3-channel"):
         m(pipe_n(bin_to_norm(u)))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 160, 160), (3, 3, 8, 96, 128)])
+def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkeypatch):
+    """The squeeze-excite gate computed by the clip's last-arriving stencil block (in-launch hand-off: write-through partial rows, an
+    agent-scope arrival counter, acquire on the last arriver) against the stencil launch + stand-alone gate launch: same features up
+    to the fp32 summation order of the pool, bitwise equal across repeated runs (the counters return to zero after every launch, the
+    reduction order is fixed), and every SE layer really takes the fused launch."""
+    x = synth.echo_clips(shape).to(DEV).bfloat16()
+    m = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        runs = [m.cnn_backbone(x).float().clone() for _ in range(6)]
+    meta = m.cnn_backbone.plan_for(x).meta
+    fused = [k["kernel"] for k in meta if k["kernel"].endswith("+se")]
+    assert len(fused) >= 10 and not any(k["kernel"].startswith("se_gate") for k in meta), [k["kernel"] for k in meta]
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0]), "fused gate must be bitwise reproducible"
+    monkeypatch.setenv("PASN_NO_SE_FUSE", "1")
+    m2 = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        ref = m2.cnn_backbone(x).float()
+    assert any(k["kernel"].startswith("se_gate") for k in m2.cnn_backbone.plan_for(x).meta)
+    scale = float(ref.abs().max())
+    assert_close(runs[0], ref, 2e-2 * scale, 2e-2, "fused vs stand-alone SE gate (bf16 activations)")
+    # a last-bit difference in a gate re-rounds bf16 activations downstream, so the two bf16 paths differ by rounding noise; what must
+    # hold is that the fused path is no further from the fp32 path than the stand-alone one
+    m32 = _gpu(CFG_VIDEO_X3D)
+    with torch.no_grad():
+        ref32 = m32.cnn_backbone(x.float()).float()
+    err_fused = float((runs[0] - ref32).abs().mean() / ref32.abs().mean())
+    err_alone = float((ref - ref32).abs().mean() / ref32.abs().mean())
+    assert err_fused < 1.25 * err_alone + 1e-3, (err_fused, err_alone)
