@@ -366,6 +366,20 @@ int pasn_l2_head_bwd(const void* z, const float* protos, const float* fc_w, cons
 int pasn_affine_warp_fwd(const void* x, void* y, long planes, int H, int W, float angle_deg, float scale, int dtype, void* stream);
 int pasn_affine_warp_bwd(const float* dy, float* dx, long planes, int H, int W, float angle_deg, float scale, void* stream);
 
+/*
+ * Data-parallel gradient exchange on RCCL (xGMI), without torch.distributed in the data path: ONE in-place sum all-reduce of the
+ * flat fp32 gradient bucket per optimizer step.  The reference trains on one GPU and has no collective
+ * (SURVEY section 0); these four calls are what a trainer needs around protoasnet_amd/dp.py.  librccl.so is resolved at run time.
+ *   pasn_comm_unique_id : rank 0 fills PASN_COMM_ID_BYTES bytes; the caller ships them to the other ranks (any side channel)
+ *   pasn_comm_init      : every rank, with its HIP device current; *comm_out is an opaque handle
+ *   pasn_allreduce      : buf[count] (dtype PASN_F32 / PASN_BF16) summed over the ranks in place, asynchronous on `stream`
+ */
+#define PASN_COMM_ID_BYTES 128
+int pasn_comm_unique_id(void* id_out);
+int pasn_comm_init(const void* id, int world_size, int rank, void** comm_out);
+int pasn_allreduce(void* comm, void* buf, size_t count, int dtype, void* stream);
+int pasn_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,10 @@ class XProtoDesc(ctypes.Structure):
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "pasn_version": (c_int, []),
+    "pasn_comm_unique_id": (c_int, [c_void_p]),
+    "pasn_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "pasn_allreduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "pasn_comm_destroy": (c_int, [c_void_p]),
     "pasn_last_error": (c_char_p, []),
     "pasn_first_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
     "pasn_first_conv_gray_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_float, c_float, c_void_p]),

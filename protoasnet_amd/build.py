@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ("api.hip", "conv.hip", "pwconv.hip", "gemm_pw.hip", "igemm.hip", "pwconv_xtile.hip", "pwconv_xpair.hip", "x3d_fused.hip", "x3d_front.hip", "stem.hip", "dwmarch.hip", "dwmarch2.hip", "head_l2.hip", "head_xproto.hip", "push.hip", "train.hip", "wgrad.hip", "head_train.hip", "warp.hip")
+SOURCES = ("api.hip", "comm.hip", "conv.hip", "pwconv.hip", "gemm_pw.hip", "igemm.hip", "pwconv_xtile.hip", "pwconv_xpair.hip", "x3d_fused.hip", "x3d_front.hip", "stem.hip", "dwmarch.hip", "dwmarch2.hip", "head_l2.hip", "head_xproto.hip", "push.hip", "train.hip", "wgrad.hip", "head_train.hip", "warp.hip")
 ARCH = "gfx950"
 
 
@@ -55,7 +55,7 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
         objs = list(ex.map(compile_one, SOURCES))
     target = lib_path()
     if force or _stale(target, objs):
-        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs, capture_output=True, text=True)
+        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs + ["-ldl"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     return target

@@ -9,23 +9,84 @@ Norm-layer running statistics stay per rank, as they would under the reference's
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import Iterable, Optional
 
 import torch
 import torch.distributed as dist
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
+from . import _lib
 
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None, average: bool = True) -> int:
+
+class NativeComm:
+    """RCCL communicator driven through the C-ABI (``pasn_comm_*`` / ``pasn_allreduce``): the native call site of the gradient exchange.
+
+    The 128-byte RCCL id is made by rank 0 and reaches the other ranks over the EXISTING ``torch.distributed`` group (any backend: it is
+    a one-off side channel, not the data path); after that ``all_reduce_`` is one ``ncclAllReduce`` on torch's current HIP stream, in
+    place on the flat bucket.  One communicator per process (one process per GPU).  ``world_size == 1`` works without a process group.
+    """
+
+    _instance: Optional["NativeComm"] = None
+
+    def __init__(self, rank: int, world_size: int, device: torch.device):
+        lib = _lib.lib()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            _lib.check(lib.pasn_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world_size > 1:
+            on_device = dist.get_backend() == "nccl"
+            ident = ident.to(device) if on_device else ident
+            dist.broadcast(ident, src=0)
+            ident = ident.cpu()
+        raw = (ctypes.c_ubyte * 128)(*ident.tolist())
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.pasn_comm_init(ctypes.cast(raw, ctypes.c_void_p), world_size, rank, ctypes.byref(handle)))
+        self.handle, self.rank, self.world_size, self.device = handle, rank, world_size, device
+
+    @classmethod
+    def get(cls, device: torch.device) -> "NativeComm":
+        if cls._instance is None:
+            ws = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            rk = dist.get_rank() if ws > 1 else 0
+            cls._instance = cls(rk, ws, device)
+        return cls._instance
+
+    def all_reduce_(self, flat: torch.Tensor) -> torch.Tensor:
+        assert flat.is_cuda and flat.is_contiguous() and flat.dtype in (torch.float32, torch.bfloat16)
+        _lib.check(_lib.lib().pasn_allreduce(self.handle, flat.data_ptr(), flat.numel(), _lib.dtype_code(flat.dtype), _lib.current_stream()))
+        return flat
+
+    def close(self) -> None:
+        if self.handle:
+            _lib.check(_lib.lib().pasn_comm_destroy(self.handle))
+            self.handle = ctypes.c_void_p()
+        if NativeComm._instance is self:
+            NativeComm._instance = None
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None, average: bool = True,
+                        native: Optional[bool] = None) -> int:
     """Sum (or average) ``p.grad`` of every parameter that has one across the ranks of ``group``; returns the bucket size in
-    bytes (0 when not running distributed).  Every rank must hold gradients for the same parameters (they run the same graph)."""
+    bytes (0 when not running distributed).  Every rank must hold gradients for the same parameters (they run the same graph).
+
+    ``native=True`` (or ``PASN_NATIVE_RCCL=1``) sends the bucket through ``pasn_allreduce`` -- RCCL called from the C-ABI library on
+    torch's current stream -- instead of ``torch.distributed.all_reduce``; it needs CUDA gradients and the default (world) group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
+    if native is None:
+        native = os.environ.get("PASN_NATIVE_RCCL") == "1"
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return 0
     flat = _flatten_dense_tensors(grads)
-    if flat.is_cuda and dist.get_backend(group) == "gloo":
+    if native and flat.is_cuda and group is None:
+        NativeComm.get(flat.device).all_reduce_(flat)
+    elif flat.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal only (several ranks sharing one GPU, where RCCL refuses to start): stage the bucket through the host
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

@@ -222,16 +222,18 @@ class PPNet(nn.Module):
         min_d = torch.empty((n, P), dtype=torch.float32, device=dev)
         logits = torch.empty((n, K), dtype=torch.float32, device=dev)
         act = self.prototype_activation_function
-        if act not in ("log", "linear"):
-            raise NotImplementedError("only the 'log' and 'linear' prototype activations run on the HIP path")
         protos, fcw = _f32(self.prototype_vectors), _f32(self.last_layer.weight)
         _lib.check(
             _lib.lib().pasn_l2_head_fwd(
                 z.data_ptr(), protos.data_ptr(), fcw.data_ptr(), _lib.ptr(dist), min_d.data_ptr(), 0, logits.data_ptr(),
-                n, s, D, z.shape[-1], P, K, _lib.dtype_code(z.dtype), 0 if act == "log" else 1, float(self.epsilon),
+                n, s, D, z.shape[-1], P, K, _lib.dtype_code(z.dtype), 1 if act == "linear" else 0, float(self.epsilon),
                 _lib.current_stream(),
             )
         )
+        if act not in ("log", "linear"):
+            # a callable activation (ProtoPNet.py:222-223): the kernel supplies the distance map / global minima, the callable and
+            # the (P x K) last layer run as plain torch ops on the (N, P) minima
+            logits = torch.nn.functional.linear(act(min_d), fcw)
         return logits, min_d, dist
 
     def _l2_convolution(self, x: torch.Tensor) -> torch.Tensor:

@@ -138,13 +138,15 @@ def test_plan_shapes_and_arena(cfg, shape):
                 assert a.offset + a.nbytes <= b.offset or b.offset + b.nbytes <= a.offset, "live buffers overlap"
     assert plan.arena_bytes < (0.6 if cfg["base_architecture"] == "resnet18" else 0.35) * plan.naive_bytes
     n_ops = len(plan.ops)
-    # x3d: fused stem 1 + 26 blocks x (expand, depthwise, project) + 4 shortcuts + 15 SE gates; opt-in fused launches:
+    # x3d: fused stem 1 + 26 blocks x (expand, depthwise, project) + 4 shortcuts; the 15 SE gates ride in their stencil launches
+    # (PASN_NO_SE_FUSE=1: 15 stand-alone gate launches); opt-in fused launches:
     # PASN_FRONT=1 fuses expand + depthwise of the 6 stride-1 blocks of the 7x7 stage, PASN_FUSED=1 of all 26
     fused = 26 if os.environ.get("PASN_FUSED") == "1" else (6 if os.environ.get("PASN_FRONT") == "1" else 0)
     # project conv of block i + expand conv of block i+1 chained in one launch (bf16): the 10 pairs of stage 4
     # (+ the 4 of stage 3 with PASN_XPAIR_ALL=1)
     paired = 0 if os.environ.get("PASN_NO_XPAIR") == "1" or fused else (14 if os.environ.get("PASN_XPAIR_ALL") == "1" else 10)
-    assert n_ops == {"x3d_s": 1 + 26 * 3 - fused - paired + 4 + 15, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
+    gates = 15 if (os.environ.get("PASN_NO_SE_FUSE") == "1" or fused) else 0
+    assert n_ops == {"x3d_s": 1 + 26 * 3 - fused - paired + 4 + gates, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
 
 
 def test_packed_weight_layout():

@@ -81,3 +81,29 @@ def test_bench_gpus2_real_forward_two_ranks_one_card():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["config"]["global_batch"] == 4
     assert line["metric"] == "clips/sec forward" and line["value"] > 0
+
+
+def test_native_rccl_call_site_single_rank():
+    """pasn_comm_* / pasn_allreduce: RCCL called from the C-ABI library (librccl resolved at run time), on torch's current stream.  One
+    card admits a one-rank communicator only (RCCL refuses two ranks on a device): an all-reduce over one rank must return its input,
+    for the fp32 gradient bucket and for bf16, and a second communicator can be made after the first is destroyed."""
+    from protoasnet_amd.dp import NativeComm
+
+    dev = torch.device("cuda", 0)
+    comm = NativeComm(0, 1, dev)
+    g = torch.randn(3_800_000, device=dev)  # the size of the X3D-S + head B gradient bucket
+    want = g.clone()
+    comm.all_reduce_(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    h = torch.randn(4096, device=dev).bfloat16()
+    want_h = h.clone()
+    comm.all_reduce_(h)
+    torch.cuda.synchronize()
+    assert torch.equal(h, want_h)
+    comm.close()
+    comm2 = NativeComm(0, 1, dev)
+    comm2.all_reduce_(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    comm2.close()

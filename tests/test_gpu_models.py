@@ -306,3 +306,20 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
     err_fused = float((runs[0] - ref32).abs().mean() / ref32.abs().mean())
     err_alone = float((ref - ref32).abs().mean() / ref32.abs().mean())
     assert err_fused < 1.25 * err_alone + 1e-3, (err_fused, err_alone)
+
+
+def test_ppnet_callable_prototype_activation():
+    """ProtoPNet.py:217-223: ``prototype_activation_function`` may be a callable on the distances.  The kernel supplies the minima; the
+    callable and the last layer then run in torch -- same logits as the built-in 'log' when the callable is the log formula."""
+    m = _gpu(CFG_PPNET)
+    x = synth.echo_clips((2, 3, 224, 224)).to(DEV)
+    with torch.no_grad():
+        want, min_d = m(x)
+        m.prototype_activation_function = lambda d: torch.log((d + 1) / (d + m.epsilon))
+        got, min_d2 = m(x)
+        assert torch.equal(min_d, min_d2)
+        assert_close(got, want, 1e-5, 1e-5, "callable == built-in log activation")
+        m.prototype_activation_function = lambda d: torch.exp(-d / 64.0)
+        other, _ = m(x)
+        assert_close(other, torch.nn.functional.linear(torch.exp(-min_d / 64.0), m.last_layer.weight), 1e-6, 1e-6, "callable logits")
+        assert_close(m.distance_2_similarity(min_d), torch.exp(-min_d / 64.0), 0, 0, "distance_2_similarity with a callable")
