@@ -69,6 +69,109 @@ __global__ __launch_bounds__(256) void xproto_pool_kernel(const T* __restrict__ 
     }
 }
 
+// Occurrence-weighted pooling on the matrix cores: F[p][d] = sum_s occ[s][p] * f[s][d]  (the reference forms the (N,P,D,S) product,
+// Video_XProtoNet.py:87-88).  The contraction index s is the SLOW index of both channels-last operands, which rules out the bf16
+// MFMA's 8-consecutive-k fragments without a transpose; the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) takes ONE element per lane and
+// operand -- lane (r, k) supplies A[p = r][s0 + k] and B[s0 + k][d = r] -- so both operands are plain loads of 32 consecutive channels
+// of a row, converted to fp32 on the way (exact: fp32 products of bf16 values, fp32 accumulation in s order).  At fp32-MFMA rate the
+// whole pooling of 32 clips x 1568 positions x 64 x 256 is ~10 us of matrix time (round 1's VALU kernel: 41-61 us).
+// grid (G splits of S, groups of 128 feature columns, N), one wave per block; two prototype tiles x four column tiles in accumulators.
+// The wave of column group 0 also writes the planar fp32 occurrence map (N,P,S) the callers get, through a [32 p][64 s] LDS tile.
+template <typename T>
+__global__ __launch_bounds__(64) void xproto_pool_mfma_kernel(const T* __restrict__ occ_cl, const T* __restrict__ f,
+                                                              float* __restrict__ occ_planar, float* __restrict__ ws, int S, int P, int Pp,
+                                                              int D, int Dp, int G, int pbase, int do_pool) {
+    __shared__ float tile[2][32][65];
+    const int lane = threadIdx.x, c = lane & 31, kq = lane >> 5;
+    const int g = blockIdx.x, dg = blockIdx.y, n = blockIdx.z;
+    const int SG = ((S + G - 1) / G + 63) / 64 * 64;  // whole 64-position tiles per split
+    const int sbeg = g * SG, send = min(S, sbeg + SG);
+    const int d0 = dg * 128;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    const bool want_map = occ_planar != nullptr && dg == 0;
+    const int pcol[2] = {min(pbase + c, Pp - 1), min(pbase + 32 + c, Pp - 1)};
+    const bool pok[2] = {pbase + c < P, pbase + 32 + c < P};
+    int dcol[4];
+    bool dok[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        dcol[b] = min(d0 + b * 32 + c, Dp - 1);
+        dok[b] = do_pool && (d0 + b * 32 + c) < D;
+    }
+    // groups of 4 k-steps (8 positions): the 24 loads of group q + 1 are issued BEFORE the 32 MFMAs of group q (register double buffer;
+    // with the loads behind the MFMAs every group paid a full memory round trip: 32 us per launch instead of ~16)
+    auto load_group = [&](int sq, float (&av)[4][2], float (&bv)[4][4]) {  // raw, unconditional, clamped
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long row = (long)n * S + min(sq + 2 * u + kq, S - 1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[u][a] = (float)occ_cl[row * Pp + pcol[a]];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[u][b] = (float)f[row * Dp + dcol[b]];
+        }
+    };
+    auto use_group = [&](int sq, int s0, float (&av)[4][2], float (&bv)[4][4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = sq + 2 * u + kq;
+            const bool sv = s < send;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[u][a] = (sv && pok[a]) ? av[u][a] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[u][b] = (sv && dok[b]) ? bv[u][b] : 0.0f;
+            if (want_map) {  // wave-uniform
+                tile[0][c][s - s0] = av[u][0];
+                tile[1][c][s - s0] = av[u][1];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+        }
+    };
+    auto flush_map = [&](int s0) {  // one wave: LDS ops of a wave complete in order, no barrier needed
+        const int s = s0 + lane;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            for (int pr = 0; pr < 32; ++pr) {
+                const int p = pbase + a * 32 + pr;
+                if (p < P && s < send) occ_planar[((long)n * P + p) * S + s] = tile[a][pr][lane];
+            }
+    };
+    if (sbeg < send) {
+        float avA[4][2], bvA[4][4], avB[4][2], bvB[4][4];
+        load_group(sbeg, avA, bvA);
+#pragma unroll 1
+        for (int sq = sbeg; sq < send; sq += 16) {  // two groups per iteration: buffers A and B alternate by name
+            const int s0a = sbeg + (sq - sbeg) / 64 * 64, s0b = sbeg + (sq + 8 - sbeg) / 64 * 64;
+            load_group(sq + 8, avB, bvB);
+            use_group(sq, s0a, avA, bvA);
+            load_group(sq + 16, avA, bvA);
+            if (sq + 8 < send) use_group(sq + 8, s0b, avB, bvB);
+            if (want_map && ((sq + 16 - sbeg) % 64 == 0 || sq + 16 >= send)) flush_map(s0a);
+        }
+    }
+    if (do_pool) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int d = d0 + b * 32 + c;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int p = pbase + a * 32 + acc_row(i, kq);
+                    if (p < P && d < D) ws[(((long)n * G + g) * P + p) * D + d] = acc[a][b][i];
+                }
+            }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -192,12 +295,18 @@ static bool xp_desc_ok(const pasn_xproto_desc* d) {
            d->Pp % 8 == 0;
 }
 
+static bool xp_pool_mfma() {
+    const char* e = getenv("PASN_POOL_VALU");
+    return !(e && e[0] == '1');
+}
+
 extern "C" int pasn_xproto_head_splits(const pasn_xproto_desc* d) {
     if (!xp_desc_ok(d)) return 0;
     const int pc = d->P <= 32 ? 32 : 64;
-    const long base = (long)d->N * ceil_div(d->D, 256) * ceil_div(d->P, pc);
-    long G = (1024 + base - 1) / base;  // aim at >= 1024 blocks (4 per CU)
-    const long gmax = ceil_div(d->S, POOL_ST);
+    const bool mfma = xp_pool_mfma();
+    const long base = mfma ? (long)d->N * ceil_div(d->D, 128) * ceil_div(d->P, 64) : (long)d->N * ceil_div(d->D, 256) * ceil_div(d->P, pc);
+    long G = ((mfma ? 2048 : 1024) + base - 1) / base;  // aim at >= 1024 blocks of 256 threads / 2048 single-wave blocks
+    const long gmax = ceil_div(d->S, mfma ? 64 : POOL_ST);
     if (G > gmax) G = gmax;
     if (G < 1) G = 1;
     return (int)G;
@@ -241,6 +350,18 @@ extern "C" int pasn_xproto_head_fwd(const void* x, const void* a1, const float* 
     pasn_conv_desc c5 = pointwise_desc(*d, d->Hd, d->Hp, d->P, d->Pp, PASN_ACT_ABS, dtype);  // occurrence_module.4 has no bias
     if ((rc = pasn_conv3d_fwd(b_o2, o3, nullptr, nullptr, nullptr, nullptr, b_occ, &c5, dtype, stream))) return rc;
 
+    if (xp_pool_mfma()) {
+        // matrix-core pooling: one wave per (S split, 128 feature columns, clip); prototype chunks of 64 are separate launches (P <= 64: one)
+        const dim3 grid(G, full ? ceil_div(d->D, 128) : 1, d->N), block(64);
+        for (int pbase = 0; pbase < d->P; pbase += 64) {
+            if (dtype == PASN_F32)
+                hipLaunchKernelGGL((xproto_pool_mfma_kernel<float>), grid, block, 0, s, (const float*)b_occ, (const float*)b_f, occ, b_slabs,
+                                   d->S, d->P, d->Pp, d->D, d->Dp, G, pbase, full ? 1 : 0);
+            else
+                hipLaunchKernelGGL((xproto_pool_mfma_kernel<__bf16>), grid, block, 0, s, (const __bf16*)b_occ, (const __bf16*)b_f, occ, b_slabs,
+                                   d->S, d->P, d->Pp, d->D, d->Dp, G, pbase, full ? 1 : 0);
+        }
+    } else {
     const int pc = d->P <= 32 ? 32 : 64;
     const int dchunks = full ? ceil_div(d->D, 256) : 1;
     const int pchunks = ceil_div(d->P, pc);
@@ -254,6 +375,7 @@ extern "C" int pasn_xproto_head_fwd(const void* x, const void* a1, const float* 
         if (pc == 32) PASN_POOL(__bf16, 32); else PASN_POOL(__bf16, 64);
     }
 #undef PASN_POOL
+    }
     if ((rc = check_launch("xproto_pool_kernel"))) return rc;
     if (full) {
         PASN_REQUIRE(d->D % 4 == 0 && d->D <= 1024, "prototype dimension must be a multiple of 4, at most 1024");

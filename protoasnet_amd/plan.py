@@ -392,7 +392,7 @@ class PlanBuilder:
         self._use(xb, yb, pb_, gate)
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
-        self._note("dwconv", f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>+se",
+        self._note("dwconv+se", f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>",  # the same kernel instance as the plain stencil
                    (self._touched(x, y, k, s) + out_pos) * y.C * self.es + (y.N * pool_blocks * y.C * 8 + y.N * c * 4 + 2 * c * cse * 4),
                    2 * out_pos * y.C * taps + 4 * y.N * c * cse)
         self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], ptrs[pb_], dref, code, a[3], a[4], a[5], a[6],

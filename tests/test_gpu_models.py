@@ -287,7 +287,7 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
     with torch.no_grad():
         runs = [m.cnn_backbone(x).float().clone() for _ in range(6)]
     meta = m.cnn_backbone.plan_for(x).meta
-    fused = [k["kernel"] for k in meta if k["kernel"].endswith("+se")]
+    fused = [k["kernel"] for k in meta if k["kind"] == "dwconv+se"]
     assert len(fused) >= 10 and not any(k["kernel"].startswith("se_gate") for k in meta), [k["kernel"] for k in meta]
     for r in runs[1:]:
         assert torch.equal(r, runs[0]), "fused gate must be bitwise reproducible"
