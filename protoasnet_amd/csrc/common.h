@@ -91,6 +91,11 @@ int launch_dw_march(const void* x, const float* w, const float* scale, const flo
                     const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
 // igemm.hip: windowed dense convs (bf16) as an implicit GEMM with direct-to-LDS staging; NT = 0: not covered
 int igemm_nt(const pasn_conv_desc& d, int dtype);
+// igemm_halo.hip: the same for stride-1 "same" (1,k,k) / (3,1,1) layers with the activation halo tile kept in LDS across the taps
+int igemm_halo_mode(const pasn_conv_desc& d);
+bool igemm_halo_fits(const pasn_conv_desc& d, int mode, int nt, int mt);
+int launch_igemm_halo(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,
+                      const pasn_conv_desc& d, int mode, int nt, int mt, hipStream_t s);
 int launch_igemm(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,
                  const pasn_conv_desc& d, int nt, hipStream_t s);
 // dwmarch2.hip: second-generation T-marching stencil (weight double buffer, buffer-load padding, 4 or 8 channels per thread)

@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
-    const long m0 = (long)blockIdx.x * IG_BM;
+    // consecutive position tiles on ONE XCD: the temporal / spatial taps of neighbouring tiles re-read the same rows, and only tiles that
+    // share an L2 can hit on them (round-robin placement sent every row to three XCDs: 632 MB fetched for a 231 MB input, PMC)
+    const long m0 = (long)(d.w_frag == 7 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)) * IG_BM;
     const int n0 = blockIdx.y * BN;
     const int Cin_p = d.Cin_p, Cout_p = d.Cout_p, kc = d.w_kc;
     const int taps = d.kt * d.kh * d.kw;
@@ -239,21 +241,28 @@ int igemm_nt(const pasn_conv_desc& d, int dtype) {
     int mt = 2;  // (NT = 2 with MT = 4 was measured SLOWER, 284 vs 223 us on 144 -> 64 (3,1,1): 9 DMA issues per 16 MFMAs; the LDS-DMA
                  // issue cost, ~60-180 cycles per wave-instruction, then outweighs the matrix work of the slice)
     while (mt > 1 && ceil_div(M, 128L * mt) * gy < 512) mt >>= 1;
+    // stride-1 "same" (1,k,k) / (3,1,1) layers: the halo-tile kernel (igemm_halo.hip) -- hundreds digit = 1 spatial taps, 2 temporal taps
+    const int mode = igemm_halo_mode(d);
+    if (mode && igemm_halo_fits(d, mode, nt, mt)) return mode * 100 + mt * 10 + nt;
     return mt * 10 + nt;
 }
 
 int launch_igemm(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,
                  const pasn_conv_desc& d, int inst, hipStream_t s) {
+    if (inst >= 100) return launch_igemm_halo(x, w, scale, bias, res, y, d, inst / 100, inst % 10, (inst / 10) % 10, s);
     const int nt = inst % 10, mt = inst / 10 ? inst / 10 : 2;
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const dim3 grid(ceil_div(M, 128L * mt), ceil_div(d.Cout_p, nt * 32)), block(256);
+    pasn_conv_desc dk = d;
+    if (const char* e = getenv("PASN_IGEMM_RR"))
+        if (e[0] == '1') dk.w_frag = 7;  // A/B switch: round-robin tile placement
 #define PASN_IG(NT_, MT_)                                                                                                     \
     if (nt == NT_ && mt == MT_) {                                                                                             \
         const size_t tiles = (size_t)2 * (128 * MT_ * 64 + NT_ * 32 * 64), image = (size_t)4 * 32 * (NT_ * 32 + 8) * 2;       \
         const size_t lds = tiles > image ? tiles : image;                                                                     \
         if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_glds_kernel<NT_, MT_>);                                            \
         hipLaunchKernelGGL((igemm_glds_kernel<NT_, MT_>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale, bias, \
-                           (const __bf16*)res, (__bf16*)y, d);                                                                \
+                           (const __bf16*)res, (__bf16*)y, dk);                                                               \
         return check_launch("igemm_glds_kernel");                                                                             \
     }
     PASN_IG(2, 4)

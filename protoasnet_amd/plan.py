@@ -93,6 +93,12 @@ def pack_conv_weight(w: torch.Tensor, cin_p: int, dtype: torch.dtype) -> Tuple[t
     return packed.to(dtype).contiguous(), kc, rows
 
 
+def _igemm_name(inst: int) -> str:
+    """Kernel instance of ``pasn_conv3d_variant`` - 6000 (igemm.hip / igemm_halo.hip): mode*100 + MT*10 + NT."""
+    mode, mt, nt = inst // 100, (inst // 10) % 10, inst % 10
+    return f"igemm_halo_kernel<{nt},{mt},{mode - 1}>" if mode else f"igemm_glds_kernel<{nt},{mt}>"
+
+
 class PlanBuilder:
     def __init__(self, device: torch.device, dtype: torch.dtype, in_dtype: torch.dtype, in_affine: Tuple[float, float] = (1.0, 0.0)):
         self.device, self.dtype, self.in_dtype = device, dtype, in_dtype
@@ -259,7 +265,7 @@ class PlanBuilder:
             a = (wf.data_ptr(), a[1], a[2])
             d.w_frag = 1
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", f"igemm_glds_kernel<{(variant - 6000) % 10},{(variant - 6000) // 10}>" if variant >= 6000 else f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if 2500 <= variant < 6000 else
+        self._note("conv", _igemm_name(variant - 6000) if variant >= 6000 else f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if 2500 <= variant < 6000 else
                    f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
                    f"pwconv_persist_kernel<{self.tname},{(variant - 1000) // 10},{variant % 10},{'true' if residual is not None else 'false'}>" if variant >= 1000 else
                    f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",

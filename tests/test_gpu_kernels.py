@@ -281,6 +281,74 @@ def test_conv_pair_chained(c0, c1, c2, gate, monkeypatch):
             assert float(o[..., c:].float().abs().max()) == 0.0, "padded channels must stay zero"
 
 
+HALO_CASES = [
+    # cin, cout, k, p, (N, T, H, W), act, residual -- stride-1 "same" convs of R(2+1)D-18 / ResNet-18 (igemm_halo.hip)
+    (64, 144, (1, 3, 3), (0, 1, 1), (2, 3, 9, 11), "relu", False),    # spatial taps, 160-channel tile, tiles straddle rows / frames / clips
+    (45, 64, (3, 1, 1), (1, 0, 0), (2, 5, 6, 7), "relu", False),      # temporal taps, kc 48 (half-empty second slice), ragged frames + positions
+    (144, 64, (3, 1, 1), (1, 0, 0), (1, 9, 8, 8), "none", True),      # temporal taps, 4.5 channel slices, residual, T not a multiple of the box
+    (128, 288, (1, 3, 3), (0, 1, 1), (1, 2, 14, 14), "relu", False),  # two 160-channel blocks, the second 128 wide
+    (288, 128, (3, 1, 1), (1, 0, 0), (2, 4, 7, 7), "relu", True),     # 128-channel tile
+    (64, 64, (1, 3, 3), (0, 1, 1), (3, 1, 14, 14), "relu", True),     # ResNet-18 BasicBlock conv (image = T 1)
+    (256, 256, (1, 3, 3), (0, 1, 1), (2, 1, 7, 7), "none", False),    # 7 x 7: every position has a tap outside the image
+    (64, 144, (1, 3, 3), (0, 1, 1), (1, 2, 40, 56), "relu", False),   # W = 56 (the halo of the stage-1 layers), several boxes
+    (64, 64, (1, 3, 3), (0, 1, 1), (1, 1, 5, 112), "none", False),    # W = 112: the widest halo the tile takes (8 groups per wave)
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_igemm_halo_kernel(case, monkeypatch):
+    """Halo-tile implicit GEMM (bf16, stride-1 windowed convs): against torch on the bf16-rounded operands, and against the per-tap
+    kernel it replaces (same products, fp32 accumulation in a different order)."""
+    from protoasnet_amd import _lib
+
+    cin, cout, k, p, nthw, act, use_res = case
+    torch.manual_seed(sum(nthw) + cin)
+    dtype = torch.bfloat16
+    n = nthw[0]
+    x = torch.randn(n, cin, *nthw[1:])
+    conv = nn.Conv3d(cin, cout, k, 1, p, bias=False)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    conv_r = nn.Conv3d(cin, cout, k, 1, p, bias=False)
+    conv_r.weight.data = _rt(conv.weight.data, dtype)
+    ref = bn(conv_r(_rt(x, dtype)))
+    res = torch.randn_like(ref) if use_res else None
+    if res is not None:
+        ref = ref + _rt(res, dtype)
+    ref = (F.relu(ref) if act == "relu" else ref).detach()
+    conv, bn = conv.to(DEV), bn.to(DEV)
+
+    def run(no_halo):
+        monkeypatch.setenv("PASN_NO_HALO", "1" if no_halo else "0")
+        pb = _pb(dtype)
+        xa, xs = _cl_input(pb, x, dtype)
+        ra = rs = None
+        if res is not None:
+            ra, rs = _cl_input(pb, res, dtype)
+        y = pb.conv(xa, conv, bn, act, residual=ra)
+        plan = pb.finish(xa, y)
+        if ra is not None:
+            plan.ptrs[ra.buf] = rs.data_ptr()
+        out = plan.run(xs).clone()
+        torch.cuda.synchronize()
+        return out, plan.meta[0]["kernel"]
+
+    out, name = run(False)
+    assert name.startswith("igemm_halo_kernel"), name
+    old, old_name = run(True)
+    assert old_name.startswith("igemm_glds_kernel"), old_name
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, cout), ref, 3e-2 * scale, 2e-2, f"halo conv {case}")
+    assert_close(_from_cl(out, cout), _from_cl(old, cout), 1.6e-2 * scale, 1e-2, f"halo vs per-tap kernel {case}")  # one bf16 ulp of the output
+    if out.shape[-1] > cout:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
 def test_conv_kernel_routing():
     """The variant query names the instance the launch will use (bench.py / profiles key on it)."""
     from protoasnet_amd import _lib
