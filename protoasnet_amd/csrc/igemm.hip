@@ -18,6 +18,7 @@
 // A = weights (row = output channel), B = activations (column = position): the accumulator has the position on the lane, which the
 // epilogue turns into whole-row 16-byte stores through a wave-private LDS image (scale / bias, residual, activation fused).
 #include "common.h"
+#include "igemm_epilogue.h"
 
 namespace pasn {
 
@@ -32,7 +33,8 @@ constexpr int IG_BK = 32;
 template <int NT, int MT>
 __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
-                                                            const __bf16* __restrict__ res, __bf16* __restrict__ y, pasn_conv_desc d) {
+                                                            const __bf16* __restrict__ res, __bf16* __restrict__ y, pasn_conv_desc d,
+                                                            int scb_off) {
     constexpr int BN = NT * 32, IG_BM = 128 * MT, XG = 2 * MT;  // XG: 16-row DMA groups of the activation tile per wave
     constexpr int XBYTES = IG_BM * 64, WBYTES = BN * 64, STAGE = XBYTES + WBYTES;
     constexpr int WGROUPS = BN / 16;               // 16-row DMA groups of the weight tile
@@ -160,6 +162,8 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
         }
     };
 
+    float* const scb = reinterpret_cast<float*>(smem + scb_off);  // scale | bias of this block's channels, beyond tiles and epilogue image
+    igemm_stage_scale_bias<BN>(scb, scale, bias, n0, d.w_rows, tid);
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -177,39 +181,9 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
     const int cgs = width / 8;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = i * 32 + 8 * g + 4 * h;  // channel inside the block tile
-                const int n = n0 + col;
-                float o[4], sc[4] = {1.0f, 1.0f, 1.0f, 1.0f}, bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (n < d.w_rows) {
-                    if (scale) load4(scale + n, sc);
-                    if (bias) load4(bias + n, bs);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[i][j][4 * g + r] * sc[r] + bs[r];
-                store4(img + (size_t)c * OROW + col, o);
-            }
-        // wave-private region: no block barrier, only this wave's LDS writes must have landed (the compiler orders LDS ops of a wave)
-        for (int p = lane; p < 32 * cgs; p += 64) {
-            const int row = p / cgs, cg = p - row * cgs;
-            const long m = m0 + wave * MT * 32 + j * 32 + row;
-            if (m >= M) continue;
-            float v[8];
-            load8(img + (size_t)row * OROW + cg * 8, v);
-            const int n = n0 + cg * 8;
-            if (res) {
-                float r[8];
-                load8(res + m * Cout_p + n, r);
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) v[r2] += r[r2];
-            }
-            act_vec(v, d.act);
-            mask_tail(v, d.Cout - n);
-            store8(y + m * Cout_p + n, v);
-        }
+        const long mbase = m0 + wave * MT * 32 + j * 32;
+        const int nvalid = (int)min((long)32, M - mbase);
+        if (nvalid > 0) igemm_epilogue_tile<NT, MT>(acc, j, img, scb, res, y, mbase, nvalid, n0, cgs, d, lane);
     }
 }
 
@@ -259,10 +233,10 @@ int launch_igemm(const void* x, const void* w, const float* scale, const float* 
 #define PASN_IG(NT_, MT_)                                                                                                     \
     if (nt == NT_ && mt == MT_) {                                                                                             \
         const size_t tiles = (size_t)2 * (128 * MT_ * 64 + NT_ * 32 * 64), image = (size_t)4 * 32 * (NT_ * 32 + 8) * 2;       \
-        const size_t lds = tiles > image ? tiles : image;                                                                     \
+        const size_t scb_off = tiles > image ? tiles : image, lds = scb_off + (size_t)NT_ * 32 * 8;                           \
         if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_glds_kernel<NT_, MT_>);                                            \
         hipLaunchKernelGGL((igemm_glds_kernel<NT_, MT_>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale, bias, \
-                           (const __bf16*)res, (__bf16*)y, dk);                                                               \
+                           (const __bf16*)res, (__bf16*)y, dk, (int)scb_off);                                                 \
         return check_launch("igemm_glds_kernel");                                                                             \
     }
     PASN_IG(2, 4)
