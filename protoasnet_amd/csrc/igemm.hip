@@ -179,12 +179,10 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
     __bf16* img = reinterpret_cast<__bf16*>(smem) + (size_t)wave * 32 * OROW;
     const int width = min(BN, Cout_p - n0);  // channels of this block that exist (multiple of 8)
     const int cgs = width / 8;
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const long mbase = m0 + wave * MT * 32 + j * 32;
-        const int nvalid = (int)min((long)32, M - mbase);
-        if (nvalid > 0) igemm_epilogue_tile<NT, MT>(acc, j, img, scb, res, y, mbase, nvalid, n0, cgs, d, lane);
-    }
+    igemm_epilogue<NT, MT>(acc, img, scb, res, y, n0, cgs, d, lane, [&](int j, long& mbase, int& nvalid) {
+        mbase = m0 + wave * MT * 32 + j * 32;
+        nvalid = (int)min((long)32, M - mbase);
+    });
 }
 
 // Instance for this layer: NT channel tiles per block in the low decimal digit, MT position tiles per wave in the next; 0 = not this kernel.

@@ -3,8 +3,9 @@
 //
 // Measured on the 64 -> 144 (1,3,3) layer (8 x 32 x 56 x 56): the first version of this epilogue was 108 of the launch's 278 us.  It read
 // scale / bias with one dependent global load per 4 channels (80 L2 round trips per wave, one after the other) and ran the row loop as
-// load -> add -> store chains.  Now scale / bias sit in LDS (staged once per block, before the main loop) and the row loop issues the
-// image reads and residual loads of NT iterations before it touches any of them.
+// load -> add -> store chains with a division and 64-bit address arithmetic per 16 bytes.  Now scale / bias sit in LDS (staged once per
+// block, before the main loop), the row loop issues the image reads and residual loads of NT iterations before it touches any of them,
+// walks (row, channel group) incrementally, and is a pure copy when there is no residual.
 #pragma once
 #include "common.h"
 
@@ -22,14 +23,29 @@ __device__ __forceinline__ void igemm_stage_scale_bias(float* scb, const float* 
     }
 }
 
+template <int ACT, int N>
+__device__ __forceinline__ void igemm_act(float (&v)[N], int act) {
+    if constexpr (ACT == PASN_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.0f);
+    } else if constexpr (ACT != PASN_ACT_NONE) {
+        act_vec(v, act);
+    }
+}
+
 // Tile j of this wave: rows mbase .. mbase + nvalid - 1 of y (nvalid >= 1), channels n0 .. n0 + 8 * cgs - 1.
-template <int NT, int MT>
+// Without a residual the activation is applied on the fp32 accumulators and the row loop is a plain LDS -> global copy; with one the image
+// holds the pre-activation sums and the row loop adds, activates and rounds again (the order of the reference: norm, + identity, ReLU).
+template <int NT, int MT, bool HAS_RES, int ACT>  // ACT: PASN_ACT_NONE / PASN_ACT_RELU compiled in, -1 = the descriptor's, at run time
 __device__ __forceinline__ void igemm_epilogue_tile(const f32x16 (&acc)[NT][MT], int j, __bf16* img, const float* scb,
                                                     const __bf16* __restrict__ res, __bf16* __restrict__ y, long mbase, int nvalid, int n0,
                                                     int cgs, const pasn_conv_desc& d, int lane) {
     constexpr int BN = NT * 32, OROW = BN + 8;
     const int c = lane & 31, h = lane >> 5;
     const int Cout_p = d.Cout_p;
+    constexpr bool early = !HAS_RES;  // a template parameter, not a branch: with both paths in one body hipcc put an s_waitcnt vmcnt(0) (for the
+                                      // residual loads) after every STORE of the copy path as well -- 20 exposed store latencies per wave
+    const bool ragged = n0 + BN > d.Cout;         // wave-uniform: this block holds the padded channels (they must be stored as zeros)
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -40,43 +56,82 @@ __device__ __forceinline__ void igemm_epilogue_tile(const f32x16 (&acc)[NT][MT],
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = acc[i][j][4 * g + r] * sc[r] + bs[r];
+            if constexpr (early) {
+                igemm_act<ACT>(o, d.act);
+                if (ragged) mask_tail(o, d.Cout - (n0 + col));
+            }
             store4(img + (size_t)c * OROW + col, o);
         }
     // wave-private image: no block barrier, only this wave's LDS writes must have landed (the compiler orders LDS ops of a wave)
-    const float inv = 1.0f / (float)cgs;  // row = p / cgs through a float multiply: exact for p < 1024, cgs <= 20
     const int total = 32 * cgs;
+    const int drow = 64 / cgs, dcg = 64 - drow * cgs;  // p -> p + 64 in (row, channel group) steps
+    int row = lane / cgs, cg = lane - row * cgs;
+    __bf16* const ytile = y + mbase * Cout_p + n0;
+    const __bf16* const rtile = HAS_RES ? res + mbase * Cout_p + n0 : nullptr;
 #pragma unroll
     for (int b0 = 0; b0 < 2; ++b0) {  // 2 * NT row-loop iterations cover 32 rows x BN / 8 channel groups: two batches of NT
         bf16x8 vi[NT], vr[NT];
-        long dst[NT];
-        int nn[NT];
+        int off[NT], cgv[NT];
         bool ok[NT];
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int p = lane + 64 * (b0 * NT + u);
-            int row = (int)(((float)p + 0.5f) * inv);
-            int cg = p - row * cgs;
             ok[u] = p < total && row < nvalid;
-            row = ok[u] ? row : 0;
-            cg = ok[u] ? cg : 0;
-            nn[u] = n0 + cg * 8;
-            dst[u] = (mbase + row) * Cout_p + nn[u];
-            vi[u] = *reinterpret_cast<const bf16x8*>(img + (size_t)row * OROW + cg * 8);
-            if (res) vr[u] = *reinterpret_cast<const bf16x8*>(res + dst[u]);
+            const int rr = ok[u] ? row : 0, cc = ok[u] ? cg : 0;
+            off[u] = rr * Cout_p + cc * 8;
+            cgv[u] = cc;
+            vi[u] = *reinterpret_cast<const bf16x8*>(img + rr * OROW + cc * 8);
+            if constexpr (HAS_RES) vr[u] = *reinterpret_cast<const bf16x8*>(rtile + off[u]);
+            row += drow;
+            cg += dcg;
+            if (cg >= cgs) {
+                cg -= cgs;
+                ++row;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
-            float v[8];
+            if constexpr (HAS_RES) {
+                float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (float)vi[u][e];
-            if (res) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)vr[u][e];
+                for (int e = 0; e < 8; ++e) v[e] = (float)vi[u][e] + (float)vr[u][e];
+                igemm_act<ACT>(v, d.act);
+                if (ragged) mask_tail(v, d.Cout - (n0 + cgv[u] * 8));
+                if (ok[u]) store8(ytile + off[u], v);
+            } else if (ok[u]) {
+                *reinterpret_cast<bf16x8*>(ytile + off[u]) = vi[u];
             }
-            act_vec(v, d.act);
-            mask_tail(v, d.Cout - nn[u]);
-            if (ok[u]) store8(y + dst[u], v);
         }
+    }
+}
+
+// All MT tiles of this wave.  `rows(j, mbase, nvalid)` names the output rows of tile j.  The residual / activation variants are separate
+// bodies behind ONE block-uniform dispatch: with the activation switch inside the unrolled loops the epilogue was 10 k instructions (40
+// branch ladders per tile, every activation's code 40 times) -- larger than the instruction cache, and the copy path carried the waits of the
+// residual path.  ReLU and identity are what the ResNet trunks use; everything else takes the run-time body.
+template <int NT, int MT, bool HAS_RES, int ACT, typename Rows>
+__device__ __forceinline__ void igemm_epilogue_body(const f32x16 (&acc)[NT][MT], __bf16* img, const float* scb, const __bf16* __restrict__ res,
+                                                    __bf16* __restrict__ y, int n0, int cgs, const pasn_conv_desc& d, int lane, Rows rows) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        long mbase;
+        int nvalid;
+        rows(j, mbase, nvalid);
+        if (nvalid > 0) igemm_epilogue_tile<NT, MT, HAS_RES, ACT>(acc, j, img, scb, res, y, mbase, nvalid, n0, cgs, d, lane);
+    }
+}
+
+template <int NT, int MT, typename Rows>
+__device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[NT][MT], __bf16* img, const float* scb, const __bf16* __restrict__ res,
+                                               __bf16* __restrict__ y, int n0, int cgs, const pasn_conv_desc& d, int lane, Rows rows) {
+    if (res) {
+        if (d.act == PASN_ACT_RELU) igemm_epilogue_body<NT, MT, true, PASN_ACT_RELU>(acc, img, scb, res, y, n0, cgs, d, lane, rows);
+        else if (d.act == PASN_ACT_NONE) igemm_epilogue_body<NT, MT, true, PASN_ACT_NONE>(acc, img, scb, res, y, n0, cgs, d, lane, rows);
+        else igemm_epilogue_body<NT, MT, true, -1>(acc, img, scb, res, y, n0, cgs, d, lane, rows);
+    } else {
+        if (d.act == PASN_ACT_RELU) igemm_epilogue_body<NT, MT, false, PASN_ACT_RELU>(acc, img, scb, res, y, n0, cgs, d, lane, rows);
+        else if (d.act == PASN_ACT_NONE) igemm_epilogue_body<NT, MT, false, PASN_ACT_NONE>(acc, img, scb, res, y, n0, cgs, d, lane, rows);
+        else igemm_epilogue_body<NT, MT, false, -1>(acc, img, scb, res, y, n0, cgs, d, lane, rows);
     }
 }
 

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
         tap2 -= taps;
         ++cs2;
     }
-    for (int cs = 0; cs < ncs; ++cs) {
+    for (int cs = 0; cs < ((ABL & 16) ? 0 : ncs); ++cs) {
         int tap = 0;
         for (int tb = 0; tb < d.kt * d.kh; ++tb)      // MODE 0: tb = kh index; MODE 1: tb = kt index (kw == 1)
             for (int te = 0; te < d.kw; ++te, ++tap) {
@@ -264,10 +264,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
     __bf16* img = reinterpret_cast<__bf16*>(smem) + (size_t)wave * 32 * OROW;
     const int width = min(BN, Cout_p - n0);  // channels of this block that exist (multiple of 8)
     const int cgs = width / 8;
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        long mbase;
-        int nvalid;  // rows of this tile that are output positions
+    auto tile_rows = [&](int j, long& mbase, int& nvalid) {  // rows of tile j that are output positions
         if (MODE == 0) {
             mbase = m0 + wave * MT * 32 + j * 32;
             nvalid = (int)min((long)32, M - mbase);
@@ -276,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
             mbase = ((long)bn * T + t) * FR + p0;
             nvalid = t < T ? min(32, FR - p0) : 0;
         }
-        if (nvalid > 0) igemm_epilogue_tile<NT, MT>(acc, j, img, scb, res, y, mbase, nvalid, n0, cgs, d, lane);
-    }
+    };
+    igemm_epilogue<NT, MT>(acc, img, scb, res, y, n0, cgs, d, lane, tile_rows);
 }
 
 // Geometry of the halo tile for this layer: tile rows (padded to 16) or 0 when the layer is not a stride-1 "same" (1,k,k) / (3,1,1) conv
@@ -329,7 +326,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
                                bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                                           \
             return check_launch("igemm_halo_kernel");                                                                             \
         }
-        PASN_IHA(1) PASN_IHA(2) PASN_IHA(4) PASN_IHA(8) PASN_IHA(3) PASN_IHA(15)
+        PASN_IHA(1) PASN_IHA(2) PASN_IHA(4) PASN_IHA(8) PASN_IHA(3) PASN_IHA(15) PASN_IHA(16)
 #undef PASN_IHA
     }
     PASN_IH(2, 2, 0) PASN_IH(2, 1, 0) PASN_IH(4, 2, 0) PASN_IH(4, 1, 0) PASN_IH(5, 2, 0) PASN_IH(5, 1, 0)
