@@ -90,6 +90,17 @@ int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const 
  * tensor, as in the reference.  Same outputs as the 3-channel entry points fed the expanded clip, up to fp32 summation order.
  * d->Cin must be 1.
  */
+/*
+ * The same first layer on the matrix cores, bf16 activations out: (1,kh,kw <= 7) windows, stride (1,2,2) -- the 7x7 stems of
+ * R(2+1)D-18 and ResNet-18 (resnet_features.py:203-205, :316-320); d->Cin = 3 (the reference's clip) or 1 (grey clip, taps summed,
+ * as for pasn_first_conv_gray_fwd).  pasn_first_conv_mfma_slot returns -1 when the layer is not covered (use pasn_first_conv_fwd), else
+ * the slot o of tap 0 in the 8-wide window the weights must be laid out for:
+ *   wq : bf16 [2*ceil(Cin*kh/2)][32*ceil(Cout_p/32)][8],  wq[ci*kh + r][co][o + s] = w[co][ci][r][s], zero elsewhere
+ *   x' = x * in_a + in_b is applied while the clip is staged (1, 0 = none); zero padding pads the normalised tensor.
+ */
+int pasn_first_conv_mfma_slot(const pasn_conv_desc* d, int in_dtype, int out_dtype);
+int pasn_first_conv_mfma_fwd(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc* d,
+                             int in_dtype, float in_a, float in_b, void* stream);
 int pasn_first_conv_gray_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                              const pasn_conv_desc* d, int in_dtype, int out_dtype, float in_a, float in_b, void* stream);
 int pasn_x3d_stem_gray_fwd(const void* x, const float* w_xy, const float* w_t, const float* scale, const float* bias, void* y,

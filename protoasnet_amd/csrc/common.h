@@ -91,6 +91,10 @@ int launch_dw_march(const void* x, const float* w, const float* scale, const flo
                     const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
 // igemm.hip: windowed dense convs (bf16) as an implicit GEMM with direct-to-LDS staging; NT = 0: not covered
 int igemm_nt(const pasn_conv_desc& d, int dtype);
+// first_conv_mfma.hip: the 7x7 stride-2 stems on the matrix cores (bf16 out); slot < 0: not covered
+int first_conv_mfma_slot(const pasn_conv_desc& d, int out_dtype);
+int launch_first_conv_mfma(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc& d,
+                           int in_dtype, float in_a, float in_b, int o, hipStream_t s);
 // igemm_halo.hip: the same for stride-1 "same" (1,k,k) / (3,1,1) layers with the activation halo tile kept in LDS across the taps
 int igemm_halo_mode(const pasn_conv_desc& d);
 bool igemm_halo_fits(const pasn_conv_desc& d, int mode, int nt, int mt);

@@ -761,6 +761,19 @@ extern "C" int pasn_first_conv_fwd(const void* x, const float* w, const float* s
     return first_conv_dispatch(x, w, scale, bias, y, d, in_dtype, out_dtype, 1.0f, 0.0f, stream);
 }
 
+extern "C" int pasn_first_conv_mfma_slot(const pasn_conv_desc* d, int in_dtype, int out_dtype) {
+    if (!d || (in_dtype != PASN_F32 && in_dtype != PASN_BF16 && in_dtype != PASN_U8)) return -1;
+    return first_conv_mfma_slot(*d, out_dtype);
+}
+
+extern "C" int pasn_first_conv_mfma_fwd(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc* d,
+                                        int in_dtype, float in_a, float in_b, void* stream) {
+    PASN_REQUIRE(x && wq && scale && bias && y && d, "null argument");
+    const int o = first_conv_mfma_slot(*d, PASN_BF16);
+    PASN_REQUIRE(o >= 0, "pasn_first_conv_mfma_fwd: layer not covered (ask pasn_first_conv_mfma_slot)");
+    return launch_first_conv_mfma(x, wq, scale, bias, y, *d, in_dtype, in_a, in_b, o, (hipStream_t)stream);
+}
+
 extern "C" int pasn_first_conv_gray_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                                         const pasn_conv_desc* d, int in_dtype, int out_dtype, float in_a, float in_b, void* stream) {
     PASN_REQUIRE(d && d->Cin == 1, "pasn_first_conv_gray_fwd reads ONE planar channel");

@@ -181,21 +181,37 @@ class PlanBuilder:
             w = w[:, :, 0]
         if x.C == 1:  # grey clip: the three input channels would be identical, so their taps are summed once here
             w = w.sum(dim=1, keepdim=True)
-        wp = torch.zeros(x.C * k[1] * k[2], y.Cp, dtype=torch.float32, device=self.device)
-        wp[:, : y.C] = w.permute(1, 2, 3, 0).reshape(x.C * k[1] * k[2], y.C)
         scale, bias = fold_norm(norm, conv.bias, y.C, y.Cp, self.device)
         d = self._desc(x, y, k, s, p, act)
-        self.keep += [wp, scale, bias]
         code_in, code_out = _lib.dtype_code(self.in_dtype), self.code
-        a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
         self._use(xb, yb)
         in_es = self._in_es()
         out_pos = y.N * y.positions
-        self._note("first_conv", f"first_conv_kernel<{self._in_name()},{self.tname},{y.Cp}>" + ("[grey]" if x.C == 1 else ""),
-                   self._touched(x, y, k, s) * x.C * in_es + out_pos * y.C * self.es, 2 * out_pos * y.C * x.C * k[1] * k[2])
+        nbytes = self._touched(x, y, k, s) * x.C * in_es + out_pos * y.C * self.es
+        flops = 2 * out_pos * y.C * x.C * k[1] * k[2]
+        ia, ib = self.in_affine if x.C == 1 else (1.0, 0.0)
+        slot = int(self.lib.pasn_first_conv_mfma_slot(dref, code_in, code_out))
+        if slot >= 0:
+            # matrix-core stem: weights in the kernel's K order -- rows (ci, r), 8-wide window slots, tap s in slot `slot` + s
+            rows, nq = x.C * k[1], 2 * ((x.C * k[1] + 1) // 2)
+            bn = 32 * ((y.Cp + 31) // 32)
+            wq = torch.zeros(nq, bn, 8, dtype=torch.float32, device=self.device)
+            wq[:rows, : y.C, slot : slot + k[2]] = w.permute(1, 2, 0, 3).reshape(rows, y.C, k[2])
+            wq = wq.to(torch.bfloat16).contiguous()
+            self.keep += [wq, scale, bias, d]
+            a = (wq.data_ptr(), scale.data_ptr(), bias.data_ptr())
+            self._note("first_conv", f"first_conv_mfma_kernel<{self._in_name()},{bn // 32},{nq // 2}>" + ("[grey]" if x.C == 1 else ""), nbytes, flops)
+            fn = self.lib.pasn_first_conv_mfma_fwd
+            self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, ia, ib, st)))
+            return y
+        wp = torch.zeros(x.C * k[1] * k[2], y.Cp, dtype=torch.float32, device=self.device)
+        wp[:, : y.C] = w.permute(1, 2, 3, 0).reshape(x.C * k[1] * k[2], y.C)
+        self.keep += [wp, scale, bias, d]
+        a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
+        self._note("first_conv", f"first_conv_kernel<{self._in_name()},{self.tname},{y.Cp}>" + ("[grey]" if x.C == 1 else ""), nbytes, flops)
         if x.C == 1:
-            fn, (ia, ib) = self.lib.pasn_first_conv_gray_fwd, self.in_affine
+            fn = self.lib.pasn_first_conv_gray_fwd
             self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, code_out, ia, ib, st)))
         else:
             fn = self.lib.pasn_first_conv_fwd

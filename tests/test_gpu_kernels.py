@@ -407,6 +407,63 @@ def test_first_conv(case, dtypes):
     assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"first conv {case}")
 
 
+FC_MFMA_CASES = [
+    # cout, (kh, kw), pad, (T, H, W), act, grey -- stride (1,2,2) stems with W % 4 == 0 (first_conv_mfma.hip)
+    (45, (7, 7), (3, 3), (2, 20, 24), "relu", False),    # R(2+1)D stem: 48-channel rows, second 32-channel tile half empty
+    (64, (7, 7), (3, 3), (1, 36, 140), "relu", False),   # ResNet-18 conv1; 70 output columns = two column tiles, 18 rows = ragged row tile
+    (45, (7, 7), (3, 3), (3, 16, 16), "none", True),     # grey clip: taps summed over the input channels, normalisation at load
+    (24, (7, 7), (3, 3), (1, 12, 132), "relu", False),   # one 32-channel tile
+]
+
+
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("case", FC_MFMA_CASES)
+def test_first_conv_mfma(case, in_dtype, monkeypatch):
+    """7x7 stride-2 stem on the matrix cores (bf16 out): against torch on the bf16-rounded operands, and against the fp32 VALU kernel."""
+    cout, (kh, kw), (ph, pw), thw, act, grey = case
+    if in_dtype == torch.uint8 and not grey:
+        pytest.skip("uint8 clips enter through the grey pipeline")
+    torch.manual_seed(cout + thw[2])
+    n, cin = 2, 1 if grey else 3
+    if in_dtype == torch.uint8:
+        x8 = torch.randint(0, 256, (n, 1, *thw), dtype=torch.uint8)
+        xin, mean, std, sc = x8, 0.099, 0.171, 255.0
+        xf = (x8.float() / 255.0 - mean) / std
+    else:
+        xf = _rt(torch.randn(n, cin, *thw), in_dtype)
+        xin, mean, std, sc = xf.to(in_dtype), 0.0, 1.0, 1.0
+    conv = nn.Conv3d(3, cout, (1, kh, kw), (1, 2, 2), (0, ph, pw), bias=False)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    ref = bn(conv(xf.expand(n, 3, *thw) if grey else xf))
+    ref = (F.relu(ref) if act == "relu" else ref).detach()
+
+    def run(no_mfma):
+        monkeypatch.setenv("PASN_NO_FC_MFMA", "1" if no_mfma else "0")
+        pb = _pb(torch.bfloat16, in_dtype)
+        if grey:
+            pb.in_affine = (1.0 / (sc * std), -mean / std)
+        xa = pb.input((n, cin, *thw))
+        y = pb.first_conv(xa, conv.to(DEV), bn.to(DEV), act)
+        out = _run_single(pb, xa, y, xin.to(DEV).contiguous()).clone()
+        return out, pb.meta[-1]["kernel"]
+
+    out, name = run(False)
+    assert name.startswith("first_conv_mfma_kernel"), name
+    old, old_name = run(True)
+    assert old_name.startswith("first_conv_kernel"), old_name
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, cout), ref, 3e-2 * scale, 2e-2, f"mfma first conv {case} {in_dtype}")
+    assert_close(_from_cl(out, cout), _from_cl(old, cout), 3e-2 * scale, 2e-2, f"mfma vs VALU first conv {case} {in_dtype}")
+    if out.shape[-1] > cout:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
 DW_CASES = [
     (24, (5, 1, 1), (1, 1, 1), (2, 0, 0), (6, 5, 5), "relu", False),    # X3D stem conv_t
     (54, (3, 3, 3), (1, 2, 2), (1, 1, 1), (3, 9, 9), "none", True),     # X3D conv_b stride 2 + SE pool
