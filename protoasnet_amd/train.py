@@ -125,7 +125,7 @@ class TrainBuilder(PlanBuilder):
         wp = torch.zeros(rows, taps, kc, dtype=self.dtype, device=self.device)
         d = self._desc(x, y, k, s, p, "none", False, kc, rows)
         dref = ctypes.byref(d)
-        frag = int(self.lib.pasn_conv3d_variant(dref, self.code, 0)) >= 2500
+        frag = 2500 <= int(self.lib.pasn_conv3d_variant(dref, self.code, 0)) < 6000  # x-tile kernels: fragment-major weights; 6000+: implicit GEMM, plain
         wf = torch.empty_like(wp) if frag else None
         if frag:
             d.w_frag = 1
