@@ -883,7 +883,13 @@ extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, in
         if (e[0] == '1') return 0;
     if (dw_march2_geom(*d, dtype).WT) return 0;  // the opt-in second-generation kernel has no fused gate
     const DwMarchGeom m = dw_march_geom(*d, dtype);
-    return m.WT != 0 && m.R * d->Cout_p >= d->Cout_p + Cse + 8;  // the gate's LDS scratch is the pool scratch
+    // The last block of a clip computes the gate alone, at the END of the launch: atomic + acquire, the partial rows (agent-scope loads:
+    // memory-side round trips), two FCs -- an exposed tail of 5-30 us that grows with the channel count (432 channels: +29 us per launch,
+    // 216: +4..9 us) against ~9 us for the stand-alone gate launch it replaces.  Measured end to end (32 x 16 x 224 x 224, one box): fused
+    // everywhere 8084 clips/s, fused up to 256 channels 8218, up to 128 channels 8250, nowhere 8193.  A version of the tail with every
+    // load batched up front (fc rows in registers) moved 432 channels to +16 us and the narrow stages to +6..9 us: no better.
+    const int max_c = getenv("PASN_SE_FUSE_MAXC") ? atoi(getenv("PASN_SE_FUSE_MAXC")) : 128;
+    return m.WT != 0 && d->Cout_p <= max_c && m.R * d->Cout_p >= d->Cout_p + Cse + 8;  // the gate's LDS scratch is the pool scratch
 }
 
 extern "C" int pasn_dwconv3d_se_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool_partial,

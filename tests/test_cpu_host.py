@@ -138,14 +138,16 @@ def test_plan_shapes_and_arena(cfg, shape):
                 assert a.offset + a.nbytes <= b.offset or b.offset + b.nbytes <= a.offset, "live buffers overlap"
     assert plan.arena_bytes < (0.6 if cfg["base_architecture"] == "resnet18" else 0.35) * plan.naive_bytes
     n_ops = len(plan.ops)
-    # x3d: fused stem 1 + 26 blocks x (expand, depthwise, project) + 4 shortcuts; the 15 SE gates ride in their stencil launches
-    # (PASN_NO_SE_FUSE=1: 15 stand-alone gate launches); opt-in fused launches:
+    # x3d: fused stem 1 + 26 blocks x (expand, depthwise, project) + 4 shortcuts; the 5 SE gates of the stages up to 128 channels ride in
+    # their stencil launches, the 10 of the wider stages are stand-alone launches (PASN_SE_FUSE_MAXC moves the boundary,
+    # PASN_NO_SE_FUSE=1: all 15 stand-alone); opt-in fused launches:
     # PASN_FRONT=1 fuses expand + depthwise of the 6 stride-1 blocks of the 7x7 stage, PASN_FUSED=1 of all 26
     fused = 26 if os.environ.get("PASN_FUSED") == "1" else (6 if os.environ.get("PASN_FRONT") == "1" else 0)
     # project conv of block i + expand conv of block i+1 chained in one launch (bf16): the 10 pairs of stage 4
     # (+ the 4 of stage 3 with PASN_XPAIR_ALL=1)
     paired = 0 if os.environ.get("PASN_NO_XPAIR") == "1" or fused else (14 if os.environ.get("PASN_XPAIR_ALL") == "1" else 10)
-    gates = 15 if (os.environ.get("PASN_NO_SE_FUSE") == "1" or fused) else 0
+    max_c = int(os.environ.get("PASN_SE_FUSE_MAXC", "128"))
+    gates = 15 if (os.environ.get("PASN_NO_SE_FUSE") == "1" or fused) else sum(n for c, n in ((54, 2), (108, 3), (216, 6), (432, 4)) if c > max_c)
     assert n_ops == {"x3d_s": 1 + 26 * 3 - fused - paired + 4 + gates, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
 
 
