@@ -82,6 +82,18 @@ int pasn_x3d_stem_fwd(const void* x, const float* w_xy, const float* w_t, const 
                       const pasn_conv_desc* d, int in_dtype, int out_dtype, void* stream);
 
 /*
+ * The same stem on the matrix cores, bf16 activations out, Wi % 4 == 0 (pasn_x3d_stem_mfma_supported says when): conv_xy and conv_t as
+ * ONE linear map over 5 frames x Cin x 3 rows x 4-wide window slots, weights multiplied together by the caller:
+ *   wq : bf16 [2*ceil(5*Cin*3/4)][32][8], K row R = (kt*Cin + ci)*3 + r:  wq[R/2][co][4*(R%2) + 1 + s] = w_t[co][kt] * w_xy[co][ci][r][s],
+ *        zero elsewhere
+ * d->Cin = 3 or 1 (grey clip, taps summed over the input channels); x' = x * in_a + in_b while staging (1, 0 = none).  A bf16 tolerance
+ * path (no rounding of the 24-channel intermediate): fp32 activations keep pasn_x3d_stem_fwd.
+ */
+int pasn_x3d_stem_mfma_supported(const pasn_conv_desc* d, int in_dtype, int out_dtype);
+int pasn_x3d_stem_mfma_fwd(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc* d,
+                           int in_dtype, float in_a, float in_b, void* stream);
+
+/*
  * Device side of the input pipeline.  The reference dataloader resizes a single-channel cine on the host,
  * normalises it ((x - 0.099) / 0.171, as_dataloader.py:180-182), repeats it to 3 identical channels (:168-170) and ships fp32
  * (N,3,T,H,W).  These two entry points take the SINGLE channel instead -- planar [N][1][Ti][Hi][Wi], fp32 / bf16 / uint8 -- apply

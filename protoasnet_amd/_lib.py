@@ -38,6 +38,8 @@ SIGNATURES = {
     "pasn_first_conv_gray_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_float, c_float, c_void_p]),
     "pasn_first_conv_mfma_slot": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "pasn_first_conv_mfma_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_float, c_float, c_void_p]),
+    "pasn_x3d_stem_mfma_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "pasn_x3d_stem_mfma_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_float, c_float, c_void_p]),
     "pasn_x3d_stem_gray_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_float, c_float, c_void_p]),
     "pasn_x3d_stem_supported": (c_int, [POINTER(ConvDesc)]),
     "pasn_x3d_stem_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),

@@ -95,6 +95,10 @@ int igemm_nt(const pasn_conv_desc& d, int dtype);
 int first_conv_mfma_slot(const pasn_conv_desc& d, int out_dtype);
 int launch_first_conv_mfma(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc& d,
                            int in_dtype, float in_a, float in_b, int o, hipStream_t s);
+// stem_mfma.hip: the X3D stem (conv_xy + conv_t + BN + ReLU) as one MFMA map, bf16 out
+int x3d_stem_mfma_supported(const pasn_conv_desc& d, int out_dtype);
+int launch_x3d_stem_mfma(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc& d, int in_dtype,
+                         float in_a, float in_b, hipStream_t s);
 // igemm_halo.hip: the same for stride-1 "same" (1,k,k) / (3,1,1) layers with the activation halo tile kept in LDS across the taps
 int igemm_halo_mode(const pasn_conv_desc& d);
 bool igemm_halo_fits(const pasn_conv_desc& d, int mode, int nt, int mt);

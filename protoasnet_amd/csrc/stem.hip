@@ -187,3 +187,17 @@ extern "C" int pasn_x3d_stem_gray_fwd(const void* x, const float* w_xy, const fl
     PASN_REQUIRE(d && d->Cin == 1, "pasn_x3d_stem_gray_fwd reads ONE planar channel");
     return stem_dispatch(x, w_xy, w_t, scale, bias, y, d, in_dtype, out_dtype, in_a, in_b, stream);
 }
+
+// ---- the same stem on the matrix cores (stem_mfma.hip): bf16 out, W % 4 == 0 ----
+extern "C" int pasn_x3d_stem_mfma_supported(const pasn_conv_desc* d, int in_dtype, int out_dtype) {
+    if (!d || (in_dtype != PASN_F32 && in_dtype != PASN_BF16 && in_dtype != PASN_U8)) return 0;
+    return pasn::x3d_stem_mfma_supported(*d, out_dtype);
+}
+
+extern "C" int pasn_x3d_stem_mfma_fwd(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc* d,
+                                      int in_dtype, float in_a, float in_b, void* stream) {
+    using namespace pasn;
+    PASN_REQUIRE(x && wq && scale && bias && y && d, "null argument");
+    PASN_REQUIRE(x3d_stem_mfma_supported(*d, PASN_BF16), "pasn_x3d_stem_mfma_fwd: layer not covered (ask pasn_x3d_stem_mfma_supported)");
+    return launch_x3d_stem_mfma(x, wq, scale, bias, y, *d, in_dtype, in_a, in_b, (hipStream_t)stream);
+}

@@ -234,6 +234,29 @@ class PlanBuilder:
         wsrc = conv_xy.weight.detach().float()[:, :, 0]
         if x.C == 1:  # grey clip: taps summed over the three identical input channels (9 instead of 27)
             wsrc = wsrc.sum(dim=1, keepdim=True)
+        code_in, code_out = _lib.dtype_code(self.in_dtype), self.code
+        if int(self.lib.pasn_x3d_stem_mfma_supported(ctypes.byref(d), code_in, code_out)):
+            # matrix-core stem: both convs as one map, K rows R = (kt, ci, r), 4-wide window slots with tap s in slot 1 + s; rows in pairs
+            rows = 5 * x.C * 3
+            ksteps = (rows + 3) // 4
+            wtc = conv_t.weight.detach().float().reshape(c, 5)                       # [co][kt]
+            comb = wtc[:, :, None, None, None] * wsrc[:, None]                       # [co][kt][ci][r][s]
+            wr = torch.zeros(4 * ksteps, 32, 4, dtype=torch.float32, device=self.device)
+            wr[:rows, :c, 1:4] = comb.permute(1, 2, 3, 0, 4).reshape(rows, c, 3)
+            wq = wr.view(2 * ksteps, 2, 32, 4).permute(0, 2, 1, 3).reshape(2 * ksteps, 32, 8)
+            wq = wq.to(torch.bfloat16).contiguous()
+            scale, bias = fold_norm(norm, None, c, y.Cp, self.device)
+            self.keep += [wq, scale, bias, d]
+            a = (wq.data_ptr(), scale.data_ptr(), bias.data_ptr())
+            xb, yb, dref = x.buf, y.buf, ctypes.byref(d)
+            self._use(xb, yb)
+            out_pos = y.N * y.positions
+            self._note("stem", f"x3d_stem_mfma_kernel<{self._in_name()},{x.C}>",
+                       x.N * x.C * x.positions * self._in_es() + out_pos * c * self.es, 2 * out_pos * c * (9 * x.C + 5))
+            ia, ib = self.in_affine if x.C == 1 else (1.0, 0.0)
+            fn = self.lib.pasn_x3d_stem_mfma_fwd
+            self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], dref, code_in, ia, ib, st)))
+            return y
         wxy = torch.zeros(9 * x.C, y.Cp, dtype=torch.float32, device=self.device)
         wxy[:, :c] = wsrc.permute(1, 2, 3, 0).reshape(9 * x.C, c)
         wt = torch.zeros(5, y.Cp, dtype=torch.float32, device=self.device)

@@ -703,6 +703,7 @@ def test_x3d_stem_fused(thw, dtypes, monkeypatch):
     bit-identical to the two unfused launches (ring values are rounded to the activation dtype exactly like the tensor
     the unfused path stores)."""
     in_dtype, dtype = dtypes
+    monkeypatch.setenv("PASN_NO_STEM_MFMA", "1")  # the matrix-core stem (bf16, W % 4 == 0) is a tolerance path: test_x3d_stem_mfma
     torch.manual_seed(21)
     n, c = 2, 24
     x = torch.randn(n, 3, *thw)
@@ -735,6 +736,53 @@ def test_x3d_stem_fused(thw, dtypes, monkeypatch):
     unfused, kinds = run()
     assert kinds == ["first_conv", "dwconv"]
     assert torch.equal(fused, unfused), "fused stem must be bit-identical to the unfused pair"
+
+
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("thw,grey", [((7, 18, 24), False), ((3, 10, 132), False), ((1, 16, 16), False), ((12, 9, 20), True), ((16, 12, 12), False)])
+def test_x3d_stem_mfma(thw, grey, in_dtype, monkeypatch):
+    """X3D stem on the matrix cores (both convs as one MFMA map, T-marching LDS ring): against torch and against the VALU stem; ragged
+    row / column tiles, T below / above the ring length, two column tiles (66 output columns), grey clips with the normalisation at load."""
+    if in_dtype == torch.uint8 and not grey:
+        pytest.skip("uint8 clips enter through the grey pipeline")
+    torch.manual_seed(thw[0] + thw[2])
+    n, c, cin = 2, 24, 1 if grey else 3
+    if in_dtype == torch.uint8:
+        x8 = torch.randint(0, 256, (n, 1, *thw), dtype=torch.uint8)
+        xin, mean, std, sc = x8, 0.099, 0.171, 255.0
+        xf = (x8.float() / 255.0 - mean) / std
+    else:
+        xf = _rt(torch.randn(n, cin, *thw), in_dtype)
+        xin, mean, std, sc = xf.to(in_dtype), 0.0, 1.0, 1.0
+    from protoasnet_amd.backbones import _X3DStem
+
+    stem = _X3DStem(c)
+    with torch.no_grad():
+        stem.bn.weight.uniform_(0.5, 1.5)
+        stem.bn.bias.normal_(0, 0.3)
+        stem.bn.running_mean.normal_(0, 0.3)
+        stem.bn.running_var.uniform_(0.5, 1.5)
+    stem.eval()
+    x3 = xf.expand(n, 3, *thw) if grey else xf
+    ref = F.relu(stem.bn(stem.conv_t(stem.conv_xy(x3)))).detach()
+    stem = stem.to(DEV)
+
+    def run(no_mfma):
+        monkeypatch.setenv("PASN_NO_STEM_MFMA", "1" if no_mfma else "0")
+        pb = _pb(torch.bfloat16, in_dtype)
+        if grey:
+            pb.in_affine = (1.0 / (sc * std), -mean / std)
+        xa = pb.input((n, cin, *thw))
+        y = pb.x3d_stem(xa, stem.conv_xy, stem.conv_t, stem.bn)
+        return _run_single(pb, xa, y, xin.to(DEV).contiguous()).clone(), pb.meta[-1]["kernel"]
+
+    out, name = run(False)
+    assert name.startswith("x3d_stem_mfma_kernel"), name
+    old, old_name = run(True)
+    assert old_name.startswith("x3d_stem_kernel"), old_name
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, c), ref, 3e-2 * scale, 2e-2, f"mfma stem {thw} {in_dtype}")
+    assert_close(_from_cl(out, c), _from_cl(old, c), 3e-2 * scale, 2e-2, f"mfma stem vs VALU stem {thw} {in_dtype}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
