@@ -17,6 +17,10 @@
 #include "common.h"
 #include "igemm_epilogue.h"
 
+#ifndef PASN_HALO_PIPE
+#define PASN_HALO_PIPE 0  // 1: measured no gain (231 vs 228 us on 64 -> 144), 20 more registers
+#endif
+
 namespace pasn {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -32,6 +36,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
                                                             const __bf16* __restrict__ res, __bf16* __restrict__ y, pasn_conv_desc d,
                                                             int rows16, int scb_off) {
     constexpr int BN = NT * 32, BM = 128 * MT, BT = 4 * MT;
+    constexpr bool PIPE = PASN_HALO_PIPE;
     constexpr int WBYTES = BN * 64, WGROUPS = BN / 16;
     constexpr int OROW = BN + 8;  // epilogue image row (elements)
     extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][rows16 * 64] halo tiles, [3][WBYTES] weight tiles; the epilogue aliases
@@ -215,6 +220,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j) mma32(acc[i][j], a[i], b[j]);
+        }
+        // machine-scheduler order of the step: the fragment reads of BOTH k-steps first, then the MFMAs back to back (the other wave of the
+        // SIMD covers this wave's one LDS wait; left alone hipcc waits twice per step, once per k-step)
+        if (PIPE) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT + NT), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
         }
     };
 

@@ -646,9 +646,97 @@ static void launch_pw_wgrad_bf16(const void* x, const void* dy, float* dw, const
                        (int)rpb);
 }
 
+// ---- the same for WIDE stride-1 pointwise layers (X3D stages 4-5: 216 <-> 96, 432 <-> 192 channels) -----------------------------
+// pw_wgrad_bf16_kernel stages ALL channels of dy and x per 32-row step in every block and then lets blockIdx.y pick 16 of the (co, ci)
+// tiles: on the 432 x 192 layers six y-blocks each load, transpose and store the same 624 channels for 8 MFMAs per wave and step, one
+// exposed L2 round trip per step, 210 blocks for 256 CUs -- 71 us for 31 MB (0.44 TB/s), 69 us for 63 MB on the 216 x 96 layers; 34
+// launches, 2.4 of the step's 32 ms.  Here a block owns a 2 x 2 group of tiles (one per wave) and stages ONLY the 64 + 64 channels those
+// need, 128 rows per step: one 8 x 8 patch per thread and step, 8 MFMAs per wave between barriers, 35 KB of LDS (several blocks per CU,
+// so one block's round trip hides under another's MFMAs), and 4 x 1024 atomics per block instead of 16 x 1024.
+constexpr int WT_KT = 128, WT_PITCH = WT_KT * 2 + 16;
+
+__global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, float* __restrict__ dw,
+                                                            pasn_conv_desc d, int co_pairs, int ci_pairs, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* At = lds;                          // [64 co channels][WT_PITCH]
+    unsigned char* Bt = lds + (size_t)64 * WT_PITCH;  // [64 ci channels][WT_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    const int cop = blockIdx.y / ci_pairs, cip = blockIdx.y % ci_pairs;
+    const int co0 = cop * 64, ci0 = cip * 64;  // first channel of this block's two co / ci tiles
+    // staging role: one 8-row x 8-channel patch per thread and step -- 16 row octets x (8 co + 8 ci channel groups)
+    const int g = tid & 15, r8 = tid >> 4;
+    const bool is_a = g < 8;
+    const int cg = is_a ? g : g - 8;
+    const int cp = is_a ? d.Cout_p : d.Cin_p;
+    const int ch = (is_a ? co0 : ci0) + cg * 8;
+    const bool ch_ok = ch < cp;  // a pair past the last tile: zeros
+    const __bf16* src = (is_a ? dy : x) + (ch_ok ? ch : 0);
+    unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * WT_PITCH + r8 * 16;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const int tco = wave >> 1, tci = wave & 1;  // this wave's tile inside the 2 x 2 group
+    for (long rb = r0; rb < r1; rb += WT_KT) {
+        uint4 pre[8];
+        unsigned okbits = 0;  // applied after ALL loads are issued (a select next to a load serialises the batch)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long r = rb + r8 * 8 + i;
+            const bool ok = ch_ok && r < r1;
+            pre[i] = *reinterpret_cast<const uint4*>(src + (ok ? r : r0) * cp);
+            okbits |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (!((okbits >> i) & 1u)) pre[i] = make_uint4(0, 0, 0, 0);
+        uint4 out[8];
+        transpose8x8_bf16(pre, out);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst + c * WT_PITCH) = out[c];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < WT_KT / 16; ++kk) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (size_t)(tco * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (size_t)(tci * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int cig = ci0 + tci * 32 + m;
+    if (cig < d.Cin) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int cog = co0 + tco * 32 + acc_row(reg, h);
+            if (cog < d.Cout) unsafeAtomicAdd(dw + (size_t)cog * d.Cin + cig, acc[reg]);
+        }
+    }
+}
+
+static bool pw_wgrad_tile(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s) {
+    if (const char* e = getenv("PASN_NO_WGRAD_TILE"))
+        if (e[0] == '1') return false;
+    const bool pointwise = d.kt * d.kh * d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
+    const int co_tiles = ceil_div(d.Cout_p, 32), ci_tiles = ceil_div(d.Cin_p, 32);
+    if (!pointwise || co_tiles + ci_tiles <= 6) return false;  // narrow layers: every block stages all channels anyway
+    const int co_pairs = ceil_div(co_tiles, 2), ci_pairs = ceil_div(ci_tiles, 2);
+    const long R = (long)d.N * d.To * d.Ho * d.Wo;
+    const int gy = co_pairs * ci_pairs;
+    // row partitions: about four blocks per CU in flight, at least two 128-row steps each
+    long parts = std::max<long>(1, std::min<long>(1024 / gy + 1, R / (2 * WT_KT)));
+    long rpb = (ceil_div(R, parts) + WT_KT - 1) / WT_KT * WT_KT;
+    const dim3 grid((unsigned)ceil_div(R, rpb), gy);
+    hipLaunchKernelGGL(pw_wgrad_tile_kernel, grid, dim3(256), (size_t)128 * WT_PITCH, s, (const __bf16*)x, (const __bf16*)dy, dw, d, co_pairs,
+                       ci_pairs, (int)rpb);
+    return true;
+}
+
 // returns false when the geometry is outside the fast path
 bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s) {
     if (d.kt * d.kh * d.kw > 64) return false;
+    if (pw_wgrad_tile(x, dy, dw, d, s)) return true;
     const int co_tiles = ceil_div(d.Cout_p, 32), ci_tiles = ceil_div(d.Cin_p, 32);
     const int ntiles = co_tiles * ci_tiles;
     const bool small = (co_tiles + ci_tiles) <= 6;  // few channels: stage more rows per step so every thread has a patch to move

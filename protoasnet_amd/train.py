@@ -48,6 +48,8 @@ class TrainBuilder(PlanBuilder):
         self.nbt: List[torch.Tensor] = []      # num_batches_tracked counters bumped once per forward
         self.n_fwd = -1
         self.op_names: List[str] = []
+        self.op_bytes: List[int] = []          # bytes of the arena / external buffers a launch touches, each buffer once (bench roofline)
+        self._pending: Dict[int, int] = {}
         # activation buffer id -> does anything that produced it hold a parameter with requires_grad?  (The reference's agents
         # freeze the trunk / everything but the last layer in some phases: XProtoNet_Base.py:253-293; frozen parts get no
         # backward launches at all.)
@@ -83,6 +85,14 @@ class TrainBuilder(PlanBuilder):
 
         self.ops.append(run)
         self.op_names.append(getattr(fn, "__name__", "?"))
+        self.op_bytes.append(sum(self._pending.values()))
+        self._pending = {}
+
+    def _use(self, *buf_ids) -> None:
+        super()._use(*buf_ids)
+        for b in buf_ids:
+            if b is not None:
+                self._pending[b] = self.bufs[b].nbytes
 
     @staticmethod
     def B(buf: Optional[int]):
@@ -470,6 +480,7 @@ class TrainBuilder(PlanBuilder):
 class TrainPlan:
     def __init__(self, tb: TrainBuilder, x_in: Act, ext: Dict[str, int], arena_bytes: int):
         self.ops, self.n_fwd, self.keep, self.refresh, self.op_names = tb.ops, tb.n_fwd, tb.keep, tb.refresh, tb.op_names
+        self.op_bytes = tb.op_bytes
         self.offsets = [None if b.external else b.offset for b in tb.bufs]
         self.in_buf, self.ext, self.gbuf = x_in.buf, ext, tb.gbuf
         self.pslots, self.gsize, self.nbt = tb.pslots, tb.gsize, tb.nbt

@@ -159,6 +159,9 @@ WGRAD_CASES = [
     (216, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 2, 5, 5)),
     (24, 48, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 2, 9, 9)),      # strided shortcut
     (20, 40, (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 3, 7, 6)),      # windowed path
+    (432, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 7, 7)),    # wide layers: 2 x 2 tile groups, several row partitions, ragged last step
+    (192, 432, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 5, 7, 7)),
+    (96, 216, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 9, 14, 14)),   # 7 / 3 tiles: half-empty last pairs
 ]
 
 

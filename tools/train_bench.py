@@ -102,7 +102,10 @@ def main(argv=None):
         elapsed = float(t.item())
     assert torch.isfinite(loss), "non-finite loss"
     runner = next(r for r in model._train_runners.values() if r.mode == 0)
-    if args.per_op and rank == 0:
+    roofline = per_entry = None
+    if rank == 0:
+        # one more step with every launch of the first-pass plan bracketed by HIP events on the launch stream: device time per C-ABI entry
+        # point, and the roofline of the entry point that takes the most time (bytes = the buffers its launches touch, each buffer once)
         plan = runner.plan
         evs = []
         orig = list(plan.ops)
@@ -114,19 +117,27 @@ def main(argv=None):
         plan.ops[:] = [wrap(i, op) for i, op in enumerate(orig)]
         step(); torch.cuda.synchronize()
         plan.ops[:] = orig
-        with open(args.per_op, "w") as fh:
-            tot = 0.0
-            for i, a, b in evs:
-                ms = a.elapsed_time(b); tot += ms
-                fh.write(f"{i:4d} {'fwd' if i < plan.n_fwd else 'bwd'} {plan.op_names[i]:32s} {ms * 1e3:9.1f} us\n")
-            fh.write(f"total {tot:.3f} ms over {len(evs)} launches (event-bracketed, includes launch gaps)\n")
-            agg = {}
-            for i, a, b in evs:
-                k = ('fwd ' if i < plan.n_fwd else 'bwd ') + plan.op_names[i]
-                agg.setdefault(k, [0.0, 0])
-                agg[k][0] += a.elapsed_time(b); agg[k][1] += 1
-            for k, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-                fh.write(f"SUM {k:40s} {n:4d} launches {ms:9.3f} ms\n")
+        agg = {}
+        for i, a, b in evs:
+            k = ('fwd ' if i < plan.n_fwd else 'bwd ') + plan.op_names[i]
+            e = agg.setdefault(k, [0.0, 0, 0])
+            e[0] += a.elapsed_time(b); e[1] += 1; e[2] += plan.op_bytes[i]
+        per_entry = {k: {"ms": round(ms, 3), "launches": n, "GB/s": round(nb / ms / 1e6, 1) if ms > 0 else None}
+                     for k, (ms, n, nb) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
+        top, (ms, n, nb) = max(agg.items(), key=lambda kv: kv[1][0])
+        roofline = {"kernel": top, "bound": "hbm", "achieved": round(nb / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(nb / ms / 1e6 / 8000.0, 4), "traffic": None, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                    "algorithmic_bytes_per_launch": int(nb / n), "note": "first-pass plan of the step; bytes = buffers touched, each once"}
+        if args.per_op:
+            with open(args.per_op, "w") as fh:
+                tot = 0.0
+                for i, a, b in evs:
+                    ms_ = a.elapsed_time(b); tot += ms_
+                    fh.write(f"{i:4d} {'fwd' if i < plan.n_fwd else 'bwd'} {plan.op_names[i]:32s} {ms_ * 1e3:9.1f} us {plan.op_bytes[i] / 1e6:9.1f} MB "
+                             f"{plan.op_bytes[i] / max(ms_, 1e-6) / 1e6:8.0f} GB/s\n")
+                fh.write(f"total {tot:.3f} ms over {len(evs)} launches (event-bracketed, includes launch gaps)\n")
+                for k, (ms_, n_, nb_) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                    fh.write(f"SUM {k:40s} {n_:4d} launches {ms_:9.3f} ms {nb_ / 1e6:10.1f} MB {nb_ / max(ms_, 1e-6) / 1e6:8.0f} GB/s\n")
     if rank == 0:
         plan = runner.plan
         print(json.dumps({
@@ -141,6 +152,7 @@ def main(argv=None):
             "launches": {"forward": plan.n_fwd, "backward": len(plan.ops) - plan.n_fwd}, "arena_bytes": plan.arena_bytes,
             "naive_bytes": plan.naive_bytes, "grad_bucket_bytes": plan.gsize * 4, "loss": round(float(loss.detach()), 5),
             "max_memory_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+            "roofline": roofline, "device_ms_by_entry_point": per_entry,
         }))
     if world > 1:
         dist.destroy_process_group()
