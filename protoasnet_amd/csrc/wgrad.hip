@@ -805,16 +805,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
         const int h1 = min(d.Ho, (hg + 1) * HR);
         {
             for (int ho = hg * HR; ho < h1; ++ho) {
+                // every load of the row first (clamped addresses), the zeroing of out-of-image values afterwards: a select right after
+                // a load makes hipcc wait for that load on the spot -- 18 dependent round trips per output row in the first version
                 float g[WT][CH];
+                unsigned gok = 0;
 #pragma unroll
                 for (int j = 0; j < WT; ++j) {
                     const int wo = wo0 + j;
                     const bool ok = wo < d.Wo;
                     loadc<CH>(gp + ((size_t)ho * d.Wo + (ok ? wo : 0)) * d.Cout_p, g[j]);
-                    if (!ok) {
-#pragma unroll
-                        for (int e = 0; e < CH; ++e) g[j][e] = 0.0f;
-                    }
+                    gok |= (ok ? 1u : 0u) << j;
                 }
 #pragma unroll
                 for (int ai = 0; ai < NA; ++ai) {
@@ -823,28 +823,43 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
                 const bool tok = ti >= 0 && ti < d.Ti;
                 if (NA == 1 && !tok) continue;
                 const T* xp = x + (((size_t)n * d.Ti + (tok ? ti : 0)) * d.Hi) * d.Wi * d.Cin_p + cg * CH;
+                float xr[3][IW][CH];
+                unsigned xok = 0;
 #pragma unroll
                 for (int dh = 0; dh < 3; ++dh) {
                     const int hi = ho * SW - 1 + dh;
                     const bool hok = tok && hi >= 0 && hi < d.Hi;
-                    float xr[IW][CH];
 #pragma unroll
                     for (int i = 0; i < IW; ++i) {
                         const int wi = wi0 + i;
                         const bool ok = hok && wi >= 0 && wi < d.Wi;
-                        loadc<CH>(xp + ((size_t)(hok ? hi : 0) * d.Wi + (ok ? wi : 0)) * d.Cin_p, xr[i]);
-                        if (!ok) {
-#pragma unroll
-                            for (int e = 0; e < CH; ++e) xr[i][e] = 0.0f;
-                        }
+                        loadc<CH>(xp + ((size_t)(hok ? hi : 0) * d.Wi + (ok ? wi : 0)) * d.Cin_p, xr[dh][i]);
+                        xok |= (ok ? 1u : 0u) << (dh * IW + i);
                     }
+                }
+                if (ai == 0) {
+#pragma unroll
+                    for (int j = 0; j < WT; ++j)
+                        if (!((gok >> j) & 1u)) {
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) g[j][e] = 0.0f;
+                        }
+                }
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+#pragma unroll
+                    for (int i = 0; i < IW; ++i)
+                        if (!((xok >> (dh * IW + i)) & 1u)) {
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) xr[dh][i][e] = 0.0f;
+                        }
 #pragma unroll
                     for (int dw_ = 0; dw_ < 3; ++dw_)
 #pragma unroll
                         for (int j = 0; j < WT; ++j)
 #pragma unroll
                             for (int e = 0; e < CH; ++e)
-                                acc[ai * 9 + dh * 3 + dw_][e] = fmaf(g[j][e], xr[j * SW + dw_][e], acc[ai * 9 + dh * 3 + dw_][e]);
+                                acc[ai * 9 + dh * 3 + dw_][e] = fmaf(g[j][e], xr[dh][j * SW + dw_][e], acc[ai * 9 + dh * 3 + dw_][e]);
                 }
                 }
             }
