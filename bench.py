@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling there is ~6300 GB/s
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.0}  # dense peaks, same guide (never the 2:1-sparsity figures)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
@@ -244,12 +245,23 @@ def main():
                 traffic = json.load(open(pmc_path)).get(dominant, {}).get("traffic_bytes_per_launch")
             except (ValueError, OSError):
                 traffic = None
-        result["roofline"] = {
-            "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": len(idx),
-            "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
-            "mfma_tflops": round(avg_flops / (avg_ms * 1e-3) / 1e12, 2),
-        }
+        tflops = avg_flops / (avg_ms * 1e-3) / 1e12
+        # which roof bounds this kernel: its arithmetic intensity against the machine balance (dense bf16 MFMA peak / HBM peak)
+        mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
+        if avg_flops / max(avg_bytes, 1.0) > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+            result["roofline"] = {
+                "kernel": dominant, "bound": "mfma", "achieved": round(tflops, 1), "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": round(tflops / mfma_peak, 4), "traffic": traffic, "launches_per_step": len(idx),
+                "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
+                "algorithmic_flops_per_launch": int(avg_flops), "hbm_gbs": round(achieved, 1),
+            }
+        else:
+            result["roofline"] = {
+                "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": len(idx),
+                "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
+                "mfma_tflops": round(tflops, 2),
+            }
         result["kernel_ms_per_step"] = kernel_ms
     result["trunk_algorithmic"] = {
         "bytes_per_clip": int(total_bytes / args.batch), "flops_per_clip": int(total_flops / args.batch),
