@@ -356,6 +356,11 @@ int pasn_maxpool3d_bwd(const void* x, const void* dy, void* dx, const pasn_conv_
  *   pasn_dwconv3d_wgrad    dw [C][kt*kh*kw]          (kh*kw <= 9; ws of pasn_dwconv3d_wgrad_workspace_floats(d) floats)
  * pasn_dwconv3d_dgrad: dx[n,ti,hi,wi,c] = sum_taps dy[n,to,ho,wo,c] * w[tap][c], w fp32 [taps][Cp] as for pasn_dwconv3d_fwd. */
 int pasn_conv3d_wgrad(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int dtype, void* stream);
+/* The same with a workspace of pasn_conv3d_wgrad_workspace_bytes(d, dtype) bytes (0 = this layer has no workspace path: ws may be NULL and
+ * the call is pasn_conv3d_wgrad).  Non-zero for the stride-1 "same" (1,3,3) / (3,1,1) convs in bf16 (R(2+1)D-18, ResNet-18): the
+ * gradient is then accumulated per row partition into ws and the partitions are summed in index order -- deterministic, no atomics. */
+size_t pasn_conv3d_wgrad_workspace_bytes(const pasn_conv_desc* d, int dtype);
+int pasn_conv3d_wgrad_ws(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int dtype, void* ws, void* stream);
 /* ws: NULL, or pasn_first_conv_wgrad_workspace_bytes(d, dtype) bytes (non-zero for bf16): the clip's windows are then gathered once
  * into im2col rows and the gradient runs on the LDS-transposed bf16 MFMA kernel instead of the per-element gather. */
 size_t pasn_first_conv_wgrad_workspace_bytes(const pasn_conv_desc* d, int dtype);

@@ -76,6 +76,8 @@ SIGNATURES = {
     "pasn_add_inplace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "pasn_maxpool3d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_conv3d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "pasn_conv3d_wgrad_ws": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "pasn_first_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "pasn_first_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p, c_void_p]),
     "pasn_dwconv3d_wgrad_workspace_floats": (c_size_t, [POINTER(ConvDesc)]),

@@ -99,6 +99,9 @@ int launch_first_conv_mfma(const void* x, const void* wq, const float* scale, co
 int x3d_stem_mfma_supported(const pasn_conv_desc& d, int out_dtype);
 int launch_x3d_stem_mfma(const void* x, const void* wq, const float* scale, const float* bias, void* y, const pasn_conv_desc& d, int in_dtype,
                          float in_a, float in_b, hipStream_t s);
+// wgrad_halo.hip: weight gradient of the stride-1 "same" (1,3,3) / (3,1,1) convs (bf16) through a partial buffer; 0 bytes = not covered
+size_t wgrad_halo_workspace_bytes(const pasn_conv_desc& d, int dtype);
+bool wgrad_halo(const void* x, const void* dy, float* dw, void* ws, const pasn_conv_desc& d, int dtype, hipStream_t s);
 // igemm_halo.hip: the same for stride-1 "same" (1,k,k) / (3,1,1) layers with the activation halo tile kept in LDS across the taps
 int igemm_halo_mode(const pasn_conv_desc& d);
 bool igemm_halo_fits(const pasn_conv_desc& d, int mode, int nt, int mt);

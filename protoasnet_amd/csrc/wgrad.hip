@@ -266,6 +266,17 @@ static long dw_wgrad_rows_per_chunk(const pasn_conv_desc& d) {
 
 using namespace pasn;
 
+extern "C" size_t pasn_conv3d_wgrad_workspace_bytes(const pasn_conv_desc* d, int dtype) {
+    return d ? wgrad_halo_workspace_bytes(*d, dtype) : 0;
+}
+
+extern "C" int pasn_conv3d_wgrad_ws(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int dtype, void* ws, void* stream) {
+    PASN_REQUIRE(x && dy && dw && d, "null pointer");
+    PASN_REQUIRE(d->Cin_p % 8 == 0 && d->Cout_p % 8 == 0 && d->Cin <= d->Cin_p && d->Cout <= d->Cout_p, "bad channel extents");
+    if (ws && wgrad_halo(x, dy, dw, ws, *d, dtype, (hipStream_t)stream)) return check_launch("conv3d_wgrad_halo");
+    return pasn_conv3d_wgrad(x, dy, dw, d, dtype, stream);
+}
+
 extern "C" int pasn_conv3d_wgrad(const void* x, const void* dy, float* dw, const pasn_conv_desc* d, int dtype, void* stream) {
     PASN_REQUIRE(x && dy && dw && d, "null pointer");
     PASN_REQUIRE(d->Cin_p % 8 == 0 && d->Cout_p % 8 == 0 && d->Cin <= d->Cin_p && d->Cout <= d->Cout_p, "bad channel extents");

@@ -326,8 +326,10 @@ class TrainBuilder(PlanBuilder):
                 self.add_grad(x, dx)
                 return
             if w_live:
-                self._use(x.buf, dy.buf)
-                self._op(lib.pasn_conv3d_wgrad, B(x.buf), B(dy.buf), dW, dref, code)
+                wsz = int(lib.pasn_conv3d_wgrad_workspace_bytes(dref, code))  # windowed stride-1 convs, bf16: partial-buffer path
+                wsb = self._new_buf(wsz) if wsz else None
+                self._use(x.buf, dy.buf, wsb)
+                self._op(lib.pasn_conv3d_wgrad_ws, B(x.buf), B(dy.buf), dW, dref, code, B(wsb))
             if not x_live:
                 return
             # ---- input gradient of the dense conv

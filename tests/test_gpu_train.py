@@ -183,6 +183,50 @@ def test_conv_wgrad(cin, cout, k, s, p, shape, dtype):
     _rel(dw.view_as(wt), wt.grad, 1e-4, "dW")
 
 
+WGRAD_HALO_CASES = [
+    # cin, cout, k, p, (N,T,H,W) -- stride-1 "same" windowed convs of R(2+1)D-18 / ResNet-18 (wgrad_halo.hip, bf16)
+    (64, 144, (1, 3, 3), (0, 1, 1), (2, 3, 10, 12)),    # spatial taps: 5 co tiles (two groups), 2 ci tiles, borders on every side
+    (144, 64, (3, 1, 1), (1, 0, 0), (2, 5, 6, 6)),      # temporal taps: 5 ci tiles (three groups, the last one with a single tile)
+    (45, 64, (3, 1, 1), (1, 0, 0), (1, 4, 9, 7)),       # 45 -> padded 48 channels, odd W (temporal taps do not care)
+    (128, 288, (1, 3, 3), (0, 1, 1), (1, 2, 14, 14)),   # 9 co tiles = 3 groups, 4 ci tiles = 2 groups
+    (64, 64, (1, 3, 3), (0, 1, 1), (3, 1, 28, 28)),     # ResNet-18 block conv (T = 1), several row partitions
+    (64, 144, (1, 3, 3), (0, 1, 1), (1, 2, 20, 56)),    # W = 56 as in stage 1 of the 112 x 112 clip
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,p,shape", WGRAD_HALO_CASES)
+def test_conv_wgrad_halo(cin, cout, k, p, shape):
+    """Windowed stride-1 weight gradient through the partial buffer (bf16): against autograd on the bf16-rounded operands, bitwise
+    reproducible from run to run (no atomics), and the workspace query / NULL-workspace fallback of the entry point."""
+    lib = _lib.lib()
+    n, t, h, w = shape
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout + w)
+    x = torch.randn(n, cin, t, h, w, generator=g).to(dtype).float()
+    wt = torch.zeros(cout, cin, *k, requires_grad=True)
+    y = F.conv3d(x, wt, stride=1, padding=p)
+    dy = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(dy)
+    d = _desc(x, y, k, (1, 1, 1), p)
+    xd, dyd = _cl(x, dtype=dtype), _cl(dy, dtype=dtype)
+    nbytes = int(lib.pasn_conv3d_wgrad_workspace_bytes(ctypes.byref(d), BF16))
+    assert nbytes > 0, "this layer must take the partial-buffer path"
+    assert int(lib.pasn_conv3d_wgrad_workspace_bytes(ctypes.byref(d), F32)) == 0
+    taps = k[0] * k[1] * k[2]
+    outs = []
+    for _ in range(2):
+        ws = torch.full((nbytes // 4,), float("nan"), device=DEV)  # every value the reduce reads must have been written
+        dw = torch.zeros(cout, cin, taps, device=DEV)
+        _lib.check(lib.pasn_conv3d_wgrad_ws(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, ws.data_ptr(), _st()))
+        torch.cuda.synchronize()
+        outs.append(dw.clone())
+    _rel(outs[0].view_as(wt), wt.grad, 1e-4, "dW (partial-buffer path)")
+    assert torch.equal(outs[0], outs[1]), "the partial-buffer path has a fixed summation order"
+    dw = torch.zeros(cout, cin, taps, device=DEV)
+    _lib.check(lib.pasn_conv3d_wgrad_ws(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, 0, _st()))
+    _rel(dw.view_as(wt), wt.grad, 1e-4, "dW (no workspace: the atomic path)")
+
+
 @pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
 def test_first_conv_wgrad(in_dtype):
     lib = _lib.lib()
