@@ -100,9 +100,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
     const int units = dy_units + x_units;  // <= 1024 (host-checked)
     unsigned char* u_dst[2];
     int u_pitch[2], u_cp[2];      // u_cp: -1 = dy patch, 0..2 = x copy
-    long u_rel[2];                // source row of the patch's first row, relative to the step's first row
+    int u_row[2];                 // source row of the patch's first row in the CURRENT step (32-bit: the host bounds rows * channels by 2^31)
     const __bf16* u_src[2];       // channel-offset base pointer, nullptr = zeros (channel group past the tensor / no unit)
     int u_rowlen[2];
+    int u_coord[2], u_within[2];  // x copies: column (mode 0) / frame and in-frame position (mode 1) of that source row, kept incrementally
+    const int Mi = (int)M, r0i = (int)r0, r1i = (int)r1;
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
         const int u = tid + v * 512;
@@ -110,14 +112,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
         u_src[v] = nullptr;
         u_pitch[v] = 0;
         u_cp[v] = -1;
-        u_rel[v] = 0;
+        u_row[v] = r0i;
         u_rowlen[v] = 0;
+        u_coord[v] = u_within[v] = 0;
         if (u < dy_units) {
             const int cg = u % dy_cgs, oct = u / dy_cgs;
             const int ch = co0 + cg * 8;
             u_dst[v] = At + (size_t)(cg * 8) * g.pitchA + oct * 16;
             u_pitch[v] = g.pitchA;
-            u_rel[v] = oct * 8;
+            u_row[v] = r0i + oct * 8;
             u_rowlen[v] = d.Cout_p;
             if (ch < d.Cout_p) u_src[v] = dy + ch;
         } else if (u < units) {
@@ -127,67 +130,82 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
             u_dst[v] = Bt + ((size_t)cp * 64 + cg * 8) * g.pitchB + oct * 16;
             u_pitch[v] = g.pitchB;
             u_cp[v] = cp;
-            u_rel[v] = g.mode == 0 ? (long)oct * 8 - g.HAL + (cp - 1) : (long)oct * 8 + (long)(cp - 1) * FR;
+            u_row[v] = r0i + oct * 8 + (g.mode == 0 ? -g.HAL + (cp - 1) : (cp - 1) * FR);
             u_rowlen[v] = d.Cin_p;
             if (ch < d.Cin_p) u_src[v] = x + ch;
+            if (g.mode == 0) {
+                u_coord[v] = ((u_row[v] % W) + W) % W;  // rows before the tensor are masked by their sign; the column arithmetic is modular
+            } else {
+                const int sp = u_row[v] + FR * T;        // one clip period up: non-negative, same frame index modulo T
+                u_within[v] = sp % FR;
+                u_coord[v] = (sp / FR) % T;
+            }
         }
     }
+    const int step_w = WH_KT % W, step_fr = WH_KT % FR, step_t = (WH_KT / FR) % T;  // coordinate advance per 128-row step
 
     for (long rb = r0; rb < r1; rb += WH_KT) {
-        uint4 pre[2][8];
-        unsigned okbits = 0;
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < 2; ++v) {  // one unit at a time: both in flight (64 staging registers) spilled the 9-tile instance
+            uint4 pre[8];
+            unsigned okbits = 0;
             const __bf16* src = u_src[v] ? u_src[v] : x;
-            const long s0 = rb + u_rel[v];
+            const int s0 = u_row[v];
             if (u_cp[v] < 0) {  // dy rows of this partition
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const long r = s0 + i;
-                    const bool ok = u_src[v] != nullptr && r < r1;
-                    pre[v][i] = *reinterpret_cast<const uint4*>(src + (ok ? r : r0) * u_rowlen[v]);
-                    okbits |= (ok ? 1u : 0u) << (v * 8 + i);
+                    const bool ok = u_src[v] != nullptr && s0 + i < r1i;
+                    pre[i] = *reinterpret_cast<const uint4*>(src + (ok ? s0 + i : r0i) * u_rowlen[v]);
+                    okbits |= (ok ? 1u : 0u) << i;
                 }
             } else {
-                // x rows of copy cp; the coordinate whose wrap invalidates a row of the copy: column (mode 0) / frame (mode 1) of the SOURCE row
-                const long s0c = s0 < 0 ? 0 : s0;
-                int coord = g.mode == 0 ? (int)(s0c % W) : (int)((s0c / FR) % T);
-                int within = g.mode == 0 ? 0 : (int)(s0c % FR);
+                // x rows of copy cp; a row is zero when its column (mode 0) / frame (mode 1) is the one that only a wrapped tap would read
                 const int period = g.mode == 0 ? W : T;
                 const int bad = u_cp[v] == 0 ? period - 1 : (u_cp[v] == 2 ? 0 : -1);
+                int coord = u_coord[v], within = u_within[v];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const long sr = s0 + i;
-                    const bool ok = u_src[v] != nullptr && sr >= 0 && sr < M && coord != bad;
-                    pre[v][i] = *reinterpret_cast<const uint4*>(src + (ok ? sr : 0) * u_rowlen[v]);
-                    okbits |= (ok ? 1u : 0u) << (v * 8 + i);
-                    if (sr >= 0) {  // coordinate of the next source row
-                        if (g.mode == 0) {
-                            coord = coord + 1 == W ? 0 : coord + 1;
-                        } else if (++within == FR) {
-                            within = 0;
-                            coord = coord + 1 == T ? 0 : coord + 1;
-                        }
+                    const int sr = s0 + i;
+                    const bool ok = u_src[v] != nullptr && sr >= 0 && sr < Mi && coord != bad;
+                    pre[i] = *reinterpret_cast<const uint4*>(src + (ok ? sr : 0) * u_rowlen[v]);
+                    okbits |= (ok ? 1u : 0u) << i;
+                    if (g.mode == 0) {
+                        coord = coord + 1 == W ? 0 : coord + 1;
+                    } else if (++within == FR) {
+                        within = 0;
+                        coord = coord + 1 == T ? 0 : coord + 1;
                     }
                 }
+                // advance to the next step
+                if (g.mode == 0) {
+                    u_coord[v] += step_w;
+                    if (u_coord[v] >= W) u_coord[v] -= W;
+                } else {
+                    u_within[v] += step_fr;
+                    int carry = step_t;
+                    if (u_within[v] >= FR) {
+                        u_within[v] -= FR;
+                        ++carry;
+                    }
+                    u_coord[v] += carry;
+                    while (u_coord[v] >= T) u_coord[v] -= T;
+                }
             }
-        }
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
+            u_row[v] += WH_KT;
             if (u_dst[v]) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (!((okbits >> (v * 8 + i)) & 1u)) pre[v][i] = make_uint4(0, 0, 0, 0);
+                    if (!((okbits >> i) & 1u)) pre[i] = make_uint4(0, 0, 0, 0);
                 uint4 out[8];
-                wh_transpose8x8(pre[v], out);
+                wh_transpose8x8(pre, out);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(u_dst[v] + (size_t)c * u_pitch[v]) = out[c];
             }
         }
         if (g.mode == 0 && tid < WH_KT / 8) {  // rows whose tap row b = 0 / b = 2 leaves the image: bit i of byte [sel][octet] = row valid
             unsigned m0 = 0, m2 = 0;
-            const long rr = rb + tid * 8;
-            int hh = (int)((rr / W) % H), ww = (int)(rr % W);
+            const int rr = (int)rb + tid * 8;
+            int hh = (rr / W) % H, ww = rr % W;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 m0 |= (hh != 0 ? 1u : 0u) << i;
