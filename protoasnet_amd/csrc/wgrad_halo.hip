@@ -98,18 +98,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
     const int dy_cgs = COT * 4, dy_units = (WH_KT / 8) * dy_cgs;
     const int x_oct = g.L / 8, x_units = 3 * x_oct * 8;
     const int units = dy_units + x_units;  // <= 1024 (host-checked)
-    unsigned char* u_dst[2];
+    int u_dst[2];                 // LDS byte offset (an int: a pointer kept in a register array loses its address space and every
+                                  // access through it becomes a flat_load / flat_store), -1 = no unit
     int u_pitch[2], u_cp[2];      // u_cp: -1 = dy patch, 0..2 = x copy
     int u_row[2];                 // source row of the patch's first row in the CURRENT step (32-bit: the host bounds rows * channels by 2^31)
-    const __bf16* u_src[2];       // channel-offset base pointer, nullptr = zeros (channel group past the tensor / no unit)
+    int u_ch[2];                  // first channel of the patch, -1 = zeros (channel group past the tensor / no unit)
     int u_rowlen[2];
     int u_coord[2], u_within[2];  // x copies: column (mode 0) / frame and in-frame position (mode 1) of that source row, kept incrementally
     const int Mi = (int)M, r0i = (int)r0, r1i = (int)r1;
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
         const int u = tid + v * 512;
-        u_dst[v] = nullptr;
-        u_src[v] = nullptr;
+        u_dst[v] = -1;
+        u_ch[v] = -1;
         u_pitch[v] = 0;
         u_cp[v] = -1;
         u_row[v] = r0i;
@@ -118,21 +119,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
         if (u < dy_units) {
             const int cg = u % dy_cgs, oct = u / dy_cgs;
             const int ch = co0 + cg * 8;
-            u_dst[v] = At + (size_t)(cg * 8) * g.pitchA + oct * 16;
+            u_dst[v] = (cg * 8) * g.pitchA + oct * 16;
             u_pitch[v] = g.pitchA;
             u_row[v] = r0i + oct * 8;
             u_rowlen[v] = d.Cout_p;
-            if (ch < d.Cout_p) u_src[v] = dy + ch;
+            if (ch < d.Cout_p) u_ch[v] = ch;
         } else if (u < units) {
             const int q = u - dy_units;
             const int cg = q & 7, oct = (q >> 3) % x_oct, cp = (q >> 3) / x_oct;
             const int ch = ci0 + cg * 8;
-            u_dst[v] = Bt + ((size_t)cp * 64 + cg * 8) * g.pitchB + oct * 16;
+            u_dst[v] = COT * 32 * g.pitchA + (cp * 64 + cg * 8) * g.pitchB + oct * 16;
             u_pitch[v] = g.pitchB;
             u_cp[v] = cp;
             u_row[v] = r0i + oct * 8 + (g.mode == 0 ? -g.HAL + (cp - 1) : (cp - 1) * FR);
             u_rowlen[v] = d.Cin_p;
-            if (ch < d.Cin_p) u_src[v] = x + ch;
+            if (ch < d.Cin_p) u_ch[v] = ch;
             if (g.mode == 0) {
                 u_coord[v] = ((u_row[v] % W) + W) % W;  // rows before the tensor are masked by their sign; the column arithmetic is modular
             } else {
@@ -149,12 +150,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
         for (int v = 0; v < 2; ++v) {  // one unit at a time: both in flight (64 staging registers) spilled the 9-tile instance
             uint4 pre[8];
             unsigned okbits = 0;
-            const __bf16* src = u_src[v] ? u_src[v] : x;
+            const bool chok = u_ch[v] >= 0;
+            const __bf16* src = (u_cp[v] < 0 ? dy : x) + (chok ? u_ch[v] : 0);
             const int s0 = u_row[v];
             if (u_cp[v] < 0) {  // dy rows of this partition
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const bool ok = u_src[v] != nullptr && s0 + i < r1i;
+                    const bool ok = chok && s0 + i < r1i;
                     pre[i] = *reinterpret_cast<const uint4*>(src + (ok ? s0 + i : r0i) * u_rowlen[v]);
                     okbits |= (ok ? 1u : 0u) << i;
                 }
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int sr = s0 + i;
-                    const bool ok = u_src[v] != nullptr && sr >= 0 && sr < Mi && coord != bad;
+                    const bool ok = chok && sr >= 0 && sr < Mi && coord != bad;
                     pre[i] = *reinterpret_cast<const uint4*>(src + (ok ? sr : 0) * u_rowlen[v]);
                     okbits |= (ok ? 1u : 0u) << i;
                     if (g.mode == 0) {
@@ -192,14 +194,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const __bf16* __re
                 }
             }
             u_row[v] += WH_KT;
-            if (u_dst[v]) {
+            if (u_dst[v] >= 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     if (!((okbits >> i) & 1u)) pre[i] = make_uint4(0, 0, 0, 0);
                 uint4 out[8];
                 wh_transpose8x8(pre, out);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(u_dst[v] + (size_t)c * u_pitch[v]) = out[c];
+                for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(lds + u_dst[v] + c * u_pitch[v]) = out[c];
             }
         }
         if (g.mode == 0 && tid < WH_KT / 8) {  // rows whose tap row b = 0 / b = 2 leaves the image: bit i of byte [sel][octet] = row valid
