@@ -107,7 +107,7 @@ def test_x3d_production_routes_vs_oracle(dtype):
         logits, sim, occ = m(x.to(DEV))
         kernels = {meta["kernel"].split("<")[0] for meta in m.cnn_backbone.plan_for(x.to(DEV).to(dtype)).meta}
     if dtype == torch.bfloat16:
-        assert {"x3d_stem_kernel", "dwconv3d_march_kernel", "pwconv_xtile_kernel", "pwconv_persist_kernel"} <= kernels, kernels
+        assert {"x3d_stem_mfma_kernel", "dwconv3d_march_kernel", "pwconv_xtile_kernel", "pwconv_persist_kernel"} <= kernels, kernels
         assert_close(sim, ref["similarity"], 2e-2, 0, "bf16 similarity")
         assert_close(logits, ref["logits"], 0.25, 0.05, "bf16 logits")
         rel = (occ.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()
@@ -283,6 +283,13 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
     to the fp32 summation order of the pool, bitwise equal across repeated runs (the counters return to zero after every launch, the
     reduction order is fixed), and every SE layer really takes the fused launch."""
     x = synth.echo_clips(shape).to(DEV).bfloat16()
+    # default routing: the gate rides in the stencil launch up to 128 channels (stages 2-3), the wider stages keep the stand-alone launch
+    m0 = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        m0.cnn_backbone(x)
+    meta0 = m0.cnn_backbone.plan_for(x).meta
+    assert len([k for k in meta0 if k["kind"] == "dwconv+se"]) == 5 and len([k for k in meta0 if k["kernel"].startswith("se_gate")]) == 10
+    monkeypatch.setenv("PASN_SE_FUSE_MAXC", "1024")  # the mechanism itself: every SE layer fused
     m = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
     with torch.no_grad():
         runs = [m.cnn_backbone(x).float().clone() for _ in range(6)]
