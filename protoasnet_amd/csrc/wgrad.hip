@@ -895,6 +895,137 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const T* __restrict
     }
 }
 
+// ---- depthwise 3x3x3 weight gradient, T-marching form (stride (1,s,s), pad 1) -------------------------------------------------------
+// The strip kernel above runs one temporal tap per blockIdx.z: every (frame, row) of x and dy is loaded and converted three times, 18
+// loads for 108 FMAs.  It is VALU-issue bound at ~1 TB/s (the forward stencil, with the same 27 FMAs per element, runs at 2.4).  Here a
+// thread owns (4 channels, a strip of WT outputs, one output row) and MARCHES ALONG T: the three rows of input frame ti are loaded and
+// converted ONCE and meet the gradients of output frames ti+1, ti, ti-1 (temporal taps 0, 1, 2), which sit in a three-frame register
+// ring -- 18 loads for 324 FMAs, 27 x 4 accumulators.
+template <int SW, int WT>
+__global__ __launch_bounds__(256, 2) void dw_wgrad_march_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, float* __restrict__ partial,
+                                                             pasn_conv_desc d, int CG, int CGb, int strips, long items) {
+    typedef __bf16 T;
+    constexpr int CH = 4;
+    __shared__ float red[256 * CH];
+    constexpr int IW = (WT - 1) * SW + 3;
+    const int cg = threadIdx.x % CGb, pl = threadIdx.x / CGb, PL = 256 / CGb;
+    float acc[27][CH];
+#pragma unroll
+    for (int p = 0; p < 27; ++p)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[p][j] = 0.0f;
+    for (long item = (long)blockIdx.x * PL + pl; cg < CG && item < items; item += (long)gridDim.x * PL) {  // (n, ho, strip)
+        const int strip = (int)(item % strips);
+        const long q = item / strips;
+        const int ho = (int)(q % d.Ho), n = (int)(q / d.Ho);
+        const int wo0 = strip * WT, wi0 = wo0 * SW - 1;
+        // gradients of this strip in frame `to` (clamped addresses; columns past the row are masked after the loads)
+        const T* gp = dy + (((size_t)n * d.To) * d.Ho + ho) * d.Wo * d.Cout_p + cg * CH;
+        const size_t gframe = (size_t)d.Ho * d.Wo * d.Cout_p;
+        unsigned gmask = 0;
+        int goff[WT];
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+            const bool ok = wo0 + j < d.Wo;
+            goff[j] = (ok ? wo0 + j : 0) * d.Cout_p;
+            gmask |= (ok ? 1u : 0u) << j;
+        }
+        // input rows hi = ho*SW - 1 + dh, columns wi0 .. wi0 + IW - 1 (clamped; masked after the loads)
+        const T* xp = x + ((size_t)n * d.Ti) * d.Hi * d.Wi * d.Cin_p + cg * CH;
+        const size_t xframe = (size_t)d.Hi * d.Wi * d.Cin_p;
+        unsigned xmask = 0;
+        int xoff[3][IW];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = ho * SW - 1 + dh;
+            const bool hok = hi >= 0 && hi < d.Hi;
+#pragma unroll
+            for (int i = 0; i < IW; ++i) {
+                const int wi = wi0 + i;
+                const bool ok = hok && wi >= 0 && wi < d.Wi;
+                xoff[dh][i] = ((hok ? hi : 0) * d.Wi + (ok ? wi : 0)) * d.Cin_p;
+                xmask |= (ok ? 1u : 0u) << (dh * IW + i);
+            }
+        }
+        float g0[WT][CH], g1[WT][CH], g2[WT][CH];  // gradients of output frames ti-1, ti, ti+1
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+            loadc<CH>(gp + goff[j], g1[j]);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                g0[j][e] = 0.0f;
+                if (!((gmask >> j) & 1u)) g1[j][e] = 0.0f;
+            }
+        }
+#pragma unroll 1
+        for (int ti = 0; ti < d.Ti; ++ti) {
+            // this frame's loads first (raw 8-byte words: 30 registers instead of 60 converted ones): the three input rows and the
+            // gradients of frame ti + 1
+            uint2 raw[3][IW];
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int i = 0; i < IW; ++i) raw[dh][i] = *reinterpret_cast<const uint2*>(xp + (size_t)ti * xframe + xoff[dh][i]);
+            const bool next = ti + 1 < d.To;
+#pragma unroll
+            for (int j = 0; j < WT; ++j) loadc<CH>(gp + (size_t)(next ? ti + 1 : ti) * gframe + goff[j], g2[j]);
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int e = 0; e < CH; ++e)
+                    if (!next || !((gmask >> j) & 1u)) g2[j][e] = 0.0f;
+            // temporal tap a pairs input frame ti with output frame ti - a + 1: a = 0 -> g2, 1 -> g1, 2 -> g0
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                float xr[IW][CH];  // one row converted at a time
+#pragma unroll
+                for (int i = 0; i < IW; ++i) {
+                    const bool ok = (xmask >> (dh * IW + i)) & 1u;
+                    const unsigned lo = ok ? raw[dh][i].x : 0u, hi = ok ? raw[dh][i].y : 0u;
+                    xr[i][0] = __uint_as_float(lo << 16);
+                    xr[i][1] = __uint_as_float(lo & 0xffff0000u);
+                    xr[i][2] = __uint_as_float(hi << 16);
+                    xr[i][3] = __uint_as_float(hi & 0xffff0000u);
+                }
+#pragma unroll
+                for (int dw_ = 0; dw_ < 3; ++dw_)
+#pragma unroll
+                    for (int j = 0; j < WT; ++j)
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) {
+                            const float xv = xr[j * SW + dw_][e];
+                            acc[0 * 9 + dh * 3 + dw_][e] = fmaf(g2[j][e], xv, acc[0 * 9 + dh * 3 + dw_][e]);
+                            acc[1 * 9 + dh * 3 + dw_][e] = fmaf(g1[j][e], xv, acc[1 * 9 + dh * 3 + dw_][e]);
+                            acc[2 * 9 + dh * 3 + dw_][e] = fmaf(g0[j][e], xv, acc[2 * 9 + dh * 3 + dw_][e]);
+                        }
+            }
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    g0[j][e] = g1[j][e];
+                    g1[j][e] = g2[j][e];
+                }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * 27 * d.Cout_p;
+#pragma unroll
+    for (int p = 0; p < 27; ++p) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CH; ++j) red[threadIdx.x * CH + j] = acc[p][j];
+        __syncthreads();
+        for (int t = threadIdx.x; t < CGb * CH; t += 256) {
+            const int g2i = t / CH, j = t % CH;
+            if (g2i < CG) {
+                float s = 0.0f;
+                for (int q2 = 0; q2 < PL; ++q2) s += red[(q2 * CGb + g2i) * CH + j];
+                out[(size_t)p * d.Cout_p + g2i * CH + j] = s;
+            }
+        }
+    }
+}
+
 // dw[c][tap] = sum_chunks partial[chunk][tap*Cp + c]: 64 columns x 4 parts per block, parts combined in a fixed order
 __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int taps, int C,
                                                               int Cp) {
@@ -1014,9 +1145,22 @@ static DwWgGeom dw_wgrad_strip_geom(const pasn_conv_desc& d) {
 
 namespace pasn {
 
+// T-marching form: 3x3x3, temporal stride 1 and pad 1, frames kept (To == Ti)
+static bool dw_wgrad_march_ok(const pasn_conv_desc& d) {
+    if (const char* e = getenv("PASN_NO_DWWG_MARCH"))
+        if (e[0] == '1') return false;
+    return d.kt == 3 && d.st == 1 && d.pt == 1 && d.To == d.Ti && d.kh == 3 && d.kw == 3 && d.ph == 1 && d.pw == 1;
+}
+static long dw_wgrad_march_blocks(const pasn_conv_desc& d, const DwWgGeom& g) {
+    const long items = (long)d.N * d.Ho * g.strips;
+    return std::min<long>((items + g.PL - 1) / g.PL, 1024);
+}
+
 size_t dw_wgrad_strip_floats(const pasn_conv_desc& d) {
     if (dw_temporal_ok(d)) return (size_t)dw_temporal_blocks(d) * d.kt * d.Cout_p;
     const DwWgGeom g = dw_wgrad_strip_geom(d);
+    if (g.ok && dw_wgrad_march_ok(d))  // bf16 takes the marching kernel, fp32 the strip kernel: room for either
+        return (size_t)std::max<long>(dw_wgrad_march_blocks(d, g), g.blocks) * 27 * d.Cout_p;
     return g.ok ? (size_t)g.blocks * d.kt * 9 * d.Cout_p : 0;
 }
 
@@ -1037,6 +1181,16 @@ bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const p
     }
     const DwWgGeom g = dw_wgrad_strip_geom(d);
     if (!g.ok) return false;
+    if (dtype == PASN_BF16 && dw_wgrad_march_ok(d)) {
+        const long items = (long)d.N * d.Ho * g.strips, blocks = dw_wgrad_march_blocks(d, g);
+#define DWM(SWv, WTv) \
+    hipLaunchKernelGGL((dw_wgrad_march_kernel<SWv, WTv>), dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, ws, d, g.CG, g.CGb, g.strips, items)
+        if (g.SW == 1) DWM(1, 3);
+        else DWM(2, 2);
+#undef DWM
+        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div((long)27 * d.Cout_p, 64)), dim3(256), 0, s, ws, dw, (int)blocks, 27, d.Cout, d.Cout_p);
+        return true;
+    }
     static const bool fuse3 = getenv("PASN_DWWG_FUSED") ? atoi(getenv("PASN_DWWG_FUSED")) != 0 : false;
     const bool na3 = fuse3 && d.kt == 3;
     const dim3 grid((unsigned)g.blocks, 1, na3 ? 1 : d.kt);

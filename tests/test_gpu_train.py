@@ -280,6 +280,32 @@ def test_depthwise_dgrad_wgrad(c, k, s, p, shape):
     _rel(dw.view_as(wt), wt.grad, 1e-4, "dW")
 
 
+@pytest.mark.parametrize("c,s,shape", [(54, 1, (2, 5, 9, 10)), (54, 2, (2, 4, 12, 14)), (432, 1, (1, 3, 7, 7)), (108, 2, (1, 16, 8, 9)), (216, 1, (2, 1, 5, 4))])
+def test_depthwise_wgrad_march_bf16(c, s, shape, monkeypatch):
+    """T-marching depthwise 3x3x3 weight gradient (bf16): against autograd on the bf16-rounded operands and against the strip kernel it
+    replaces; T = 1 (both neighbour frames out of the clip), ragged strips, stride 2, odd widths."""
+    lib = _lib.lib()
+    n, t, h, w = shape
+    g = torch.Generator().manual_seed(c + s + w)
+    x = torch.randn(n, c, t, h, w, generator=g).bfloat16().float()
+    wt = torch.zeros(c, 1, 3, 3, 3, requires_grad=True)
+    y = F.conv3d(x, wt, stride=(1, s, s), padding=1, groups=c)
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    d = _desc(x, y, (3, 3, 3), (1, s, s), (1, 1, 1))
+    xd, dyd = _cl(x, dtype=torch.bfloat16), _cl(dy, dtype=torch.bfloat16)
+    outs = []
+    for no_march in ("0", "1"):
+        monkeypatch.setenv("PASN_NO_DWWG_MARCH", no_march)
+        ws = torch.full((int(lib.pasn_dwconv3d_wgrad_workspace_floats(ctypes.byref(d))),), float("nan"), device=DEV)
+        dw = torch.zeros(c, 27, device=DEV)
+        _lib.check(lib.pasn_dwconv3d_wgrad(xd.data_ptr(), dyd.data_ptr(), ws.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, _st()))
+        torch.cuda.synchronize()
+        _rel(dw.view_as(wt), wt.grad, 1e-4, f"dW (PASN_NO_DWWG_MARCH={no_march})")
+        outs.append(dw)
+    _rel(outs[0], outs[1], 1e-5, "marching vs strip kernel")
+
+
 def test_scatter_strided_and_add():
     lib = _lib.lib()
     src = torch.randn(2, 2, 4, 5, 16, device=DEV)
