@@ -280,6 +280,44 @@ def test_depthwise_dgrad_wgrad(c, k, s, p, shape):
     _rel(dw.view_as(wt), wt.grad, 1e-4, "dW")
 
 
+WGRAD_GATHER_CASES = [
+    # cin, cout, k, s, p, (N,T,H,W) -- windowed / strided convs outside the halo kernel (conv_wgrad_gather_kernel, bf16)
+    (64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 3, 12, 14)),   # R(2+1)D stage transition, spatial
+    (230, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), (2, 6, 7, 7)),    # ... temporal, stride 2 in T
+    (24, 48, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 2, 9, 9)),      # strided shortcut
+    (20, 40, (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 3, 7, 6)),      # 27 taps
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 6, 7)),      # stride 1 but odd W: not the halo kernel's
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,shape", WGRAD_GATHER_CASES)
+def test_conv_wgrad_gather(cin, cout, k, s, p, shape):
+    """Gathered tile weight gradient through the partial buffer (bf16): against autograd, bitwise reproducible."""
+    lib = _lib.lib()
+    n, t, h, w = shape
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout + w)
+    x = torch.randn(n, cin, t, h, w, generator=g).to(dtype).float()
+    wt = torch.zeros(cout, cin, *k, requires_grad=True)
+    y = F.conv3d(x, wt, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(dy)
+    d = _desc(x, y, k, s, p)
+    xd, dyd = _cl(x, dtype=dtype), _cl(dy, dtype=dtype)
+    nbytes = int(lib.pasn_conv3d_wgrad_workspace_bytes(ctypes.byref(d), BF16))
+    assert nbytes > 0
+    taps = k[0] * k[1] * k[2]
+    outs = []
+    for _ in range(2):
+        ws = torch.full((nbytes // 4,), float("nan"), device=DEV)
+        dw = torch.zeros(cout, cin, taps, device=DEV)
+        _lib.check(lib.pasn_conv3d_wgrad_ws(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, ws.data_ptr(), _st()))
+        torch.cuda.synchronize()
+        outs.append(dw.clone())
+    _rel(outs[0].view_as(wt), wt.grad, 1e-4, "dW (gathered tiles, partial buffer)")
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("c,s,shape", [(54, 1, (2, 5, 9, 10)), (54, 2, (2, 4, 12, 14)), (432, 1, (1, 3, 7, 7)), (108, 2, (1, 16, 8, 9)), (216, 1, (2, 1, 5, 4))])
 def test_depthwise_wgrad_march_bf16(c, s, shape, monkeypatch):
     """T-marching depthwise 3x3x3 weight gradient (bf16): against autograd on the bf16-rounded operands and against the strip kernel it
