@@ -399,7 +399,8 @@ static bool wgrad_gather_geom(const pasn_conv_desc& d, int dtype, WgGather& g) {
     if (dtype != PASN_BF16 || d.Cin_p % 8 || d.Cout_p % 8) return false;
     g.taps = d.kt * d.kh * d.kw;
     const bool strided = d.st != 1 || d.sh != 1 || d.sw != 1;
-    if (g.taps == 1 && !strided) return false;  // plain pointwise layers keep their kernels
+    static const bool det = getenv("PASN_WGRAD_DET") ? atoi(getenv("PASN_WGRAD_DET")) != 0 : false;
+    if (g.taps == 1 && !strided && !det) return false;  // plain pointwise layers keep their (atomic) kernels unless asked
     if (g.taps > 27) return false;
     const long R = (long)d.N * d.To * d.Ho * d.Wo, Rin = (long)d.N * d.Ti * d.Hi * d.Wi;
     if (R * d.Cout_p >= (1L << 31) || Rin * d.Cin_p >= (1L << 31)) return false;
@@ -409,7 +410,9 @@ static bool wgrad_gather_geom(const pasn_conv_desc& d, int dtype, WgGather& g) {
     g.Cout_r = g.co_pairs * 64;
     g.Cin_r = g.ci_pairs * 64;
     const long gy = (long)g.co_pairs * g.ci_pairs * g.taps;
-    long parts = std::max<long>(1, std::min<long>(std::min<long>(128, 2048 / gy + 1), R / (2 * WH_KT)));
+    // about 2048 blocks, at least two 128-row steps each, at most 48 MB of partials
+    const long per_part = (long)g.taps * g.Cout_r * g.Cin_r * 4;
+    long parts = std::max<long>(1, std::min<long>(std::min<long>((48L << 20) / per_part, 2048 / gy + 1), R / (2 * WH_KT)));
     const long rpb = (ceil_div(R, parts) + WH_KT - 1) / WH_KT * WH_KT;
     g.rows_per_block = (int)rpb;
     g.parts = (int)ceil_div(R, rpb);
