@@ -169,14 +169,30 @@ class TrainBuilder(PlanBuilder):
         # ---------------- forward conv (raw output) ----------------
         if kind == "first":
             assert x.planar and x.C == 3 and k[0] == 1 and s[0] == 1 and p[0] == 0
-            wfirst = torch.zeros(3 * k[1] * k[2], Cp, dtype=torch.float32, device=self.device)
             d = self._desc(x, y, k, s, p, "none")
-            self.refresh.append(lambda: wfirst[:, :C].copy_(conv.weight.detach().reshape(C, 3, k[1], k[2]).permute(1, 2, 3, 0).reshape(3 * k[1] * k[2], C)))
             one, zero = self.const(Cp, 1.0), self.const(Cp, 0.0)
-            self.keep += [wfirst, one, zero]
+            slot = int(lib.pasn_first_conv_mfma_slot(ctypes.byref(d), _lib.dtype_code(self.in_dtype), code))
             self._use(x.buf, y.buf)
-            self._op(lib.pasn_first_conv_fwd, B(x.buf), wfirst.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), ctypes.byref(d),
-                     _lib.dtype_code(self.in_dtype), code)
+            if slot >= 0:
+                # the 7x7 stride-2 stems with bf16 activations: matrix-core kernel, weights in its K order (rows (ci, r), 8-wide window slots)
+                rows, nq, bn = 3 * k[1], 2 * ((3 * k[1] + 1) // 2), 32 * ((Cp + 31) // 32)
+                wq32 = torch.zeros(nq, bn, 8, dtype=torch.float32, device=self.device)
+                wq = torch.zeros(nq, bn, 8, dtype=torch.bfloat16, device=self.device)
+
+                def refresh_first():
+                    wq32[:rows, :C, slot:slot + k[2]] = conv.weight.detach().reshape(C, 3, k[1], k[2]).permute(1, 2, 0, 3).reshape(rows, C, k[2])
+                    wq.copy_(wq32)
+
+                self.refresh.append(refresh_first)
+                self.keep += [wq32, wq, one, zero]
+                self._op(lib.pasn_first_conv_mfma_fwd, B(x.buf), wq.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), ctypes.byref(d),
+                         _lib.dtype_code(self.in_dtype), 1.0, 0.0)
+            else:
+                wfirst = torch.zeros(3 * k[1] * k[2], Cp, dtype=torch.float32, device=self.device)
+                self.refresh.append(lambda: wfirst[:, :C].copy_(conv.weight.detach().reshape(C, 3, k[1], k[2]).permute(1, 2, 3, 0).reshape(3 * k[1] * k[2], C)))
+                self.keep += [wfirst, one, zero]
+                self._op(lib.pasn_first_conv_fwd, B(x.buf), wfirst.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), ctypes.byref(d),
+                         _lib.dtype_code(self.in_dtype), code)
         elif kind == "dw":
             assert conv.groups == cin == cout == x.C and not x.planar
             dw_w = torch.zeros(taps, Cp, dtype=torch.float32, device=self.device)
