@@ -785,6 +785,79 @@ def test_x3d_stem_mfma(thw, grey, in_dtype, monkeypatch):
     assert_close(_from_cl(out, c), _from_cl(old, c), 3e-2 * scale, 2e-2, f"mfma stem vs VALU stem {thw} {in_dtype}")
 
 
+@pytest.mark.parametrize("layer", ["c133_64_144", "c311_144_64", "first_7x7", "x3d_stem"])
+def test_matrix_core_kernels_at_full_benchmark_shapes(layer, monkeypatch):
+    """The round-2 matrix-core kernels at the FULL shapes of the benchmark configs (8 x 32 x 56 x 56 stage-1 layers of R(2+1)D-18, its
+    7x7 stem on 8 x 3 x 32 x 112 x 112, the X3D stem on 4 x 3 x 16 x 224 x 224), where no CPU oracle finishes in seconds: each must agree
+    with the kernel it replaces (same operands, fp32 accumulation in another order: one bf16 ulp of the output scale), be bitwise
+    reproducible, and keep the padded channels zero."""
+    torch.manual_seed(3)
+    dtype = torch.bfloat16
+
+    def bn_of(c):
+        bn = nn.BatchNorm3d(c)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.5, 1.5)
+        return bn.eval().to(DEV)
+
+    if layer in ("c133_64_144", "c311_144_64"):
+        cin, cout, k, p = (64, 144, (1, 3, 3), (0, 1, 1)) if layer == "c133_64_144" else (144, 64, (3, 1, 1), (1, 0, 0))
+        x = torch.randn(8, cin, 32, 56, 56)
+        conv, bn = nn.Conv3d(cin, cout, k, 1, p, bias=False).to(DEV), bn_of(cout)
+        env, new_name, old_name = "PASN_NO_HALO", "igemm_halo_kernel", "igemm_glds_kernel"
+
+        def run():
+            pb = _pb(dtype)
+            xa, xs = _cl_input(pb, x, dtype)
+            y = pb.conv(xa, conv, bn, "relu")
+            return pb.finish(xa, y).run(xs).clone(), pb.meta[0]["kernel"], cout
+    elif layer == "first_7x7":
+        x = torch.randn(8, 3, 32, 112, 112)
+        conv, bn = nn.Conv3d(3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3), bias=False).to(DEV), bn_of(45)
+        env, new_name, old_name = "PASN_NO_FC_MFMA", "first_conv_mfma_kernel", "first_conv_kernel"
+
+        def run():
+            pb = _pb(dtype, dtype)
+            xa = pb.input(tuple(x.shape))
+            y = pb.first_conv(xa, conv, bn, "relu")
+            return _run_single(pb, xa, y, x.to(DEV).to(dtype).contiguous()).clone(), pb.meta[-1]["kernel"], 45
+    else:
+        from protoasnet_amd.backbones import _X3DStem
+
+        x = torch.randn(4, 3, 16, 224, 224)
+        stem = _X3DStem(24)
+        stem.bn = bn_of(24)
+        stem = stem.eval().to(DEV)
+        env, new_name, old_name = "PASN_NO_STEM_MFMA", "x3d_stem_mfma_kernel", "x3d_stem_kernel"
+
+        def run():
+            pb = _pb(dtype, dtype)
+            xa = pb.input(tuple(x.shape))
+            y = pb.x3d_stem(xa, stem.conv_xy, stem.conv_t, stem.bn)
+            return _run_single(pb, xa, y, x.to(DEV).to(dtype).contiguous()).clone(), pb.meta[-1]["kernel"], 24
+
+    monkeypatch.setenv(env, "0")
+    a, name, c = run()
+    assert name.startswith(new_name), name
+    b, _, _ = run()
+    assert torch.equal(a, b), "bitwise reproducible"
+    monkeypatch.setenv(env, "1")
+    ref, name_old, _ = run()
+    assert name_old.startswith(old_name), name_old
+    torch.cuda.synchronize()
+    af, rf = a[..., :c].float(), ref[..., :c].float()
+    scale = float(rf.abs().max())
+    tol = 2.5e-2 if layer in ("first_7x7", "x3d_stem") else 1.6e-2  # the stems multiply bf16-rounded weights (the VALU kernels fp32 ones)
+    err = float((af - rf).abs().max())
+    assert err <= tol * scale, f"{layer}: max |new - old| = {err:.3g} at output scale {scale:.3g}"
+    assert float((af - rf).abs().mean()) <= 2e-3 * scale
+    if a.shape[-1] > c:
+        assert float(a[..., c:].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool(dtype):
     torch.manual_seed(9)
