@@ -344,6 +344,56 @@ def test_depthwise_wgrad_march_bf16(c, s, shape, monkeypatch):
     _rel(outs[0], outs[1], 1e-5, "marching vs strip kernel")
 
 
+@pytest.mark.parametrize("layer", ["c133_64_144", "c311_144_64", "c133_s2_64_230", "dw_54"])
+def test_weight_gradient_kernels_at_full_benchmark_shapes(layer, monkeypatch):
+    """Round-2 weight-gradient kernels at the full R(2+1)D-18 / X3D-S benchmark shapes (no CPU oracle finishes there in seconds): each
+    must agree with the kernel it replaces (same operands, another summation order) and be bitwise reproducible."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    if layer == "dw_54":
+        n, c, t, h, w = 32, 54, 16, 56, 56
+        d = ConvDesc(N=n, Ti=t, Hi=h, Wi=w, Cin=c, Cin_p=56, To=t, Ho=h, Wo=w, Cout=c, Cout_p=56, kt=3, kh=3, kw=3, st=1, sh=1, sw=1, pt=1, ph=1, pw=1)
+        xd = torch.randn(n, t, h, w, 56, generator=g).bfloat16().to(DEV)
+        dyd = torch.randn(n, t, h, w, 56, generator=g).bfloat16().to(DEV)
+        xd[..., c:] = 0
+        dyd[..., c:] = 0
+        outs = {}
+        for tag, env in (("march", "0"), ("march2", "0"), ("strip", "1")):
+            monkeypatch.setenv("PASN_NO_DWWG_MARCH", env)
+            ws = torch.empty(int(lib.pasn_dwconv3d_wgrad_workspace_floats(ctypes.byref(d))), device=DEV)
+            dw = torch.zeros(c, 27, device=DEV)
+            _lib.check(lib.pasn_dwconv3d_wgrad(xd.data_ptr(), dyd.data_ptr(), ws.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, _st()))
+            torch.cuda.synchronize()
+            outs[tag] = dw
+        assert torch.equal(outs["march"], outs["march2"])
+        _rel(outs["march"], outs["strip"], 2e-4, "marching vs strip depthwise dW at 32x16x56x56")
+        return
+    cin, cout, k, s_, p, shape = {"c133_64_144": (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 32, 56, 56)),
+                                  "c311_144_64": (144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (8, 32, 56, 56)),
+                                  "c133_s2_64_230": (64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), (8, 32, 56, 56))}[layer]
+    n, t, h, w = shape
+    to, ho, wo = (t + 2 * p[0] - k[0]) // s_[0] + 1, (h + 2 * p[1] - k[1]) // s_[1] + 1, (w + 2 * p[2] - k[2]) // s_[2] + 1
+    cinp, coutp = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+    d = ConvDesc(N=n, Ti=t, Hi=h, Wi=w, Cin=cin, Cin_p=cinp, To=to, Ho=ho, Wo=wo, Cout=cout, Cout_p=coutp, kt=k[0], kh=k[1], kw=k[2],
+                 st=s_[0], sh=s_[1], sw=s_[2], pt=p[0], ph=p[1], pw=p[2])
+    xd = torch.randn(n, t, h, w, cinp, generator=g).bfloat16().to(DEV)
+    dyd = torch.randn(n, to, ho, wo, coutp, generator=g).bfloat16().to(DEV)
+    xd[..., cin:] = 0
+    dyd[..., cout:] = 0
+    taps = k[0] * k[1] * k[2]
+    nbytes = int(lib.pasn_conv3d_wgrad_workspace_bytes(ctypes.byref(d), BF16))
+    assert nbytes > 0
+    outs = []
+    for wsp in (True, True, False):
+        ws = torch.full((nbytes // 4,), float("nan"), device=DEV)
+        dw = torch.zeros(cout, cin, taps, device=DEV)
+        _lib.check(lib.pasn_conv3d_wgrad_ws(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, ws.data_ptr() if wsp else 0, _st()))
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]), "partial-buffer path: fixed summation order"
+    _rel(outs[0], outs[2], 2e-4, f"{layer}: partial-buffer kernel vs the atomic per-tap kernel")
+
+
 def test_scatter_strided_and_add():
     lib = _lib.lib()
     src = torch.randn(2, 2, 4, 5, 16, device=DEV)
