@@ -374,10 +374,26 @@ extern "C" int pasn_first_conv_wgrad(const void* x, const void* dy, float* dw, c
 // 3x3x3, stride (1,2,2), pad 1 (the first block of every X3D stage): a thread owns a 2x2 input patch.  Even rows / columns
 // see only the centre tap, odd ones the two outer taps, so the four pixels need dy[to][i..i+1][j..j+1] for the three temporal
 // taps -- 12 loads and 27 FMAs per channel for 4 outputs, no divergent tap loop.
-template <typename T>
+template <int CH, typename T>
+__device__ __forceinline__ void dg_load(const T* p, float (&v)[CH]) {
+    if constexpr (CH == 8) load8(p, v);
+    else load4(p, v);
+}
+template <int CH, typename T>
+__device__ __forceinline__ void dg_store(T* p, const float (&v)[CH]) {
+    if constexpr (CH == 8) store8(p, v);
+    else store4(p, v);
+}
+
+template <typename T, int CH>  // CH channels per thread: 4 keeps the patch + taps + gradients at ~130 registers (8: 330, one wave per SIMD)
 __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
                                                           pasn_conv_desc d) {
-    const int CG = d.Cin_p / 8, Hh = (d.Hi + 1) / 2, Wh = (d.Wi + 1) / 2;
+    // the 27 x Cp taps in LDS, staged once per block (the first version read its 27 weight vectors per patch from global memory: 864
+    // bytes of weights for 192 bytes of gradients per thread)
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [27][Cp]
+    for (int i = threadIdx.x * 4; i < 27 * d.Cout_p; i += 256 * 4) *reinterpret_cast<f32x4*>(wl + i) = *reinterpret_cast<const f32x4*>(w + i);
+    __syncthreads();
+    const int CG = d.Cin_p / CH, Hh = (d.Hi + 1) / 2, Wh = (d.Wi + 1) / 2;
     const size_t total = (size_t)d.N * d.Ti * Hh * Wh * CG;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int cg = (int)(idx % CG);
@@ -387,41 +403,52 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const T* __restrict__ 
         const int i = (int)(q % Hh);
         q /= Hh;
         const int ti = (int)(q % d.Ti), n = (int)(q / d.Ti);
-        float o[2][2][8];
+        float o[2][2][CH];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[a][b][e] = 0.0f;
+                for (int e = 0; e < CH; ++e) o[a][b][e] = 0.0f;
+        // all twelve gradient loads first (clamped addresses), masks afterwards
+        float g[3][2][2][CH];
+        unsigned okbits = 0;
+#pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             const int to = ti + 1 - kt;
-            if (to < 0 || to >= d.To) continue;
-            float g[2][2][8];
+            const bool tok = to >= 0 && to < d.To;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int ho = i + a, wo = j + b;
-                    const bool ok = ho < d.Ho && wo < d.Wo;
-                    load8(dy + ((((size_t)n * d.To + to) * d.Ho + (ok ? ho : 0)) * d.Wo + (ok ? wo : 0)) * d.Cout_p + cg * 8, g[a][b]);
-                    if (!ok) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) g[a][b][e] = 0.0f;
-                    }
+                    const bool ok = tok && ho < d.Ho && wo < d.Wo;
+                    dg_load<CH>(dy + ((((size_t)n * d.To + (tok ? to : 0)) * d.Ho + (ok ? ho : 0)) * d.Wo + (ok ? wo : 0)) * d.Cout_p + cg * CH, g[kt][a][b]);
+                    okbits |= (ok ? 1u : 0u) << (kt * 4 + a * 2 + b);
                 }
-            const float* wk = w + (size_t)kt * 9 * d.Cout_p + cg * 8;
-            float wv[9][8];
+        }
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) load8(wk + (size_t)tp * d.Cout_p, wv[tp]);
+        for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (!((okbits >> (kt * 4 + a * 2 + b)) & 1u)) {
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) g[kt][a][b][e] = 0.0f;
+                    }
+            const float* wk = wl + kt * 9 * d.Cout_p + cg * CH;
+            float wv[9][CH];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) dg_load<CH>(wk + tp * d.Cout_p, wv[tp]);
             // input (2i+a, 2j+b) <- output (ho, wo) through tap (kh, kw) with 2*ho - 1 + kh = 2i + a
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                o[0][0][e] = fmaf(g[0][0][e], wv[4][e], o[0][0][e]);                                             // (1,1)
-                o[0][1][e] = fmaf(g[0][0][e], wv[5][e], fmaf(g[0][1][e], wv[3][e], o[0][1][e]));                  // (1,2) from j, (1,0) from j+1
-                o[1][0][e] = fmaf(g[0][0][e], wv[7][e], fmaf(g[1][0][e], wv[1][e], o[1][0][e]));                  // (2,1) from i, (0,1) from i+1
-                o[1][1][e] = fmaf(g[0][0][e], wv[8][e], fmaf(g[0][1][e], wv[6][e],
-                             fmaf(g[1][0][e], wv[2][e], fmaf(g[1][1][e], wv[0][e], o[1][1][e]))));
+            for (int e = 0; e < CH; ++e) {
+                o[0][0][e] = fmaf(g[kt][0][0][e], wv[4][e], o[0][0][e]);                                                      // (1,1)
+                o[0][1][e] = fmaf(g[kt][0][0][e], wv[5][e], fmaf(g[kt][0][1][e], wv[3][e], o[0][1][e]));                      // (1,2) from j, (1,0) from j+1
+                o[1][0][e] = fmaf(g[kt][0][0][e], wv[7][e], fmaf(g[kt][1][0][e], wv[1][e], o[1][0][e]));                      // (2,1) from i, (0,1) from i+1
+                o[1][1][e] = fmaf(g[kt][0][0][e], wv[8][e], fmaf(g[kt][0][1][e], wv[6][e],
+                             fmaf(g[kt][1][0][e], wv[2][e], fmaf(g[kt][1][1][e], wv[0][e], o[1][1][e]))));
             }
         }
 #pragma unroll
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const T* __restrict__ 
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int hi = 2 * i + a, wi = 2 * j + b;
-                if (hi < d.Hi && wi < d.Wi) store8(dx + ((((size_t)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.Cin_p + cg * 8, o[a][b]);
+                if (hi < d.Hi && wi < d.Wi) dg_store<CH>(dx + ((((size_t)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.Cin_p + cg * CH, o[a][b]);
             }
     }
 }
@@ -438,13 +465,14 @@ extern "C" int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, con
     PASN_REQUIRE(dy && w && dx && d, "null pointer");
     PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0, "depthwise conv keeps the channel stride");
     if (d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 1 && d->ph == 1 && d->pw == 1 &&
-        !getenv("PASN_NO_DGRAD_S2")) {
-        const size_t items = (size_t)d->N * d->Ti * ((d->Hi + 1) / 2) * ((d->Wi + 1) / 2) * (d->Cin_p / 8);
-        const int nb = (int)std::min<size_t>((items + 255) / 256, 1 << 20);
+        d->Cout_p <= 512 && !getenv("PASN_NO_DGRAD_S2")) {
+        const size_t items = (size_t)d->N * d->Ti * ((d->Hi + 1) / 2) * ((d->Wi + 1) / 2) * (d->Cin_p / 4);
+        const int nb = (int)std::min<size_t>((items + 255) / 256, 4096);  // grid-stride: the weight staging amortises over many patches
+        const size_t wlds = (size_t)27 * d->Cout_p * sizeof(float);  // <= 55 KB (Cout_p <= 512 checked above)
         if (dtype == PASN_BF16)
-            hipLaunchKernelGGL(dw_dgrad_s2_kernel<__bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, w, (__bf16*)dx, *d);
+            hipLaunchKernelGGL((dw_dgrad_s2_kernel<__bf16, 4>), dim3(nb), dim3(256), wlds, (hipStream_t)stream, (const __bf16*)dy, w, (__bf16*)dx, *d);
         else
-            hipLaunchKernelGGL(dw_dgrad_s2_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, *d);
+            hipLaunchKernelGGL((dw_dgrad_s2_kernel<float, 4>), dim3(nb), dim3(256), wlds, (hipStream_t)stream, (const float*)dy, w, (float*)dx, *d);
         return check_launch("dwconv3d_dgrad");
     }
     const size_t total = (size_t)d->N * d->Ti * d->Hi * d->Wi * (d->Cin_p / 8);
