@@ -151,16 +151,16 @@ __global__ __launch_bounds__(256, 2) void first_conv_mfma_kernel(const TIN* __re
     });
 }
 
-// Slot of tap 0 inside the 8-wide window, or -1 when this layer is not covered: (1,kh,kw) stride (1,2,2), kw <= 7 with the window start
-// on a multiple of 4 input columns, Wi % 4 == 0, bf16 output, Cout_p <= 64, C*kh <= 22.
+// Slot of tap 0 inside the 8-wide window, or -1 when this layer is not covered: (1,kh,kw) stride (1,2,2), slot + kw <= 8 with the window
+// start on a multiple of 4 input columns (slot = (4 - pw) mod 4), Wi % 4 == 0, bf16 output, Cout_p <= 64, C*kh <= 22.
 int first_conv_mfma_slot(const pasn_conv_desc& d, int out_dtype) {
     if (const char* e = getenv("PASN_NO_FC_MFMA"))
         if (e[0] == '1') return -1;
     if (out_dtype != PASN_BF16 || d.kt != 1 || d.st != 1 || d.pt != 0 || d.sh != 2 || d.sw != 2) return -1;
     if (d.Cin != 1 && d.Cin != 3) return -1;
     if (d.Cout_p > 64 || d.Wi % 4 != 0 || d.kw > 7 || d.pw > 4 || d.Cin * d.kh > 22) return -1;
-    const int o = (4 - d.pw) & 1;  // the window starts on an even patch column
-    if (o + d.kw > 8 || (d.pw + o) % 4 != 0) return -1;
+    const int o = (4 - d.pw % 4) % 4;  // the window starts on a multiple of 4 input columns (aligned staging units, even patch column)
+    if (o + d.kw > 8) return -1;
     if (2 * (FC_COLS - 1) + 8 > FC_PC) return -1;
     return o;
 }
@@ -179,6 +179,7 @@ static int launch_fc_mfma_t(const void* x, const void* wq, const float* scale, c
         return check_launch("first_conv_mfma_kernel");                                                                           \
     }
     PASN_FCM(2, 11) PASN_FCM(1, 11) PASN_FCM(2, 4) PASN_FCM(1, 4)  // 3 x 7 rows (the 7x7 stems), 1 x 7 rows (grey)
+    PASN_FCM(2, 5) PASN_FCM(1, 5) PASN_FCM(2, 2) PASN_FCM(1, 2)    // 3 x 3 rows (X3D conv_xy when the stem is not fused), 1 x 3 rows
 #undef PASN_FCM
     set_error("first_conv_mfma: no such instance");
     return PASN_ERR_UNSUPPORTED;

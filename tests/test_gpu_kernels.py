@@ -413,6 +413,8 @@ FC_MFMA_CASES = [
     (64, (7, 7), (3, 3), (1, 36, 140), "relu", False),   # ResNet-18 conv1; 70 output columns = two column tiles, 18 rows = ragged row tile
     (45, (7, 7), (3, 3), (3, 16, 16), "none", True),     # grey clip: taps summed over the input channels, normalisation at load
     (24, (7, 7), (3, 3), (1, 12, 132), "relu", False),   # one 32-channel tile
+    (24, (3, 3), (1, 1), (3, 18, 24), "none", False),    # X3D conv_xy (the unfused stem of the training path): window slot 3
+    (24, (3, 3), (1, 1), (2, 9, 16), "relu", True),      # ... grey
 ]
 
 
@@ -704,6 +706,7 @@ def test_x3d_stem_fused(thw, dtypes, monkeypatch):
     the unfused path stores)."""
     in_dtype, dtype = dtypes
     monkeypatch.setenv("PASN_NO_STEM_MFMA", "1")  # the matrix-core stem (bf16, W % 4 == 0) is a tolerance path: test_x3d_stem_mfma
+    monkeypatch.setenv("PASN_NO_FC_MFMA", "1")    # ... and so is the matrix-core first conv the unfused pair would take
     torch.manual_seed(21)
     n, c = 2, 24
     x = torch.randn(n, 3, *thw)
