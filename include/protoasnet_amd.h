@@ -377,6 +377,11 @@ int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, const pasn_con
  * alone, backward is dr = sign(r) * docc (every other pointer but r / occ / docc / dr may be NULL). */
 int pasn_xproto_tail_fwd(const void* z, const void* r, const float* protos, const float* fc_w, float* occ, float* feat, float* sim,
                          float* logits, const pasn_xproto_desc* d, int dtype, void* stream);
+/* pasn_xproto_tail_fwd with a workspace of pasn_xproto_tail_workspace_bytes(d) bytes (0: no workspace path, ws may be NULL): the pooling
+ * then runs on the matrix cores split over S, as in pasn_xproto_head_fwd. */
+size_t pasn_xproto_tail_workspace_bytes(const pasn_xproto_desc* d);
+int pasn_xproto_tail_fwd_ws(const void* z, const void* r, const float* protos, const float* fc_w, float* occ, float* feat, float* sim,
+                            float* logits, const pasn_xproto_desc* d, int dtype, void* ws, void* stream);
 int pasn_xproto_tail_bwd(const void* z, const void* r, const float* protos, const float* fc_w, const float* feat, const float* sim,
                          const float* dlogits, const float* dsim, const float* docc, float* dfeat, void* dz, void* dr, float* dprotos,
                          float* dfc_w, const pasn_xproto_desc* d, int dtype, void* stream);

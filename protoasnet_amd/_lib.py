@@ -84,6 +84,8 @@ SIGNATURES = {
     "pasn_dwconv3d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_dwconv3d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_xproto_tail_fwd": (c_int, [c_void_p] * 8 + [POINTER(XProtoDesc), c_int, c_void_p]),
+    "pasn_xproto_tail_workspace_bytes": (c_size_t, [POINTER(XProtoDesc)]),
+    "pasn_xproto_tail_fwd_ws": (c_int, [c_void_p] * 8 + [POINTER(XProtoDesc), c_int, c_void_p, c_void_p]),
     "pasn_xproto_tail_bwd": (c_int, [c_void_p] * 14 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_l2_head_bwd": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_void_p]),
     "pasn_affine_warp_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_float, c_int, c_void_p]),

@@ -213,6 +213,31 @@ extern "C" int pasn_xproto_tail_fwd(const void* z, const void* r, const float* p
     return check_launch("xproto_tail_fwd");
 }
 
+namespace pasn {
+int xproto_tail_splits(const pasn_xproto_desc& d);
+int xproto_tail_pool_finish(const void* z, const void* r, const float* protos, const float* fc_w, float* occ, float* feat, float* sim,
+                            float* logits, float* slabs, const pasn_xproto_desc& d, int dtype, hipStream_t s);
+}  // namespace pasn
+
+// The same forward with a workspace of pasn_xproto_tail_workspace_bytes(d) bytes: pooling on the matrix cores split over S (the kernels of
+// the inference head) instead of N x P/8 blocks that each walk all S positions (R(2+1)D-18, 8 clips: 32 blocks, 438 us per step).
+extern "C" size_t pasn_xproto_tail_workspace_bytes(const pasn_xproto_desc* d) {
+    if (!d || d->N <= 0 || d->S <= 0 || d->P <= 0 || d->D <= 0) return 0;
+    if (const char* e = getenv("PASN_NO_TAIL_MFMA"))
+        if (e[0] == '1') return 0;
+    if (d->D % 4 != 0 || d->D > 1024) return 0;
+    return (size_t)d->N * xproto_tail_splits(*d) * d->P * d->D * sizeof(float);
+}
+
+extern "C" int pasn_xproto_tail_fwd_ws(const void* z, const void* r, const float* protos, const float* fc_w, float* occ, float* feat,
+                                       float* sim, float* logits, const pasn_xproto_desc* d, int dtype, void* ws, void* stream) {
+    if (!ws || pasn_xproto_tail_workspace_bytes(d) == 0) return pasn_xproto_tail_fwd(z, r, protos, fc_w, occ, feat, sim, logits, d, dtype, stream);
+    PASN_REQUIRE(r && occ && d, "null pointer");
+    PASN_REQUIRE(z == nullptr || (protos && fc_w && feat && sim && logits), "null pointer (only the occurrence-map mode, z == NULL, may omit them)");
+    PASN_REQUIRE(d->Dp % 8 == 0 && d->Pp % 8 == 0 && d->P <= 256 && d->P <= d->Pp && d->D <= d->Dp, "bad head extents (P <= 256)");
+    return xproto_tail_pool_finish(z, r, protos, fc_w, occ, feat, sim, logits, (float*)ws, *d, dtype, (hipStream_t)stream);
+}
+
 extern "C" int pasn_xproto_tail_bwd(const void* z, const void* r, const float* protos, const float* fc_w, const float* feat, const float* sim,
                                     const float* dlogits, const float* dsim, const float* docc, float* dfeat, void* dz, void* dr,
                                     float* dprotos, float* dfc_w, const pasn_xproto_desc* d, int dtype, void* stream) {

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void xproto_pool_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(64) void xproto_pool_mfma_kernel(const T* __restrict__ occ_cl, const T* __restrict__ f,
                                                               float* __restrict__ occ_planar, float* __restrict__ ws, int S, int P, int Pp,
-                                                              int D, int Dp, int G, int pbase, int do_pool) {
+                                                              int D, int Dp, int G, int pbase, int do_pool, int abs_in) {
     __shared__ float tile[2][32][65];
     const int lane = threadIdx.x, c = lane & 31, kq = lane >> 5;
     const int g = blockIdx.x, dg = blockIdx.y, n = blockIdx.z;
@@ -111,7 +111,10 @@ __global__ __launch_bounds__(64) void xproto_pool_mfma_kernel(const T* __restric
         for (int u = 0; u < 4; ++u) {
             const long row = (long)n * S + min(sq + 2 * u + kq, S - 1);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) av[u][a] = (float)occ_cl[row * Pp + pcol[a]];
+            for (int a = 0; a < 2; ++a) {
+                const float o = (float)occ_cl[row * Pp + pcol[a]];
+                av[u][a] = abs_in ? fabsf(o) : o;  // training tail: the occurrence module's output before its |.|
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) bv[u][b] = (float)f[row * Dp + dcol[b]];
         }
@@ -300,6 +303,42 @@ static bool xp_pool_mfma() {
     return !(e && e[0] == '1');
 }
 
+// Pooling on the matrix cores + finish, for the training tail (head_train.hip): r = occurrence-module output BEFORE its |.| (abs applied
+// on load), z = add-on output (NULL: occurrence map only), slabs = [N][G][P][D] floats.  Same kernels as the inference head.
+namespace pasn {
+int xproto_tail_splits(const pasn_xproto_desc& d) {
+    const long base = (long)d.N * ceil_div(d.D, 128) * ceil_div(d.P, 64);
+    long G = (2048 + base - 1) / base;
+    const long gmax = ceil_div(d.S, 64);
+    return (int)std::max<long>(1, std::min(G, gmax));
+}
+int xproto_tail_pool_finish(const void* z, const void* r, const float* protos, const float* fc_w, float* occ, float* feat, float* sim,
+                            float* logits, float* slabs, const pasn_xproto_desc& d, int dtype, hipStream_t s) {
+    const int G = xproto_tail_splits(d);
+    const bool full = z != nullptr;
+    const dim3 grid(G, full ? ceil_div(d.D, 128) : 1, d.N), block(64);
+    // occurrence map only: the kernel still issues its (unused) feature loads -- point them at r itself with r's row width
+    const int D_ = full ? d.D : 0, Dp_ = full ? d.Dp : d.Pp;
+    for (int pbase = 0; pbase < d.P; pbase += 64) {
+        if (dtype == PASN_F32)
+            hipLaunchKernelGGL((xproto_pool_mfma_kernel<float>), grid, block, 0, s, (const float*)r, (const float*)(full ? z : r), occ, slabs, d.S, d.P,
+                               d.Pp, D_, Dp_, G, pbase, full ? 1 : 0, 1);
+        else
+            hipLaunchKernelGGL((xproto_pool_mfma_kernel<__bf16>), grid, block, 0, s, (const __bf16*)r, (const __bf16*)(full ? z : r), occ, slabs, d.S,
+                               d.P, d.Pp, D_, Dp_, G, pbase, full ? 1 : 0, 1);
+    }
+    if (full) {
+        if (d.D <= 256)
+            hipLaunchKernelGGL((xproto_finish_kernel<1, 1024>), dim3(d.N), dim3(1024), (size_t)d.P * sizeof(float), s, slabs, protos, fc_w, feat, sim,
+                               logits, G, d.P, d.D, d.K);
+        else
+            hipLaunchKernelGGL((xproto_finish_kernel<4, 256>), dim3(d.N), dim3(256), (size_t)d.P * sizeof(float), s, slabs, protos, fc_w, feat, sim,
+                               logits, G, d.P, d.D, d.K);
+    }
+    return check_launch("xproto_tail_pool_finish");
+}
+}  // namespace pasn
+
 extern "C" int pasn_xproto_head_splits(const pasn_xproto_desc* d) {
     if (!xp_desc_ok(d)) return 0;
     const int pc = d->P <= 32 ? 32 : 64;
@@ -356,10 +395,10 @@ extern "C" int pasn_xproto_head_fwd(const void* x, const void* a1, const float* 
         for (int pbase = 0; pbase < d->P; pbase += 64) {
             if (dtype == PASN_F32)
                 hipLaunchKernelGGL((xproto_pool_mfma_kernel<float>), grid, block, 0, s, (const float*)b_occ, (const float*)b_f, occ, b_slabs,
-                                   d->S, d->P, d->Pp, d->D, d->Dp, G, pbase, full ? 1 : 0);
+                                   d->S, d->P, d->Pp, d->D, d->Dp, G, pbase, full ? 1 : 0, 0);
             else
                 hipLaunchKernelGGL((xproto_pool_mfma_kernel<__bf16>), grid, block, 0, s, (const __bf16*)b_occ, (const __bf16*)b_f, occ, b_slabs,
-                                   d->S, d->P, d->Pp, d->D, d->Dp, G, pbase, full ? 1 : 0);
+                                   d->S, d->P, d->Pp, d->D, d->Dp, G, pbase, full ? 1 : 0, 0);
         }
     } else {
     const int pc = d->P <= 32 ? 32 : 64;

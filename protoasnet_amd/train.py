@@ -425,8 +425,11 @@ class TrainBuilder(PlanBuilder):
         dref, code, lib, B, Pm = ctypes.byref(d), self.code, self.lib, self.B, self.Pm
         zb = z.buf if z is not None else None
         e = ext
-        self._use(zb, r.buf)
-        self._op(lib.pasn_xproto_tail_fwd, B(zb), B(r.buf), Pm(pv), Pm(fw), B(e["occ"]), B(e["feat"]), B(e["sim"]), B(e["logits"]), dref, code)
+        wsz = int(lib.pasn_xproto_tail_workspace_bytes(dref))  # split-S pooling on the matrix cores (the inference head's kernels)
+        wsb = self._new_buf(wsz) if wsz else None
+        self._use(zb, r.buf, wsb)
+        self._op(lib.pasn_xproto_tail_fwd_ws, B(zb), B(r.buf), Pm(pv), Pm(fw), B(e["occ"]), B(e["feat"]), B(e["sim"]), B(e["logits"]), dref, code,
+                 B(wsb))
 
         def backward() -> None:
             dz = self.like(z) if z is not None else None
