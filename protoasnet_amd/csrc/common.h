@@ -89,6 +89,17 @@ struct DwSeArgs {
 };
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
                     const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+// dwmfma.hip: the stride-1 depthwise 3x3x3 stencil on the matrix cores (block-diagonal bf16 weight operands, LDS-DMA frame ring, T-marching); ok = 0: not covered
+struct DwMfmaGeom {
+    int ok, CT, CQ;            // channel tiles of 16, quads of 4 tiles (one block owns a quad)
+    int BH, BW, RPT, RTH, RTW;  // outputs per region, output rows per 16-lane position tile, regions per frame
+    int RP, NI;                // staged positions per frame, 1-KiB DMA instructions per frame
+    int Tc, nT, upb, chunks, bpc;  // T chunk (+count), units (T chunk x region) per block, SE partial rows per clip, blocks per clip
+    int abl;                   // timing ablations (PASN_DWMFMA_ABL; results are wrong when set)
+};
+DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
+int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
+                   const DwMfmaGeom& g, hipStream_t s);
 // igemm.hip: windowed dense convs (bf16) as an implicit GEMM with direct-to-LDS staging; NT = 0: not covered
 int igemm_nt(const pasn_conv_desc& d, int dtype);
 // first_conv_mfma.hip: the 7x7 stride-2 stems on the matrix cores (bf16 out); slot < 0: not covered

@@ -844,6 +844,7 @@ extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
     const Dw2Geom m2 = dw_march2_geom(*d, dtype);
     if (m2.WT) return 40000 + m2.CH * 1000 + m2.WT * 10 + d->sw;  // dwconv3d_march2_kernel<SW, WT, CH>
+    if (dw_mfma_geom(*d, dtype).ok) return 50000;                     // dwconv3d_mfma_kernel
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return 3000 + m.WT * 10 + d->sw;  // dwconv3d_march_kernel<SW, WT>
     const DwGeom g = dw_geom(*d);
@@ -854,6 +855,8 @@ extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
     const Dw2Geom m2 = dw_march2_geom(*d, dtype);
     if (m2.WT) return m2.bpc;
+    const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
+    if (mf.ok) return mf.chunks;
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return m.bpc;
     return dw_geom(*d).blocks;
@@ -867,6 +870,8 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     hipStream_t s = (hipStream_t)stream;
     const Dw2Geom m2 = dw_march2_geom(*d, dtype);
     if (m2.WT) return launch_dw_march2(x, w, scale, bias, y, pool_partial, *d, m2, s);
+    const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
+    if (mf.ok) return launch_dw_mfma(x, w, scale, bias, y, pool_partial, *d, mf, s);
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return launch_dw_march(x, w, scale, bias, y, pool_partial, *d, m, s);
     if (dtype == PASN_F32) return launch_dwconv3d<float>(x, w, scale, bias, y, pool_partial, *d, s);
@@ -882,6 +887,7 @@ extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, in
     if (const char* e = getenv("PASN_NO_SE_FUSE"))
         if (e[0] == '1') return 0;
     if (dw_march2_geom(*d, dtype).WT) return 0;  // the opt-in second-generation kernel has no fused gate
+    if (dw_mfma_geom(*d, dtype).ok) return 0;    // nor has the matrix-core stencil
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     // The last block of a clip computes the gate alone, at the END of the launch: atomic + acquire, the partial rows (agent-scope loads:
     // memory-side round trips), two FCs -- an exposed tail of 5-30 us that grows with the channel count (432 channels: +29 us per launch,

@@ -1,0 +1,398 @@
+// Depthwise 3x3x3 stencil (stride 1, pad 1, bf16) on the MATRIX CORES -- the X3D conv_b of every stride-1 block, third generation.
+//
+// Why: both VALU generations (dwmarch.hip, dwmarch2.hip) are bound by vector-instruction issue, not by bytes: per output element 27
+// fp32 FMAs plus the bf16->fp32 conversions, padding selects and accumulator moves around them (FMAs are ~1/3 of the issued
+// instructions; 0.29 of the HBM rate on the 54-channel 56x56 layer).  The matrix cores take bf16 operands as they lie in memory
+// and issue beside the vector unit, so the whole inner loop moves there with a BLOCK-DIAGONAL weight operand:
+//
+//   v_mfma_f32_16x16x32_bf16:  D[16 channels][16 positions] += A[16 channels][K = 32] * B[K = 32][16 positions]
+//   K = 2 taps x 16 channels;  B[(tap, c')][p] = x[p + tap][c0 + c'] -- for lane (p = lane & 15, g = lane >> 4) ONE 16-byte read:
+//   8 consecutive channels c0 + 8 (g & 1) .. of the position shifted by tap (g >> 1) of the pair, no conversion;
+//   A[c][(tap, c')] = w[tap][c0 + c] if c' == c else 0 -- 15 such operands (3 kt x 5 pairs of the 9 (kh, kw) taps), built once per
+//   wave and kept in registers.
+//
+// 1/16 of every MFMA is useful work, which is still 27 useful MACs per 16 x 16 outputs per 15 MFMAs x 16 cycles -- what the packed fp32
+// FMAs alone would take if nothing else had to be issued -- and the vector unit is left to the epilogue (scale, bias, Swish, SE partial
+// sums, bf16 stores).  As in dwmarch.hip a wave MARCHES ALONG T with three accumulator sets per position tile (outputs t-1, t, t+1):
+// every operand read feeds the three kt taps.
+//
+// Operand supply.  A first version read the B operands straight from global memory (16 positions x 2 x 32-byte pieces per
+// wave-instruction): 30 % SLOWER than the VALU kernel, bound by L1 tag lookups (~44 cycles per wave-load, ring depth irrelevant).  Here a
+// block owns BH x BW outputs (4 x 14) of one 64-channel quad and stages the (BH+2) x (BW+2) input region of every frame by LDS-DMA
+// (whole 128-byte position rows; cells outside the image are zeroed once per unit and never fetched) into a 3-frame ring; B operands are ds_read_b128 from a
+// position stride of 160 bytes (10 slots: conflict-free for the read's four 16-lane groups, see the bank rule in the guide).  One
+// barrier per frame; a wave's DMA for frame t+2 is issued right after it, under the 60 MFMAs of frame t.
+//
+// Weights are rounded to bf16 here (round-to-nearest-even), like the weights of every other bf16 conv of the path; accumulation is
+// fp32.  A zero weight times a non-finite activation of ANOTHER channel of the tile would leak (0 x inf); the trunk's activations are
+// finite.  Work split: block = 4 waves = the 4 channel tiles of a quad; unit = (T chunk, region); a block walks `upb` units; SE partial
+// sums: one row per (clip, chunk), every channel written by exactly one wave, fixed summation order.
+#include "common.h"
+
+namespace pasn {
+
+typedef __attribute__((ext_vector_type(4))) unsigned dwm_u32x4;
+typedef __attribute__((address_space(3))) void* dwm_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* dwm_gbl_ptr_t;
+
+constexpr int DWF_SLOTS = 10;   // 16-byte slots per staged position (8 used)
+constexpr int DWF_NTL = 4;      // position tiles per wave (4 x 14 outputs; 7 tiles = 84 accumulator registers spill at two waves per SIMD)
+constexpr int DWF_NE = 7;       // DMA instructions per wave and frame (<= 28 per block)
+constexpr int DWF_RING = 3;
+constexpr int DWF_PITCH = 16;   // staged positions per region row
+constexpr int DWF_OPITCH = 136; // bytes per position of the output image (128 used)
+constexpr int DWF_OBYTES = DWF_NTL * 16 * DWF_OPITCH;
+
+__device__ __forceinline__ unsigned bf16_bits_rne(float f) {
+    const __bf16 b = (__bf16)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ void dwf_wait_all_but(int n) {  // n wave-uniform: everything but this wave's n most recent vector-memory ops is done
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;  // n <= DWF_NE + DWF_NTL = 11
+    }
+}
+
+// Barrier of the frame loop WITHOUT the fence of __syncthreads(): that fence is `s_waitcnt vmcnt(0)`, which drains the DMA groups of the
+// next frames (and the output stores) at every frame and serialises the ring.  Here only LDS traffic is drained; what must have landed
+// from memory is waited for by count (dwf_wait_all_but) just before.
+__device__ __forceinline__ void dwf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int RPT>
+__global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ scale, const float* __restrict__ bias,
+                                                               __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
+                                                               DwMfmaGeom g) {
+    extern __shared__ __attribute__((aligned(1024))) char ring[];  // [DWF_RING][NI x 1024]: frame images, position stride 160 bytes
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = lb / g.bpc, bx = lb - n * g.bpc;
+    const int chunk = bx / g.CQ, cq = bx - chunk * g.CQ;
+    const int Cp = d.Cout_p;
+    const int c0 = (cq * 4 + wave) * 16;
+    const bool wave_live = c0 < Cp;                  // wave-uniform: the last channel quad may be short (the wave still stages and syncs)
+    const int npieces = min(8, (Cp - cq * 64) / 8);  // 16-byte pieces per position of this quad
+
+    // ---- block-diagonal weight operands A[kt][pair]: lane (m, q) holds k = 8q .. 8q+7 = tap (q >> 1) of the pair, channels 8 (q & 1) ..;
+    // only element (m & 7) can be nonzero, and only when m's half matches
+    dwm_u32x4 A[3][5];
+    {
+        const int c = c0 + m;
+        const bool mine = ((m >> 3) == (q & 1)) && c < Cp;
+        const int dwsel = (m & 7) >> 1, sh = (m & 1) * 16;
+        // all 15 loads first, from clamped (always valid) addresses: predicated loads became 15 dependent round trips (~35 us per block)
+        float wv[3][5];
+        const int cc = min(c, Cp - 1);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) wv[kt][j] = w[(kt * 9 + min(2 * j + (q >> 1), 8)) * Cp + cc];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const bool live = mine && 2 * j + (q >> 1) < 9;
+                const unsigned bits = live ? (bf16_bits_rne(wv[kt][j]) << sh) : 0u;
+                A[kt][j] = dwm_u32x4{dwsel == 0 ? bits : 0u, dwsel == 1 ? bits : 0u, dwsel == 2 ? bits : 0u, dwsel == 3 ? bits : 0u};
+            }
+    }
+    // epilogue constants of this lane's 4 output channels c0 + 4q + i
+    const int ce = c0 + 4 * q;
+    const bool cev = ce < Cp;
+    float sc[4], bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = cev ? scale[ce + i] : 0.0f;
+        bs[i] = cev ? bias[ce + i] : 0.0f;
+    }
+    float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
+    const long fstride = (long)Hi * Wi * Cp;  // elements per frame
+    const __bf16* xclip = x + (long)n * Ti * fstride + cq * 64;
+    constexpr int RW = DWF_PITCH;  // staged positions per region row (BW + 2 <= 16 used)
+    // frame image size is a compile-time constant of the instance (the ring slots, the DMA destinations and the operand reads are then
+    // immediates: as run-time scalars they cost ~90 spilled SGPRs, reloaded lane by lane at every frame)
+    constexpr int NI = ((DWF_NTL * RPT + 2) * DWF_PITCH * DWF_SLOTS + 63) / 64;
+    constexpr int fbytes = NI * 1024;
+    char* otile = ring + DWF_RING * fbytes;  // [2][NTL x 16 positions][136]: output images of two consecutive frames
+    // tap offsets of this lane inside the staged region (pair j -> tap 2j + (q >> 1); the absent 10th tap reads the 9th's cell: its
+    // weights are zero)
+    int tapoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int tap9 = min(2 * j + (q >> 1), 8);
+        tapoff[j] = ((tap9 / 3) * RW + (tap9 % 3)) * (DWF_SLOTS * 16);
+    }
+    const int regions = g.RTH * g.RTW;
+    const int units = g.nT * regions;
+    const int u_end = min(units, (chunk + 1) * g.upb);
+
+#pragma unroll 1
+    for (int u = chunk * g.upb; u < u_end; ++u) {
+        const int tch = u / regions, reg = u - tch * regions;
+        const int rth = reg / g.RTW, rtw = reg - rth * g.RTW;
+        const int t0 = tch * g.Tc, t1 = min(t0 + g.Tc, d.To);
+        const int h0 = rth * g.BH, w0 = rtw * g.BW;
+        // ---- DMA roles: instruction i = wave + 4e covers ring slots 64 i .. 64 i + 63; this lane's slot -> (region position, piece).
+        // Pieces outside the image are NOT fetched: their cells were zeroed below and stay zero for the whole unit (same lanes every frame).
+        // The source is a wave-uniform frame base + this 32-bit byte offset: no per-frame pointer arithmetic in the vector unit.
+        unsigned goff[DWF_NE];  // byte offset inside a frame (this quad), ~0 = not fetched
+        unsigned emask = 0;     // instructions with any fetching lane (wave-uniform): exactly those are issued and counted
+#pragma unroll
+        for (int e = 0; e < DWF_NE; ++e) {
+            const int slot = (wave + 4 * e) * 64 + lane;
+            const int rp = slot / DWF_SLOTS, c = slot - rp * DWF_SLOTS;
+            const int rr = rp / RW, cc = rp - rr * RW;
+            const int hi = h0 - 1 + rr, wi = w0 - 1 + cc;
+            const bool ok = !(g.abl & 16) && wave + 4 * e < NI && rp < g.RP && cc < g.BW + 2 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cp + c * 8) * 2) : ~0u;
+            if (__builtin_amdgcn_ballot_w64(ok) != 0) emask |= 1u << e;
+        }
+        const int kdma = __builtin_popcount(emask);  // DMA instructions of this wave per frame
+        auto staged = [&](int ti) -> bool { return ti >= 0 && ti < Ti && ti >= t0 - 1 && ti <= t1; };
+        auto issue = [&](int ti, int slot) {
+            if (!staged(ti) || (g.abl & 2)) return;
+            const char* xf = reinterpret_cast<const char*>(xclip + (long)ti * fstride);
+            char* dst = ring + slot * fbytes;
+#pragma unroll
+            for (int e = 0; e < DWF_NE; ++e) {
+                if ((emask >> e) & 1u) {    // wave-uniform
+                    // (the lane predicates of this kernel are recomputed where they are used -- one v_cmp -- behind an opaque copy: hoisted
+                    // out of the frame loop they are ~25 SGPR pairs, spilled and reloaded lane by lane at every frame)
+                    unsigned gv = goff[e];
+                    asm volatile("" : "+v"(gv));
+                    if (gv != ~0u)          // per lane: the others keep the cell's zero
+                        __builtin_amdgcn_global_load_lds((dwm_gbl_ptr_t)(xf + gv), (dwm_lds_ptr_t)(dst + (wave + 4 * e) * 1024), 16, 0, 0);
+                }
+            }
+        };
+        // ---- fragment roles: position tile l holds RPT whole output rows of the region (rows l RPT ..), lane m -> (row m / BW, column
+        // m % BW): every per-tile address is the tile-0 address plus a wave-uniform multiple of l
+        const int mrow = m / g.BW, mcol = m - mrow * g.BW;
+        const bool lane_ok = m < RPT * g.BW && w0 + mcol < d.Wo && cev;
+        const int mrow_lim = lane_ok ? mrow : (1 << 20);  // row of this lane inside its tile, or "never valid"
+        const int rows_valid = min(g.BH, d.Ho - h0);                                       // output rows of this region
+        const int ntl = (rows_valid + RPT - 1) / RPT;                                      // tiles that hold any of them (wave-uniform)
+        const int lbase0 = ((min(mrow, RPT - 1) * RW + min(mcol, g.BW - 1)) * DWF_SLOTS + 2 * wave + (q & 1)) * 16;
+        constexpr int lstep = RPT * RW * DWF_SLOTS * 16;                                   // bytes between tiles in the staged image: an immediate
+        const int ystep = RPT * d.Wo * Cp;
+        __bf16* yclip = y + (long)n * d.To * d.Ho * d.Wo * Cp;
+        const long ofs = (long)d.Ho * d.Wo * Cp;
+        const int fl_m = threadIdx.x >> 4, fl_row = fl_m / g.BW, fl_col = fl_m - fl_row * g.BW;
+        const bool fl_ok = fl_m < RPT * g.BW && w0 + fl_col < d.Wo && (int)(threadIdx.x & 15) < 2 * npieces;
+        const int fl_lim = fl_ok ? fl_row : (1 << 20);
+        // tiles of which this WAVE stores anything (wave-uniform): exactly those store instructions are issued, so that the wave can count
+        // them (vmcnt retires in issue order: the wait for a frame's DMA group must name every younger DMA AND store, or it waits for the
+        // stores of the previous frame to be acknowledged -- ~1.5 us per frame, the whole step serialised)
+        unsigned fmask = 0;
+#pragma unroll
+        for (int l = 0; l < DWF_NTL; ++l)
+            if (__builtin_amdgcn_ballot_w64(l * RPT + fl_lim < rows_valid) != 0) fmask |= 1u << l;
+        const int kst = __builtin_popcount(fmask);
+        const int fl_off = ((h0 + fl_row) * d.Wo + w0 + fl_col) * Cp + cq * 64 + (threadIdx.x & 15) * 4;
+
+        f32x4 S0[DWF_NTL], S1[DWF_NTL], S2[DWF_NTL];
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int l = 0; l < DWF_NTL; ++l) S0[l] = S1[l] = S2[l] = zero4;
+
+        // one input frame ti from ring slot `slot`: P = output ti-1 (kt = 2), C = output ti (kt = 1), N = output ti+1 (kt = 0)
+        auto frame = [&](int ti, int slot, f32x4 (&P)[DWF_NTL], f32x4 (&C)[DWF_NTL], f32x4 (&N)[DWF_NTL]) {
+            if (wave_live && ti >= 0 && ti < Ti && !(g.abl & 1)) {  // wave-uniform
+                // All three kt taps of every staged frame are applied: a set that belongs to an output frame outside this T chunk is
+                // simply never emitted and restarts from zero when it becomes N again (at most 2 of Tc + 2 frames carry such work).
+                // per-frame operand addresses (kept out of the loop-invariant hoisting: three slots x five taps of them otherwise stay live
+                // across the whole march)
+                int fbo = slot * fbytes + lbase0;
+                asm volatile("" : "+v"(fbo));
+                const char* ta[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) ta[j] = ring + fbo + tapoff[j];
+                // explicit two-deep operand pipeline: the 5 reads of tile l + 1 are issued before the 15 MFMAs of tile l (left to itself the
+                // scheduler serialises read -> lgkmcnt(0) -> 3 MFMAs, one LDS round trip per tap pair: ~2500 cycles per frame)
+                bf16x8 Bq[2][5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+                for (int l = 0; l < DWF_NTL; ++l) {
+                    if (l + 1 < DWF_NTL) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) Bq[(l + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ta[j] + (l + 1) * lstep);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const bf16x8 B = Bq[l & 1][j];
+                        // N was emitted (or never touched) one frame ago: its first MFMA starts from a constant zero
+                        N[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : N[l], 0, 0, 0);
+                        C[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, C[l], 0, 0, 0);
+                        P[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, P[l], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
+                }
+            }
+            const int to = ti - 1;  // has now seen frames ti-2, ti-1, ti
+            if (wave_live && to >= t0 && to < t1 && !(g.abl & 4)) {
+                // into the output image of frame `to` (LDS, position pitch 136 bytes: conflict-free 8-byte writes); the block stores it as
+                // whole channel rows after the next barrier (a wave owns 32 bytes of every position: 16 partial lines per wave-store before)
+                char* ob = otile + (to & 1) * DWF_OBYTES + m * DWF_OPITCH + wave * 32 + q * 8;
+                int mr = mrow_lim;
+                asm volatile("" : "+v"(mr));
+#pragma unroll
+                for (int l = 0; l < DWF_NTL; ++l)
+                    if (l < ntl) {  // wave-uniform
+                        float v[4];
+                        const bool ok = l * RPT + mr < rows_valid;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = P[l][i] * sc[i] + bs[i];
+                            psum[i] += ok ? v[i] : 0.0f;
+                        }
+                        act_vec(v, d.act);
+                        if (d.Cout - ce < 4) mask_tail(v, d.Cout - ce);
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+                        *reinterpret_cast<bf16x4*>(ob + l * 16 * DWF_OPITCH) = o;
+                    }
+            }
+        };
+        // store output frame `to` from its LDS image: thread -> (position lane tid >> 4, 8-byte piece tid & 15) of every tile
+        auto flush = [&](int to) {
+            if (to < t0 || to >= t1 || (g.abl & 4)) return;
+            __bf16* yf = yclip + (long)to * ofs;
+            const char* ob = otile + (to & 1) * DWF_OBYTES + (threadIdx.x >> 4) * DWF_OPITCH + (threadIdx.x & 15) * 8;
+            int fr = fl_lim;
+            asm volatile("" : "+v"(fr));
+            bf16x4 ov[DWF_NTL];
+#pragma unroll
+            for (int l = 0; l < DWF_NTL; ++l) ov[l] = *reinterpret_cast<const bf16x4*>(ob + l * 16 * DWF_OPITCH);  // all reads, then the stores
+#pragma unroll
+            for (int l = 0; l < DWF_NTL; ++l)
+                if ((fmask >> l) & 1u)  // wave-uniform
+                    if (l * RPT + fr < rows_valid) *reinterpret_cast<bf16x4*>(yf + fl_off + l * ystep) = ov[l];
+        };
+        // one pipeline step: this wave's pieces of frame ti have landed (everything it issued since is the group of frame ti+1), then
+        // everyone's have and nobody still reads the slot of frame ti-1, which takes frame ti+2
+        auto step = [&](int ti, int slot, f32x4 (&P)[DWF_NTL], f32x4 (&C)[DWF_NTL], f32x4 (&N)[DWF_NTL]) {
+            if (!(g.abl & 8)) {
+                // younger than the group of frame ti: the stores of output ti-3 and the group of frame ti+1 (both issued in step ti-1)
+                const bool st3 = ti - 3 >= t0 && ti - 3 < t1 && !(g.abl & 4);
+                dwf_wait_all_but((st3 ? kst : 0) + (staged(ti + 1) && !(g.abl & 2) ? kdma : 0));
+                dwf_barrier();
+            }
+            flush(ti - 2);  // written by frame ti-1 before this barrier; its image is rewritten by frame ti+1, after the next one
+            issue(ti + 2, slot == 0 ? 2 : slot - 1);
+            frame(ti, slot, P, C, N);
+        };
+
+        for (int o = threadIdx.x * 16; o < ((g.abl & 32) ? 0 : DWF_RING * fbytes); o += 256 * 16) *reinterpret_cast<dwm_u32x4*>(ring + o) = dwm_u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();  // zeros written (lgkmcnt drained) before any piece may land on them
+        issue(t0 - 1, 0);
+        issue(t0, 1);
+#pragma unroll 1
+        for (int ti = t0 - 1; ti <= ((g.abl & 64) ? t0 - 2 : t1); ti += 3) {
+            step(ti, 0, S0, S1, S2);
+            if (ti + 1 <= t1) step(ti + 1, 1, S1, S2, S0);
+            if (ti + 2 <= t1) step(ti + 2, 2, S2, S0, S1);
+        }
+        __syncthreads();  // the last output image is complete; nobody reads the ring any more
+        flush(t1 - 1);
+    }
+
+    if (pool && wave_live) {
+        // sum over the 16 positions of the tile (lanes sharing q): fixed butterfly order
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = psum[i];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8);
+            psum[i] = s;
+        }
+        if (m == 0 && cev) {
+            float* pr = pool + ((long)n * g.chunks + chunk) * Cp + ce;
+            *reinterpret_cast<f32x4*>(pr) = f32x4{psum[0], psum[1], psum[2], psum[3]};
+        }
+    }
+}
+
+// Geometry: ok = 0 means "not this kernel".
+DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
+    DwMfmaGeom g = {};
+    if (dtype != PASN_BF16) return g;
+    // OPT-IN (PASN_DWMFMA=1): parity-green but 15-30 % slower than the VALU stencil on the benchmark layers (profiles/README entry 45)
+    const char* on = getenv("PASN_DWMFMA");
+    if (!on || on[0] != '1') return g;
+    const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
+                       d.pw == 1 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0;
+    if (!shape) return g;
+    if ((long)d.Hi * d.Wi * d.Cin_p >= (1L << 30)) return g;  // 32-bit element offsets inside a frame
+    g.CT = ceil_div(d.Cout_p, 16);
+    g.CQ = ceil_div(g.CT, 4);
+    // region = 4 rows x 14 columns of outputs (the X3D planes are 56 / 28 / 14 / 7 wide: no ragged strips); a 16-lane position tile
+    // is one output row (14 lanes used) or, on planes at most 8 wide, two (7 x 7: one region per frame)
+    g.BW = std::min(d.Wo, 14);
+    g.RPT = g.BW <= 8 ? 2 : 1;
+    g.BH = std::min(d.Ho, DWF_NTL * g.RPT);
+    g.RTH = ceil_div(d.Ho, g.BH);
+    g.RTW = ceil_div(d.Wo, g.BW);
+    g.RP = (g.BH + 2) * DWF_PITCH;
+    g.NI = ceil_div((DWF_NTL * g.RPT + 2) * DWF_PITCH * DWF_SLOTS, 64);  // the instance's constant (region height DWF_NTL * RPT)
+    // (Tc, upb): blocks run two per CU, a block costs a setup (weight operands, pipeline fill) plus upb units of Tc + 2 frames; at most
+    // 64 chunks per clip where it costs nothing (the chunk count is the number of SE partial rows the gate has to sum)
+    const int force_tc = getenv("PASN_DWMFMA_TC") ? atoi(getenv("PASN_DWMFMA_TC")) : 0;
+    const int force_upb = getenv("PASN_DWMFMA_UPB") ? atoi(getenv("PASN_DWMFMA_UPB")) : 0;
+    const int regions = g.RTH * g.RTW;
+    double best = 1e30;
+    for (int tc = d.To;; tc = (tc + 1) / 2) {
+        const int tcu = force_tc ? std::min(force_tc, d.To) : tc;
+        const int nT = ceil_div(d.To, tcu), units = nT * regions;
+        for (int upb = 1; upb <= units; ++upb) {
+            if (force_upb && upb != std::min(force_upb, units)) continue;
+            const int chunks = ceil_div(units, upb);
+            if (chunks > 64 && upb < units && !force_upb) continue;
+            const long blocks = (long)d.N * g.CQ * chunks;
+            const double t = (double)ceil_div(blocks, 512L) * (4.0 + upb * (tcu + 2.0));
+            if (t < best) {
+                best = t;
+                g.Tc = tcu;
+                g.nT = nT;
+                g.upb = upb;
+                g.chunks = chunks;
+            }
+        }
+        if (force_tc || tc <= 4) break;
+    }
+    g.bpc = g.CQ * g.chunks;
+    g.abl = getenv("PASN_DWMFMA_ABL") ? atoi(getenv("PASN_DWMFMA_ABL")) : 0;  // timing ablations (wrong results)
+    g.ok = 1;
+    return g;
+}
+
+int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
+                   const DwMfmaGeom& g, hipStream_t s) {
+    const dim3 grid(g.bpc * d.N), block(256);
+    const size_t lds = (size_t)DWF_RING * g.NI * 1024 + 2 * DWF_OBYTES;
+    if (g.RPT == 2) hipLaunchKernelGGL(dwconv3d_mfma_kernel<2>, grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+    else hipLaunchKernelGGL(dwconv3d_mfma_kernel<1>, grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+    return check_launch("dwconv3d_mfma_kernel");
+}
+
+}  // namespace pasn

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
                 // the DMAs of steps < s have landed (in-order completion), i.e. the weight tile of step s + 1 and, after the last tap (which
                 // issues no halo group), the whole halo tile of slice cs + 1
                 wait_all_but(issued);
-                if (!(ABL & 4)) __syncthreads();  // everyone's have; nobody still reads this step's weight stage
+                // barrier WITHOUT the fence of __syncthreads(): that fence is `s_waitcnt vmcnt(0)` and drained the DMAs just issued for step
+                // s + 2 / slice cs + 1 at every step (pipeline depth 1 instead of 2); only LDS traffic is drained here
+                if (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone's have; nobody still reads this step's weight stage
                 stage = stage == 2 ? 0 : stage + 1;
             }
     }

@@ -384,7 +384,9 @@ class PlanBuilder:
         self._use(xb, yb, pb)
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
-        if dv >= 40000:
+        if dv >= 50000:
+            kname = "dwconv3d_mfma_kernel"
+        elif dv >= 40000:
             kname = f"dwconv3d_march2_kernel<{dv % 10},{dv // 10 % 100},{dv // 1000 % 10}>"
         elif dv >= 3000:
             kname = f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>"

@@ -475,9 +475,11 @@ DW_CASES = [
 ]
 
 
-def _march_case(stride, c, dtype=torch.bfloat16):
+def _march_case(stride, c, dtype=torch.bfloat16, thw=None):
     torch.manual_seed(11)
-    n, thw = 2, (9, 11, 13) if stride == 1 else (9, 14, 22)
+    n = 2
+    if thw is None:
+        thw = (9, 11, 13) if stride == 1 else (9, 14, 22)
     x = torch.randn(n, c, *thw)
     conv = nn.Conv3d(c, c, 3, (1, stride, stride), 1, groups=c, bias=False)
     bn = nn.BatchNorm3d(c)
@@ -532,13 +534,45 @@ def test_dwconv3d_march2_instances(inst, tc, c, monkeypatch):
     assert torch.equal(out, out1), "march2 must reproduce round 1's stencil bit for bit"
 
 
+@pytest.mark.parametrize("c", [24, 56, 108, 432])
+@pytest.mark.parametrize("geom", ["0,0", "4,1", "4,3", "16,2", "2,1000"])
+@pytest.mark.parametrize("thw", [(9, 11, 13), (9, 14, 22), (5, 7, 7), (4, 30, 8)])
+def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
+    """Matrix-core stencil (block-diagonal bf16 weight operands, LDS-DMA frame ring, T-marching accumulators): the cost model's own
+    split and forced (T chunk, units per block) splits on ragged shapes -- T = 9 (chunk halos, partial last chunk), planes that are not
+    multiples of the 4 x 14 region (ragged rows and strips), planes at most 8 wide (two output rows per position tile), channel counts
+    with a partial 16-channel tile (24, 56, 108) and a short last channel quad (108, 432) -- with the Swish epilogue and SE partial
+    sums, against torch; and against round 1's VALU stencil within the bf16 rounding of the weights (the only arithmetic difference:
+    fp32 accumulation in both)."""
+    tc, upb = geom.split(",")
+    monkeypatch.delenv("PASN_DWM2", raising=False)
+    monkeypatch.setenv("PASN_DWMFMA", "1")  # opt-in kernel
+    if tc != "0":
+        monkeypatch.setenv("PASN_DWMFMA_TC", tc)
+        monkeypatch.setenv("PASN_DWMFMA_UPB", upb)
+    x, conv, bn, pre = _march_case(1, c, thw=thw)
+    ref = pre * torch.sigmoid(pre)
+    out, part, kernel = _run_march(x, conv, bn, "swish")
+    assert kernel == "dwconv3d_mfma_kernel", kernel
+    atol, rtol = _tols(torch.bfloat16)
+    assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"mfma stencil {thw} {geom} c{c}")
+    want = pre.sum(dim=(2, 3, 4))
+    assert_close(part.sum(dim=1)[:, :c].cpu(), want, 2e-2 * float(want.abs().max()), 0, "SE partial sums")
+    assert float(out[..., c:].abs().max() if out.shape[-1] > c else 0.0) == 0.0, "padded channels must stay zero"
+    monkeypatch.delenv("PASN_DWMFMA")
+    out1, part1, kernel1 = _run_march(x, conv, bn, "swish")
+    assert kernel1.startswith("dwconv3d_march_kernel<"), kernel1
+    d = (out.float() - out1.float()).abs()
+    assert float(d.max()) <= 2.0 ** -6 * max(1.0, float(out1.float().abs().max())), float(d.max())
+
+
 @pytest.mark.parametrize("wt", [2, 3])
 @pytest.mark.parametrize("tc", [4, 8, 16])
 @pytest.mark.parametrize("stride", [1, 2])
 def test_dwconv3d_march_variants(stride, tc, wt, monkeypatch):
     """T-marching stencil: every (outputs per strip, T chunk) instance on a shape with T = 9 (chunk halos, a partial last
     chunk), ragged W for both strip widths and SE partial sums; the cost model's own choice is covered by DW_CASES."""
-    monkeypatch.delenv("PASN_DWM2", raising=False)  # the default kernel (the second-generation one is opt-in)
+    monkeypatch.delenv("PASN_DWM2", raising=False)  # round 1's kernel (the second-generation and the matrix-core one are opt-in)
     monkeypatch.setenv("PASN_DWM_WT", str(wt))
     monkeypatch.setenv("PASN_DWM_TC", str(tc))
     dtype = torch.bfloat16
