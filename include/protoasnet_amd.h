@@ -315,6 +315,16 @@ int pasn_train_chunks(int N, int S, int Cp);
 int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, float* stat, float* pool_u, int N, int S, int C, int Cp, int dtype, void* stream);
 
+/* Depthwise conv (raw output, as pasn_dwconv3d_fwd with pool_partial = NULL) AND the batch statistics of its output in one pass over
+ * y: replaces pasn_dwconv3d_fwd + pasn_bn_stats_fwd for the X3D conv_b units (Video_XProtoNet trunks: every block's 3x3x3 depthwise conv
+ * is followed by a BatchNorm3d).  `ws` is fp32 [N][rows][2][Cp] with rows = pasn_dwconv3d_stats_rows(d, dtype); rows = 0: the layer is
+ * not covered (caller issues the two separate calls).  Statistics are taken from the fp32 outputs before they are rounded to `dtype`;
+ * fixed summation order.  scale / bias: per-channel epilogue constants of the stencil (1 and 0 for a BatchNorm'd unit). */
+int pasn_dwconv3d_stats_rows(const pasn_conv_desc* d, int dtype);
+int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y, float* ws, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* stat, float* pool_u,
+                            const pasn_conv_desc* d, int dtype, void* stream);
+
 /* a = act((y*sc + sh + residual) * gate[n][c]);  residual (dtype [N][S][Cp]) and gate (fp32 [N][Cp]) may be NULL.
  * A unit without a norm layer passes stat = (0, 1, 1, bias). */
 int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S, int C, int Cp,

@@ -88,7 +88,8 @@ struct DwSeArgs {
     int cse;
 };
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
-                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
+                    int stats = 0);  // stats: `pool` is the batch-statistics partial buffer [N][bpc][2][Cp] (sum, sum of squares)
 // dwmfma.hip: the stride-1 depthwise 3x3x3 stencil on the matrix cores (block-diagonal bf16 weight operands, LDS-DMA frame ring, T-marching); ok = 0: not covered
 struct DwMfmaGeom {
     int ok, CT, CQ;            // channel tiles of 16, quads of 4 tiles (one block owns a quad)

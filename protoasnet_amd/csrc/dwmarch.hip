@@ -26,7 +26,7 @@ template <int SW, int WT>
 __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
-                                                             int CG, int R, int strips, int Tc, int bpc, DwSeArgs se) {
+                                                             int CG, int R, int strips, int Tc, int bpc, DwSeArgs se, int stats) {
     // [27 taps + scale + bias][2 halves][DWM_CGS slots][4] fp32 (fixed slot stride: every tap is an immediate ds_read
     // offset), then [R][Cp] pool scratch
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
     const int nT = (d.To + Tc - 1) / Tc;
     const int items = nT * d.Ho * strips;
     const int item = bx * R + r;
-    float psum[8];
+    float psum[8], psq[8];  // psq: second moments for the training path's batch statistics (stats != 0)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) psum[j] = 0.0f;
+    for (int j = 0; j < 8; ++j) psum[j] = psq[j] = 0.0f;
 
     if (item < items) {
         const int strip = item % strips;
@@ -194,6 +194,10 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                         v[j] = P[o][j] * sc[j] + bs[j];
                         psum[j] += v[j];
                     }
+                    if (stats) {  // block-uniform
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) psq[j] = fmaf(v[j], v[j], psq[j]);
+                    }
                     act_vec(v, d.act);
                     if (d.Cout - cg * 8 < 8) mask_tail(v, d.Cout - cg * 8);  // only the last channel group has padding
                     store8(yrow + (long)wo * Cp, v);
@@ -213,7 +217,21 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
             if (ti + 2 <= t1) frame(ti + 2, A2, A0, A1);
         }
     }
-    if (pool) {  // block-uniform; squeeze-excite partial sums reduced over the R items in fixed order
+    if (pool && stats) {
+        // training path: this block's row of the batch-statistics partials, ws[n][bx][2][Cp] = (sum y, sum y^2) of the fp32 outputs (the
+        // layout bn_finalize_kernel reads, shift 0), reduced over the R items in fixed order
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[r * Cp + cg * 8 + j] = pass ? psq[j] : psum[j];
+            __syncthreads();
+            for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
+                float s = 0.0f;
+                for (int q = 0; q < R; ++q) s += red[q * Cp + ch];
+                pool[(((long)n * bpc + bx) * 2 + pass) * Cp + ch] = s;
+            }
+        }
+    } else if (pool) {  // block-uniform; squeeze-excite partial sums reduced over the R items in fixed order
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[r * Cp + cg * 8 + j] = psum[j];
         __syncthreads();
@@ -335,12 +353,12 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
 }
 
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
-                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se) {
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se, int stats) {
     const dim3 grid(g.bpc * d.N), block(g.CG * g.R);
     const size_t lds = dwm_lds_bytes(g.R, d.Cout_p);
 #define PASN_DWM(SW_, WT_)                                                                                           \
     hipLaunchKernelGGL((dwconv3d_march_kernel<SW_, WT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
-                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, se)
+                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, se, stats)
     if (d.sw == 1 && g.WT == 3) PASN_DWM(1, 3);
     else if (d.sw == 1) PASN_DWM(1, 2);
     else if (g.WT == 3) PASN_DWM(2, 3);

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool live = c < Cp;
-    const float k = live ? (float)y[c] : 0.0f;
+    const float k = live && y ? (float)y[c] : 0.0f;  // y == nullptr: unshifted partials (the stencil's fused statistics)
     float a1 = 0.0f, a2 = 0.0f;
     if (live) {
         const int total = N * chunks;
@@ -563,6 +563,37 @@ extern "C" int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, c
                            running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks);
     }
     return check_launch("bn_stats_fwd");
+}
+
+// Depthwise stencil + batch statistics in ONE pass over y (the X3D conv_b units): the T-marching stencil accumulates sum / sum of squares
+// of its fp32 outputs per block, bn_finalize_kernel turns the [N][rows][2][Cp] partials into the unit's statistics table.  Saves the
+// read of y by pasn_bn_stats_fwd (27 launches, ~1 ms of the X3D-S step).  Unshifted second moments: var = E[y^2] - mean^2 in fp32 over
+// per-block fp32 partials -- a conv output without bias has |mean| ~ std.
+extern "C" int pasn_dwconv3d_stats_rows(const pasn_conv_desc* d, int dtype) {
+    if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0 || d->Cout_p > 2048) return 0;
+    if (const char* e = getenv("PASN_NO_DW_STATS"))
+        if (e[0] == '1') return 0;
+    if (dw_march2_geom(*d, dtype).WT || dw_mfma_geom(*d, dtype).ok) return 0;  // opt-in stencils: no fused statistics
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    return m.WT ? m.bpc : 0;
+}
+
+extern "C" int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y, float* ws, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps, float* stat, float* pool_u,
+                                       const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && w && scale && bias && y && ws && stat && d, "null pointer");
+    PASN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean / running_var go together");
+    PASN_REQUIRE(d->act == PASN_ACT_NONE, "the training stencil writes the raw conv output");
+    const int rows = pasn_dwconv3d_stats_rows(d, dtype);
+    PASN_REQUIRE(rows > 0, "layer not covered (pasn_dwconv3d_stats_rows returns 0)");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cp = d->Cout_p, S = d->To * d->Ho * d->Wo;
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    const int rc = launch_dw_march(x, w, scale, bias, y, ws, *d, m, s, DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)nullptr, gamma, beta, running_mean,
+                       running_var, momentum, eps, stat, pool_u, d->N, S, d->Cout, Cp, rows);
+    return check_launch("dwconv3d_stats_fwd");
 }
 
 extern "C" int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S,

@@ -200,8 +200,11 @@ class TrainBuilder(PlanBuilder):
             self.refresh.append(lambda: dw_w[:, :C].copy_(conv.weight.detach().reshape(C, taps).t()))
             one, zero = self.const(Cp, 1.0), self.const(Cp, 0.0)
             self.keep += [dw_w, one, zero]
-            self._use(x.buf, y.buf)
-            self._op(lib.pasn_dwconv3d_fwd, B(x.buf), dw_w.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), 0, ctypes.byref(d), code)
+            # the stencil can take the unit's batch statistics in the same pass over y (saves the read of y by pasn_bn_stats_fwd)
+            dw_rows = int(lib.pasn_dwconv3d_stats_rows(ctypes.byref(d), code)) if norm is not None and norm.momentum is not None else 0
+            if dw_rows == 0:
+                self._use(x.buf, y.buf)
+                self._op(lib.pasn_dwconv3d_fwd, B(x.buf), dw_w.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), 0, ctypes.byref(d), code)
         else:
             assert conv.groups == 1 and not x.planar
             d = self._dense(x, y, k, s, p, cout, cin, lambda: conv.weight.detach())
@@ -216,16 +219,23 @@ class TrainBuilder(PlanBuilder):
                 _need_fp32_param(t, "a norm parameter")
             if norm.momentum is None:
                 raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not built")
-            chunks = int(lib.pasn_train_chunks(N, S, Cp))
+            fused_dw = kind == "dw" and dw_rows > 0
+            chunks = dw_rows if fused_dw else int(lib.pasn_train_chunks(N, S, Cp))
             ws = self._new_buf(N * chunks * 2 * Cp * 4)
             stat_buf = self._new_buf(4 * Cp * 4)
             pool_buf = self._new_buf(N * Cp * 4) if se is not None else None
             track = bool(norm.track_running_stats and norm.running_mean is not None)
             if track:
                 self.nbt.append(norm.num_batches_tracked)
-            self._use(y.buf, ws, stat_buf, pool_buf)
-            self._op(lib.pasn_bn_stats_fwd, B(y.buf), B(ws), Pm(norm.weight), Pm(norm.bias), Pm(norm.running_mean if track else None),
-                     Pm(norm.running_var if track else None), float(norm.momentum), float(norm.eps), B(stat_buf), B(pool_buf), N, S, C, Cp, code)
+            if fused_dw:
+                self._use(x.buf, y.buf, ws, stat_buf, pool_buf)
+                self._op(lib.pasn_dwconv3d_stats_fwd, B(x.buf), dw_w.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), B(ws), Pm(norm.weight),
+                         Pm(norm.bias), Pm(norm.running_mean if track else None), Pm(norm.running_var if track else None), float(norm.momentum),
+                         float(norm.eps), B(stat_buf), B(pool_buf), dref, code)
+            else:
+                self._use(y.buf, ws, stat_buf, pool_buf)
+                self._op(lib.pasn_bn_stats_fwd, B(y.buf), B(ws), Pm(norm.weight), Pm(norm.bias), Pm(norm.running_mean if track else None),
+                         Pm(norm.running_var if track else None), float(norm.momentum), float(norm.eps), B(stat_buf), B(pool_buf), N, S, C, Cp, code)
             stat = B(stat_buf)
         elif not plain:
             stat_t = torch.zeros(4, Cp, dtype=torch.float32, device=self.device)  # (mean 0, invstd 1, sc 1, sh = bias)

@@ -280,6 +280,63 @@ def test_depthwise_dgrad_wgrad(c, k, s, p, shape):
     _rel(dw.view_as(wt), wt.grad, 1e-4, "dW")
 
 
+@pytest.mark.parametrize("c,s,shape,se", [(54, 1, (2, 5, 11, 13), True), (54, 2, (2, 4, 14, 18), False), (432, 1, (3, 9, 7, 7), True),
+                                          (216, 2, (2, 3, 14, 14), False)])
+def test_depthwise_stencil_with_fused_batch_statistics(c, s, shape, se):
+    """pasn_dwconv3d_stats_fwd (the stencil takes sum / sum of squares of its fp32 outputs per block; the finalize pass reads those
+    partials): y identical to pasn_dwconv3d_fwd, the statistics table, the running estimates and the per-clip SE pool equal to
+    pasn_bn_stats_fwd's on that y within fp32 / bf16-rounding noise, and to torch's batch_norm statistics of the fp32 conv output."""
+    lib = _lib.lib()
+    n, t, h, w = shape
+    g = torch.Generator().manual_seed(c + s)
+    x = torch.randn(n, c, t, h, w, generator=g).bfloat16().float()
+    wt = torch.randn(c, 1, 3, 3, 3, generator=g) * 0.3
+    yref = F.conv3d(x, wt, stride=(1, s, s), padding=1, groups=c)
+    d = _desc(x, yref, (3, 3, 3), (1, s, s), (1, 1, 1))
+    cp, S = d.Cout_p, yref.shape[2] * yref.shape[3] * yref.shape[4]
+    rows = lib.pasn_dwconv3d_stats_rows(ctypes.byref(d), BF16)
+    assert rows > 0, "the T-marching stencil covers every X3D conv_b"
+    wp = torch.zeros(27, cp, device=DEV)
+    wp[:, :c] = wt.reshape(c, 27).t().to(DEV)
+    one, zero = torch.ones(cp, device=DEV), torch.zeros(cp, device=DEV)
+    gm, bt = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+    xd = _cl(x, dtype=torch.bfloat16)
+
+    def run(fused):
+        y = torch.empty(n, yref.shape[2], yref.shape[3], yref.shape[4], cp, dtype=torch.bfloat16, device=DEV)
+        stat, pool = torch.zeros(4 * cp, device=DEV), torch.zeros(n * cp, device=DEV)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        pu = pool.data_ptr() if se else 0
+        if fused:
+            ws = torch.zeros(n * rows * 2 * cp, device=DEV)
+            _lib.check(lib.pasn_dwconv3d_stats_fwd(xd.data_ptr(), wp.data_ptr(), one.data_ptr(), zero.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                                   gm.data_ptr(), bt.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, stat.data_ptr(), pu,
+                                                   ctypes.byref(d), BF16, _st()))
+        else:
+            ws = torch.zeros(n * lib.pasn_train_chunks(n, S, cp) * 2 * cp, device=DEV)
+            _lib.check(lib.pasn_dwconv3d_fwd(xd.data_ptr(), wp.data_ptr(), one.data_ptr(), zero.data_ptr(), y.data_ptr(), 0, ctypes.byref(d), BF16, _st()))
+            _lib.check(lib.pasn_bn_stats_fwd(y.data_ptr(), ws.data_ptr(), gm.data_ptr(), bt.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5,
+                                             stat.data_ptr(), pu, n, S, c, cp, BF16, _st()))
+        torch.cuda.synchronize()
+        return y, stat.view(4, cp), pool.view(n, cp), rm, rv
+
+    y1, st1, pl1, rm1, rv1 = run(True)
+    y0, st0, pl0, rm0, rv0 = run(False)
+    assert torch.equal(y1, y0), "the fused pass must write the same y"
+    for i, name in enumerate(("mean", "invstd", "scale", "shift")):
+        _rel(st1[i, :c], st0[i, :c], 2e-3, f"statistics table: {name} (fused vs separate)")
+    _rel(rm1, rm0, 2e-3, "running_mean")
+    _rel(rv1, rv0, 2e-3, "running_var")
+    if se:
+        _rel(pl1[:, :c], pl0[:, :c], 2e-3, "per-clip SE pool")
+    # against torch on the fp32 conv output (the fused statistics never see the bf16 rounding of y)
+    mean, var = yref.mean(dim=(0, 2, 3, 4)), yref.var(dim=(0, 2, 3, 4), unbiased=False)
+    _rel(st1[0, :c], mean, 1e-4, "batch mean vs torch")
+    _rel(st1[1, :c], 1.0 / torch.sqrt(var + 1e-5), 1e-4, "batch invstd vs torch")
+    y2, st2, _, _, _ = run(True)
+    assert torch.equal(st1, st2), "fixed summation order: bitwise reproducible statistics"
+
+
 WGRAD_GATHER_CASES = [
     # cin, cout, k, s, p, (N,T,H,W) -- windowed / strided convs outside the halo kernel (conv_wgrad_gather_kernel, bf16)
     (64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 3, 12, 14)),   # R(2+1)D stage transition, spatial
