@@ -325,6 +325,16 @@ int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const float* scale, c
                             const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* stat, float* pool_u,
                             const pasn_conv_desc* d, int dtype, void* stream);
 
+/* dx of a stride-1 "same" depthwise conv (dy correlated with the reversed taps `w_flipped`, the forward stencil) AND, from the same fp32
+ * outputs, the backward sums of the unit that produced the conv's input x = act_prev(y_prev * sc + sh): coef = (sum d' / R, sum d' yhat / R),
+ * dgamma, dbeta with d' = dx * act_prev'(.) -- what pasn_unit_bwd_reduce(mode 3) would compute from (dx, y_prev) in a second pass.  The
+ * caller then runs pasn_bn_bwd_apply(dx, y_prev, stat_prev, coef, ..., act_prev) as after mode 3.  Only when dx is that unit's WHOLE output
+ * gradient (one consumer).  `ws`: fp32 [N][rows][2][Cp], rows = pasn_dwconv3d_dgrad_reduce_rows(d, dtype) (0: not covered). */
+int pasn_dwconv3d_dgrad_reduce_rows(const pasn_conv_desc* d, int dtype);
+int pasn_dwconv3d_dgrad_reduce(const void* dy, const float* w_flipped, const float* scale, const float* bias, void* dx, const void* y_prev,
+                               const float* stat_prev, int act_prev, float* ws, float* coef, float* dgamma, float* dbeta,
+                               const pasn_conv_desc* d, int dtype, void* stream);
+
 /* a = act((y*sc + sh + residual) * gate[n][c]);  residual (dtype [N][S][Cp]) and gate (fp32 [N][Cp]) may be NULL.
  * A unit without a norm layer passes stat = (0, 1, 1, bias). */
 int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S, int C, int Cp,

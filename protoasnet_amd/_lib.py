@@ -67,6 +67,8 @@ SIGNATURES = {
     # ---- training path
     "pasn_train_chunks": (c_int, [c_int, c_int, c_int]),
     "pasn_dwconv3d_stats_rows": (c_int, [POINTER(ConvDesc), c_int]),
+    "pasn_dwconv3d_dgrad_reduce_rows": (c_int, [POINTER(ConvDesc), c_int]),
+    "pasn_dwconv3d_dgrad_reduce": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 4 + [POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_dwconv3d_stats_fwd": (c_int, [c_void_p] * 10 + [c_float, c_float, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_bn_stats_fwd": (c_int, [c_void_p] * 6 + [c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pasn_affine_act_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),

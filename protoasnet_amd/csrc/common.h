@@ -80,7 +80,9 @@ struct DwMarchGeom {
     int WT, CG, R, strips, Tc, bpc;  // outputs per strip, channel groups, items per block, strips per row, T chunk, blocks per clip
 };
 DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype);
+bool dw_march_red_ok(const pasn_conv_desc& d, const DwMarchGeom& g);  // the dgrad + backward-sums instances cover this geometry
 // fused squeeze-excite gate (gate == nullptr: off): fc1 [cse][C] + bias, fc2 [C][cse] + bias, gate out [N][Cp], counter [N] ints (zero)
+struct DwRedArgs;
 struct DwSeArgs {
     const float *w1, *b1, *w2, *b2;
     float* gate;
@@ -89,7 +91,15 @@ struct DwSeArgs {
 };
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
                     const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-                    int stats = 0);  // stats: `pool` is the batch-statistics partial buffer [N][bpc][2][Cp] (sum, sum of squares)
+                    int stats = 0,  // stats: `pool` is the batch-statistics partial buffer [N][bpc][2][Cp] (sum, sum of squares)
+                    const struct DwRedArgs* red = nullptr);  // red: the launch is a dgrad whose outputs also feed the producer unit's backward sums
+// backward sums of the unit that PRODUCED the stencil's input (training): y = that unit's raw conv output (same geometry as the stencil's
+// output), stat = its (mean, invstd, sc, sh) table, act = its activation; `pool` then receives [N][bpc][2][Cp] = (sum d', sum d' yhat)
+struct DwRedArgs {
+    const void* y;
+    const float* stat;
+    int act;
+};
 // dwmfma.hip: the stride-1 depthwise 3x3x3 stencil on the matrix cores (block-diagonal bf16 weight operands, LDS-DMA frame ring, T-marching); ok = 0: not covered
 struct DwMfmaGeom {
     int ok, CT, CQ;            // channel tiles of 16, quads of 4 tiles (one block owns a quad)
@@ -263,6 +273,23 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case PASN_ACT_SWISH: return v * sigmoidf_(v);
         case PASN_ACT_ABS: return fabsf(v);
         default: return v;
+    }
+}
+
+// derivative of the activation at pre-activation u (training backward passes)
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case PASN_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+        case PASN_ACT_SIGMOID: {
+            const float s = sigmoidf_(u);
+            return s * (1.0f - s);
+        }
+        case PASN_ACT_SWISH: {
+            const float s = sigmoidf_(u);
+            return s * (1.0f + u * (1.0f - s));
+        }
+        case PASN_ACT_ABS: return u > 0.0f ? 1.0f : (u < 0.0f ? -1.0f : 0.0f);
+        default: return 1.0f;
     }
 }
 

@@ -20,30 +20,35 @@ namespace pasn {
 
 constexpr int DWM_CGS = 64;   // LDS slot stride of the weight planes = max channel groups (512 channels)
 constexpr int DWM_ROWS = 29;  // 27 taps + scale + bias
-static size_t dwm_lds_bytes(int R, int Cp) { return (size_t)(DWM_ROWS * 2 * DWM_CGS * 4 + R * Cp) * sizeof(float); }
+constexpr int DWM_RED_ROWS = 4;  // RED instances: + the producer unit's (mean, invstd, sc, sh)
+static size_t dwm_lds_bytes(int R, int Cp, bool red = false) {
+    return (size_t)((DWM_ROWS + (red ? DWM_RED_ROWS : 0)) * 2 * DWM_CGS * 4 + R * Cp) * sizeof(float);
+}
 
-template <int SW, int WT>
+template <int SW, int WT, bool RED = false>
 __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
-                                                             int CG, int R, int strips, int Tc, int bpc, DwSeArgs se, int stats) {
+                                                             int CG, int R, int strips, int Tc, int bpc, DwSeArgs se, int stats,
+                                                             DwRedArgs rd) {
     // [27 taps + scale + bias][2 halves][DWM_CGS slots][4] fp32 (fixed slot stride: every tap is an immediate ds_read
     // offset), then [R][Cp] pool scratch
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NC = (WT - 1) * SW + 3;  // input columns a strip touches
     const int Cp = d.Cout_p;
-    float* red = lds + DWM_ROWS * 2 * DWM_CGS * 4;
+    constexpr int ROWS = DWM_ROWS + (RED ? DWM_RED_ROWS : 0);
+    float* red = lds + ROWS * 2 * DWM_CGS * 4;
     // stage weights | scale | bias: batches of 8 independent 16-byte loads, THEN the LDS writes (a rolled load -> ds_write loop
     // is one L2 round trip per iteration: 14 of them per block on the 432-channel layers, ~10 us of a 35 us launch)
     {
-        const int total = DWM_ROWS * 2 * CG;
+        const int total = ROWS * 2 * CG;
         for (int i0 = threadIdx.x; i0 < total; i0 += 8 * blockDim.x) {
             f32x4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = min(i0 + u * (int)blockDim.x, total - 1);
                 const int row = i / (2 * CG), rem = i - row * 2 * CG, half = rem / CG, g = rem - half * CG;
-                const float* src = row < 27 ? w + (long)row * Cp : (row == 27 ? scale : bias);
+                const float* src = row < 27 ? w + (long)row * Cp : (row == 27 ? scale : row == 28 ? bias : rd.stat + (long)(row - 29) * Cp);
                 v[u] = *reinterpret_cast<const f32x4*>(src + g * 8 + half * 4);
             }
 #pragma unroll
@@ -194,7 +199,27 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                         v[j] = P[o][j] * sc[j] + bs[j];
                         psum[j] += v[j];
                     }
-                    if (stats) {  // block-uniform
+                    if (RED) {
+                        // this launch is a dgrad: v is the gradient w.r.t. the producer unit's activation output at this position.  Its
+                        // backward sums (sum d', sum d' yhat with d' = v act'(y sc + sh), yhat = (y - mean) invstd) are taken here, from
+                        // the fp32 v, instead of by a separate pass over (d, y)
+                        float yv[8];
+                        load8(reinterpret_cast<const __bf16*>(rd.y) + (yrow - y) + (long)wo * Cp, yv);
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {  // 4 channels at a time: 16 table registers live instead of 32
+                            const f32x4 mean = *reinterpret_cast<const f32x4*>(wl + ((29 + 0) * 2 + hf) * DWM_CGS * 4);
+                            const f32x4 istd = *reinterpret_cast<const f32x4*>(wl + ((29 + 1) * 2 + hf) * DWM_CGS * 4);
+                            const f32x4 rsc = *reinterpret_cast<const f32x4*>(wl + ((29 + 2) * 2 + hf) * DWM_CGS * 4);
+                            const f32x4 rsh = *reinterpret_cast<const f32x4*>(wl + ((29 + 3) * 2 + hf) * DWM_CGS * 4);
+#pragma unroll
+                            for (int j4 = 0; j4 < 4; ++j4) {
+                                const int j = hf * 4 + j4;
+                                const float dp = v[j] * act_grad(fmaf(yv[j], rsc[j4], rsh[j4]), rd.act);
+                                psum[j] += dp - v[j];  // psum already holds v (the SE-pool convention above); the sum wanted here is of d'
+                                psq[j] = fmaf(dp, (yv[j] - mean[j4]) * istd[j4], psq[j]);
+                            }
+                        }
+                    } else if (stats) {  // block-uniform
 #pragma unroll
                         for (int j = 0; j < 8; ++j) psq[j] = fmaf(v[j], v[j], psq[j]);
                     }
@@ -352,17 +377,30 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
     return g;
 }
 
+// the RED instances stage four more table rows: still two blocks per CU?
+bool dw_march_red_ok(const pasn_conv_desc& d, const DwMarchGeom& g) {
+    return g.WT != 0 && d.sw == 1 && d.sh == 1 && dwm_lds_bytes(g.R, d.Cout_p, true) <= 80 * 1024;
+}
+
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
-                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se, int stats) {
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se, int stats, const DwRedArgs* red) {
     const dim3 grid(g.bpc * d.N), block(g.CG * g.R);
-    const size_t lds = dwm_lds_bytes(g.R, d.Cout_p);
-#define PASN_DWM(SW_, WT_)                                                                                           \
-    hipLaunchKernelGGL((dwconv3d_march_kernel<SW_, WT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
-                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, se, stats)
-    if (d.sw == 1 && g.WT == 3) PASN_DWM(1, 3);
-    else if (d.sw == 1) PASN_DWM(1, 2);
-    else if (g.WT == 3) PASN_DWM(2, 3);
-    else PASN_DWM(2, 2);
+    const size_t lds = dwm_lds_bytes(g.R, d.Cout_p, red != nullptr);
+    const DwRedArgs rd = red ? *red : DwRedArgs{nullptr, nullptr, 0};
+#define PASN_DWM(SW_, WT_, RED_)                                                                                             \
+    hipLaunchKernelGGL((dwconv3d_march_kernel<SW_, WT_, RED_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
+                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, se, stats, rd)
+    if (red) {  // dgrad of a stride-1 "same" conv + the producer unit's backward sums (stats layout of `pool`)
+        if (!dw_march_red_ok(d, g) || !pool || !stats) {
+            set_error("launch_dw_march: the fused backward sums need a stride-1 launch with a statistics buffer");
+            return PASN_ERR_ARG;
+        }
+        if (g.WT == 3) PASN_DWM(1, 3, true);
+        else PASN_DWM(1, 2, true);
+    } else if (d.sw == 1 && g.WT == 3) PASN_DWM(1, 3, false);
+    else if (d.sw == 1) PASN_DWM(1, 2, false);
+    else if (g.WT == 3) PASN_DWM(2, 3, false);
+    else PASN_DWM(2, 2, false);
 #undef PASN_DWM
     return check_launch("dwconv3d_march_kernel");
 }

@@ -29,22 +29,6 @@ static RowGeom row_geom(int N, int S, int Cp) {
     return g;
 }
 
-__device__ __forceinline__ float act_grad(float u, int act) {
-    switch (act) {
-        case PASN_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
-        case PASN_ACT_SIGMOID: {
-            const float s = sigmoidf_(u);
-            return s * (1.0f - s);
-        }
-        case PASN_ACT_SWISH: {
-            const float s = sigmoidf_(u);
-            return s * (1.0f + u * (1.0f - s));
-        }
-        case PASN_ACT_ABS: return u > 0.0f ? 1.0f : (u < 0.0f ? -1.0f : 0.0f);
-        default: return 1.0f;
-    }
-}
-
 // Sum the per-thread 8-channel accumulators `acc[W][8]` over the row lanes of the block (fixed order) and store them
 // at out[w * Cp + cg*8 + j].
 template <int W>
@@ -594,6 +578,36 @@ extern "C" int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const floa
     hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)nullptr, gamma, beta, running_mean,
                        running_var, momentum, eps, stat, pool_u, d->N, S, d->Cout, Cp, rows);
     return check_launch("dwconv3d_stats_fwd");
+}
+
+// Input gradient of a stride-1 "same" depthwise conv (the forward stencil with reversed taps) AND the backward sums of the unit that
+// produced the conv's input, in one pass: replaces pasn_dwconv3d_fwd (as dgrad) + pasn_unit_bwd_reduce(mode 3) of the X3D conv_a units.
+extern "C" int pasn_dwconv3d_dgrad_reduce_rows(const pasn_conv_desc* d, int dtype) {
+    if (!d || d->sw != 1 || d->sh != 1) return 0;
+    // OPT-IN (PASN_DW_DGRAD_REDUCE=1): measured, the fusion does not pay -- the stencil is bound by vector-instruction issue, and the ~25
+    // extra instructions per output vector cost what the separate pass did (X3D-S: 22 launches 2.31 ms fused vs 1.37 + 0.87 ms)
+    const char* on = getenv("PASN_DW_DGRAD_REDUCE");
+    if (!on || on[0] != '1') return 0;
+    if (pasn_dwconv3d_stats_rows(d, dtype) == 0) return 0;
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    return dw_march_red_ok(*d, m) ? m.bpc : 0;
+}
+
+extern "C" int pasn_dwconv3d_dgrad_reduce(const void* dy, const float* w_flipped, const float* scale, const float* bias, void* dx,
+                                          const void* y_prev, const float* stat_prev, int act_prev, float* ws, float* coef, float* dgamma,
+                                          float* dbeta, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(dy && w_flipped && scale && bias && dx && y_prev && stat_prev && ws && coef && d, "null pointer");
+    PASN_REQUIRE(d->act == PASN_ACT_NONE, "a gradient pass has no activation");
+    const int rows = pasn_dwconv3d_dgrad_reduce_rows(d, dtype);
+    PASN_REQUIRE(rows > 0, "layer not covered (pasn_dwconv3d_dgrad_reduce_rows returns 0)");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cp = d->Cout_p, S = d->To * d->Ho * d->Wo;
+    const DwMarchGeom m = dw_march_geom(*d, dtype);
+    const DwRedArgs rd = {y_prev, stat_prev, act_prev};
+    const int rc = launch_dw_march(dy, w_flipped, scale, bias, dx, ws, *d, m, s, DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, 1, &rd);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, coef, dgamma, dbeta, d->N, S, d->Cout, Cp, rows);
+    return check_launch("dwconv3d_dgrad_reduce");
 }
 
 extern "C" int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S,

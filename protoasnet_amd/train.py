@@ -39,6 +39,8 @@ class TrainBuilder(PlanBuilder):
         super().__init__(device, dtype, in_dtype)
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[int, Act] = {}        # activation buffer id -> Act holding its gradient
+        self.readers: Dict[int, int] = {}      # activation buffer id -> number of ops that consume it (conv input, residual, pool, head)
+        self.red_hook: Dict[int, dict] = {}    # activation buffer id -> how its producer unit's backward sums can be taken by a fused dgrad
         self.refresh: List[Callable[[], None]] = []
         self.pslots: List[Tuple[torch.Tensor, int, int]] = []
         self._slot_of: Dict[int, int] = {}
@@ -166,6 +168,9 @@ class TrainBuilder(PlanBuilder):
         code, lib, B, Pm = self.code, self.lib, self.B, self.Pm
         actc = _lib.ACT[act]
         dw_w = None
+        self.readers[x.buf] = self.readers.get(x.buf, 0) + 1
+        if residual is not None:
+            self.readers[residual.buf] = self.readers.get(residual.buf, 0) + 1
         # ---------------- forward conv (raw output) ----------------
         if kind == "first":
             assert x.planar and x.C == 3 and k[0] == 1 and s[0] == 1 and p[0] == 0
@@ -265,6 +270,11 @@ class TrainBuilder(PlanBuilder):
             self._use(y.buf, out.buf, rb, stat_buf, gate_buf)
             self._op(lib.pasn_affine_act_fwd, B(y.buf), stat, B(rb), B(gate_buf), B(out.buf), N, S, C, Cp, actc, code)
 
+        if norm is not None and se is None and residual is None and not plain:
+            # a consumer whose input gradient is a stencil launch (stride-1 depthwise dgrad) may take this unit's backward sums in that
+            # launch: it leaves the coefficient buffer in hook["coef"], and backward() below then skips its own reduce pass
+            self.red_hook[out.buf] = {"y_buf": y.buf, "stat": stat, "stat_buf": stat_buf, "actc": actc,
+                                      "dg": lambda: self.Gof(norm.weight), "db": lambda: self.Gof(norm.bias), "coef": None}
         own = [conv.weight, conv.bias] + ([norm.weight, norm.bias] if norm is not None else []) + \
               ([se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias] if se is not None else [])
         own_live = any(t is not None and t.requires_grad for t in own)
@@ -292,7 +302,10 @@ class TrainBuilder(PlanBuilder):
                 else:
                     dg = db = 0
                 lazy = se is None and norm is not None and residual is None  # nobody but the apply pass reads the differentiated d
-                if se is None:
+                hook = self.red_hook.get(out.buf)
+                if hook is not None and hook["coef"] is not None:
+                    coef = hook["coef"]  # the consumer's fused dgrad already took the sums (and dgamma / dbeta)
+                elif se is None:
                     self._use(g.buf, y.buf, rb, stat_buf, ws, coef)
                     self._op(red, 3 if lazy else 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
                 else:
@@ -343,9 +356,20 @@ class TrainBuilder(PlanBuilder):
                     one_, zero_ = self.const(Cp, 1.0), self.const(Cp, 0.0)
                     dflip = self._desc(dy, dx, k, s, p, "none")
                     self.keep += [wflip]
-                    self._use(dy.buf, dx.buf)
-                    self._op(lib.pasn_dwconv3d_fwd, B(dy.buf), wflip.data_ptr(), one_.data_ptr(), zero_.data_ptr(), B(dx.buf), 0,
-                             ctypes.byref(dflip), code)
+                    hook = self.red_hook.get(x.buf)
+                    rrows = int(lib.pasn_dwconv3d_dgrad_reduce_rows(ctypes.byref(dflip), code)) if hook is not None else 0
+                    if rrows > 0 and self.readers.get(x.buf, 0) == 1 and self.grads.get(x.buf) is None:
+                        # dx is the WHOLE gradient of the producer unit's output: its backward sums ride in this launch
+                        wsr, hcoef = self._new_buf(x.N * rrows * 2 * x.Cp * 4), self._new_buf(2 * x.Cp * 4)
+                        self._use(dy.buf, dx.buf, hook["y_buf"], hook["stat_buf"], wsr, hcoef)
+                        self._op(lib.pasn_dwconv3d_dgrad_reduce, B(dy.buf), wflip.data_ptr(), one_.data_ptr(), zero_.data_ptr(), B(dx.buf),
+                                 B(hook["y_buf"]), hook["stat"], hook["actc"], B(wsr), B(hcoef), hook["dg"](), hook["db"](),
+                                 ctypes.byref(dflip), code)
+                        hook["coef"] = hcoef
+                    else:
+                        self._use(dy.buf, dx.buf)
+                        self._op(lib.pasn_dwconv3d_fwd, B(dy.buf), wflip.data_ptr(), one_.data_ptr(), zero_.data_ptr(), B(dx.buf), 0,
+                                 ctypes.byref(dflip), code)
                 else:
                     self._use(dy.buf, dx.buf)
                     self._op(lib.pasn_dwconv3d_dgrad, B(dy.buf), dw_w.data_ptr(), B(dx.buf), dref, code)
@@ -404,6 +428,7 @@ class TrainBuilder(PlanBuilder):
         y = self._out_act(x, x.C, k, s, p)
         d = self._desc(x, y, k, s, p, "none")
         dref, code, lib, B = ctypes.byref(d), self.code, self.lib, self.B
+        self.readers[x.buf] = self.readers.get(x.buf, 0) + 1
         self._use(x.buf, y.buf)
         self._op(lib.pasn_maxpool3d_fwd, B(x.buf), B(y.buf), dref, code)
         self.live[y.buf] = self.live.get(x.buf, False)
@@ -434,6 +459,9 @@ class TrainBuilder(PlanBuilder):
         self.keep.append(d)
         dref, code, lib, B, Pm = ctypes.byref(d), self.code, self.lib, self.B, self.Pm
         zb = z.buf if z is not None else None
+        for rb_ in (zb, r.buf):
+            if rb_ is not None:
+                self.readers[rb_] = self.readers.get(rb_, 0) + 1
         e = ext
         wsz = int(lib.pasn_xproto_tail_workspace_bytes(dref))  # split-S pooling on the matrix cores (the inference head's kernels)
         wsb = self._new_buf(wsz) if wsz else None
@@ -471,6 +499,7 @@ class TrainBuilder(PlanBuilder):
         N, S = z.N, z.positions
         code, lib, B, Pm, e = self.code, self.lib, self.B, self.Pm, ext
         amin = self._new_buf(N * P * 4)
+        self.readers[z.buf] = self.readers.get(z.buf, 0) + 1
         self._use(z.buf, amin)
         self._op(lib.pasn_l2_head_fwd, B(z.buf), Pm(pv), Pm(fw), 0, B(e["min_d"]), B(amin), B(e["logits"]), N, S, D, z.Cp, P, K, code, actc, eps)
 

@@ -337,6 +337,63 @@ def test_depthwise_stencil_with_fused_batch_statistics(c, s, shape, se):
     assert torch.equal(st1, st2), "fixed summation order: bitwise reproducible statistics"
 
 
+@pytest.mark.parametrize("c,shape,act", [(54, (2, 5, 11, 13), "relu"), (432, (3, 9, 7, 7), "relu"), (108, (2, 4, 14, 28), "swish")])
+def test_depthwise_dgrad_with_fused_backward_sums(c, shape, act, monkeypatch):
+    """pasn_dwconv3d_dgrad_reduce (opt-in): dx identical to the stencil dgrad (pasn_dwconv3d_fwd with reversed taps), and coef / dgamma / dbeta
+    equal to pasn_unit_bwd_reduce(mode 3) on (dx, y_prev) within the bf16 rounding of dx (the fused sums see the fp32 dx); then checked
+    end to end against autograd of  conv_dw(act(batch_norm(y_prev)))."""
+    monkeypatch.setenv("PASN_DW_DGRAD_REDUCE", "1")
+    lib = _lib.lib()
+    n, t, h, w = shape
+    g = torch.Generator().manual_seed(c)
+    actc = _lib.ACT[act]
+    fn = {"relu": F.relu, "swish": lambda v: v * torch.sigmoid(v)}[act]
+    yp = (torch.randn(n, c, t, h, w, generator=g) * 1.5 + 0.3).bfloat16().float().requires_grad_()
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_()
+    beta = (torch.randn(c, generator=g) * 0.5).requires_grad_()
+    wt = torch.randn(c, 1, 3, 3, 3, generator=g) * 0.3
+    a = fn(F.batch_norm(yp, None, None, gamma, beta, True, 0.1, 1e-5))
+    out = F.conv3d(a, wt, padding=1, groups=c)
+    dy = torch.randn(out.shape, generator=g).bfloat16().float()
+    out.backward(dy)
+    d = _desc(a, out, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    cp, S = d.Cout_p, t * h * w
+    rows = lib.pasn_dwconv3d_dgrad_reduce_rows(ctypes.byref(d), BF16)
+    assert rows > 0
+    wflip = torch.zeros(27, cp, device=DEV)
+    wflip[:, :c] = wt.reshape(c, 27).flip(1).t().to(DEV)
+    one, zero = torch.ones(cp, device=DEV), torch.zeros(cp, device=DEV)
+    ypd, dyd = _cl(yp.detach(), dtype=torch.bfloat16), _cl(dy, dtype=torch.bfloat16)
+    gm, bt = gamma.detach().to(DEV), beta.detach().to(DEV)
+    stat = torch.zeros(4 * cp, device=DEV)
+    ws0 = torch.zeros(n * lib.pasn_train_chunks(n, S, cp) * 2 * cp, device=DEV)
+    _lib.check(lib.pasn_bn_stats_fwd(ypd.data_ptr(), ws0.data_ptr(), gm.data_ptr(), bt.data_ptr(), 0, 0, 0.1, 1e-5, stat.data_ptr(), 0, n, S, c, cp,
+                                     BF16, _st()))
+    # separate: stencil dgrad, then the reduce pass
+    dx0 = torch.empty_like(ypd)
+    _lib.check(lib.pasn_dwconv3d_fwd(dyd.data_ptr(), wflip.data_ptr(), one.data_ptr(), zero.data_ptr(), dx0.data_ptr(), 0, ctypes.byref(d), BF16, _st()))
+    coef0, dg0, db0 = torch.zeros(2 * cp, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    _lib.check(lib.pasn_unit_bwd_reduce(3, dx0.data_ptr(), ypd.data_ptr(), stat.data_ptr(), 0, 0, 0, ws0.data_ptr(), coef0.data_ptr(), dg0.data_ptr(),
+                                        db0.data_ptr(), n, S, c, cp, actc, BF16, _st()))
+    # fused
+    dx1 = torch.empty_like(ypd)
+    ws1 = torch.zeros(n * rows * 2 * cp, device=DEV)
+    coef1, dg1, db1 = torch.zeros(2 * cp, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    _lib.check(lib.pasn_dwconv3d_dgrad_reduce(dyd.data_ptr(), wflip.data_ptr(), one.data_ptr(), zero.data_ptr(), dx1.data_ptr(), ypd.data_ptr(),
+                                              stat.data_ptr(), actc, ws1.data_ptr(), coef1.data_ptr(), dg1.data_ptr(), db1.data_ptr(),
+                                              ctypes.byref(d), BF16, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx0), "the fused pass must write the same dx"
+    _rel(coef1.view(2, cp)[:, :c], coef0.view(2, cp)[:, :c], 4e-3, "coef (fused vs separate)")
+    _rel(dg1, dg0, 4e-3, "dgamma (fused vs separate)")
+    _rel(db1, db0, 4e-3, "dbeta (fused vs separate)")
+    _rel(dg1, gamma.grad, 1e-2, "dgamma vs autograd")
+    _rel(db1, beta.grad, 1e-2, "dbeta vs autograd")
+    dyp = torch.empty_like(ypd)
+    _lib.check(lib.pasn_bn_bwd_apply(dx1.data_ptr(), ypd.data_ptr(), stat.data_ptr(), coef1.data_ptr(), dyp.data_ptr(), n, S, c, cp, actc, BF16, _st()))
+    _rel(_ncl(dyp, c), yp.grad, 2e-2, "gradient of the producer's raw output vs autograd")
+
+
 WGRAD_GATHER_CASES = [
     # cin, cout, k, s, p, (N,T,H,W) -- windowed / strided convs outside the halo kernel (conv_wgrad_gather_kernel, bf16)
     (64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 3, 12, 14)),   # R(2+1)D stage transition, spatial
@@ -749,11 +806,16 @@ def test_video_x3d_train_unmodified_model_vs_oracle():
     assert cos > 0.98 and median < 5e-2, f"gradient direction cosine {cos:.4f}, median per-tensor error {median:.2e}; worst {rows[:3]}"
 
 
-@pytest.mark.parametrize("cfg,shape,spatial", [(CFG_VIDEO_X3D, SHAPE, SPATIAL), (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4)),
-                                               (CFG_XPROTO, (3, 3, 96, 96), (3, 3))], ids=["x3d_s", "r2plus1d", "resnet18"])
-def test_train_bf16_activations_track_fp32(cfg, shape, spatial):
+@pytest.mark.parametrize("cfg,shape,spatial,env", [(CFG_VIDEO_X3D, SHAPE, SPATIAL, ""), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_DW_DGRAD_REDUCE"),
+                                                   (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_DW_STATS"), (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4), ""),
+                                                   (CFG_XPROTO, (3, 3, 96, 96), (3, 3), "")],
+                         ids=["x3d_s", "x3d_s-dgrad+sums", "x3d_s-separate-stats", "r2plus1d", "resnet18"])
+def test_train_bf16_activations_track_fp32(cfg, shape, spatial, env, monkeypatch):
     """bf16 activations / activation gradients (fp32 statistics, reductions, parameter gradients) against the fp32 mode, every trunk
-    (bf16 takes other kernels: T-marching stencils, LDS-transposed MFMA weight gradients incl. the windowed ones)."""
+    (bf16 takes other kernels: T-marching stencils with the batch statistics fused in -- and, opt-in, the producer unit's backward sums
+    in the stencil dgrad --, LDS-transposed MFMA weight gradients incl. the windowed ones)."""
+    if env:
+        monkeypatch.setenv(env, "1")
     x = synth.echo_clips(shape).to(DEV)
     grads, outs = {}, {}
     for tag, dt in (("f32", None), ("bf16", torch.bfloat16)):
