@@ -315,6 +315,20 @@ int pasn_train_chunks(int N, int S, int Cp);
 int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, float* stat, float* pool_u, int N, int S, int C, int Cp, int dtype, void* stream);
 
+/* Squeeze-excite unit backward in ONE pass over (d, y) -- the analytic form of modes 1 + 2:
+ *   pasn_unit_bwd_reduce(mode 4, ...): d <- d' = d * act'((y*sc + sh) * gate); ws fp32 [N][chunks][3][Cp] = per-clip partials of
+ *       (sum d', sum d' yhat, sum yhat)            (gate required; coef / dgamma / dbeta unused)
+ *   pasn_se_gate_bwd_stat: the gate's gradient sum d' u = gamma sum d' yhat + beta sum d' per clip, the two FCs' backward (add[n][c],
+ *       parameter gradients, as pasn_se_gate_bwd) and, because d'' = d' gate + add is affine in d' per clip, the norm's
+ *       coef = (sum d'' / R, sum d'' yhat / R), dgamma, dbeta WITHOUT a second pass over the tensor (ws is updated in place)
+ *   pasn_bn_bwd_apply_se: dy = sc (d' gate + add - m1 - yhat m2), d'' formed on the fly (dy may alias d).
+ * Same arithmetic as modes 1 + 2 + pasn_bn_bwd_apply up to fp32 summation order; fixed order. */
+int pasn_se_gate_bwd_stat(float* ws3, const float* pool_u, const float* stat, const float* gate, const float* fc1_w, const float* fc1_b,
+                          const float* fc2_w, const float* fc2_b, float* add, float* pn, float* dfc1_w, float* dfc1_b, float* dfc2_w,
+                          float* dfc2_b, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int Cse, void* stream);
+int pasn_bn_bwd_apply_se(const void* d, const void* y, const float* stat, const float* coef, const float* gate, const float* add, void* dy,
+                         int N, int S, int C, int Cp, int dtype, void* stream);
+
 /* Depthwise conv (raw output, as pasn_dwconv3d_fwd with pool_partial = NULL) AND the batch statistics of its output in one pass over
  * y: replaces pasn_dwconv3d_fwd + pasn_bn_stats_fwd for the X3D conv_b units (Video_XProtoNet trunks: every block's 3x3x3 depthwise conv
  * is followed by a BatchNorm3d).  `ws` is fp32 [N][rows][2][Cp] with rows = pasn_dwconv3d_stats_rows(d, dtype); rows = 0: the layer is
@@ -346,6 +360,7 @@ int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, 
  *   mode 2:  d <- d * gate + add[n][c];             coef / dgamma / dbeta as mode 0
  *   mode 3:  the sums of mode 0 WITHOUT writing d back (no residual branch needs it): pasn_bn_bwd_apply is then called with
  *            the unit's `act` and differentiates on the fly -- one tensor write less per unit
+ *   mode 4:  mode 1 with the per-clip sums of the analytic squeeze-excite backward (pasn_se_gate_bwd_stat below); ws is [N][chunks][3][Cp]
  * (yhat = (y - mean) * invstd, R = N*S; after mode 0 the buffer d is also the gradient of `residual`.) */
 int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const float* stat, const void* residual, const float* gate, const float* add,
                          float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int act, int dtype, void* stream);

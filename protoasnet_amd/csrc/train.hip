@@ -200,9 +200,12 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
     __shared__ float red[256 * 8];
     const int n = blockIdx.y, ch = blockIdx.x;
     const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
-    float acc[2][8];
+    constexpr int W = MODE == 4 ? 3 : 2;
+    float acc[W][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.0f;
+    for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[w][j] = 0.0f;
     if (cg < CG) {
         float mean[8], invstd[8], sc[8], sh[8], g[8], ad[8];
         load8(stat + cg * 8, mean);
@@ -243,11 +246,24 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
                     dv[j] *= act_grad(u * g[j], act);
                     acc[0][j] = fmaf(dv[j], u, acc[0][j]);
                 }
+            } else if (MODE == 4) {
+                // as mode 1, but the sums the squeeze-excite unit's norm needs are taken here, per clip: (sum d', sum d' yhat, sum yhat).
+                // d'' = d' gate + add[n] is affine in d' per clip, so sum d'' and sum d'' yhat follow without a second pass over (d, y)
+                // (pasn_se_gate_bwd_stat), and sum d' u = gamma sum d' yhat + beta sum d' (the gate's gradient) as well
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float u = fmaf(v[j], sc[j], sh[j]);
+                    const float yh = (v[j] - mean[j]) * invstd[j];
+                    dv[j] *= act_grad(u * g[j], act);
+                    acc[0][j] += dv[j];
+                    acc[1][j] = fmaf(dv[j], yh, acc[1][j]);
+                    acc[W - 1][j] += yh;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dv[j] = fmaf(dv[j], g[j], ad[j]);
             }
-            if (MODE != 1) {
+            if (MODE != 1 && MODE != 4) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     acc[0][j] += dv[j];
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
             if (write_back) store8(d + o, dv);
         }
     }
-    block_reduce_rows<2>(acc, red, ws + ((size_t)n * chunks + ch) * 2 * Cp, Cp, CG, CGb);
+    block_reduce_rows<W>(acc, red, ws + ((size_t)n * chunks + ch) * W * Cp, Cp, CG, CGb);
 }
 
 // totals of the mode 0 / 2 partials -> coef[2][Cp] = (sum d'/R, sum d' yhat / R), dgamma, dbeta (either may be NULL)
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ ws, int chunks, const float* __restrict__ pool_u,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, float* __restrict__ add, float* __restrict__ pn, int S, int C,
-                                                         int Cp, int Cse) {
+                                                         int Cp, int Cse, const float* __restrict__ stat, float* __restrict__ ws3) {
     extern __shared__ float sm[];
     float* pool = sm;             // [C]
     float* ds = pool + C;         // [C]
@@ -363,7 +379,25 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     float* p_b2 = p_w2 + (size_t)C * Cse;
     for (int c = tid; c < C; c += 256) {
         float dg = 0.0f;
-        for (int ch = 0; ch < chunks; ++ch) dg += ws[((size_t)n * chunks + ch) * 2 * Cp + c];
+        if (stat) {
+            // mode-4 partials [n][chunk][3][Cp]: clip totals (fixed order), left in chunk 0 for se_bn_coef_kernel; the gate's gradient
+            // sum d' u with u = gamma yhat + beta
+            float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            for (int ch = 0; ch < chunks; ++ch) {
+                const float* q = ws3 + ((size_t)n * chunks + ch) * 3 * Cp + c;
+                a1 += q[0];
+                a2 += q[Cp];
+                a3 += q[2 * Cp];
+            }
+            float* q0 = ws3 + (size_t)n * chunks * 3 * Cp + c;
+            q0[0] = a1;
+            q0[Cp] = a2;
+            q0[2 * Cp] = a3;
+            const float scv = stat[2 * Cp + c], gamma = scv / stat[Cp + c], beta = fmaf(stat[c], scv, stat[3 * Cp + c]);
+            dg = fmaf(gamma, a2, beta * a1);
+        } else {
+            for (int ch = 0; ch < chunks; ++ch) dg += ws[((size_t)n * chunks + ch) * 2 * Cp + c];
+        }
         float a = b2[c];
         for (int j = 0; j < Cse; ++j) a = fmaf(w2[(size_t)c * Cse + j], h[j], a);
         const float g = 1.0f / (1.0f + expf(-a));
@@ -635,6 +669,7 @@ static void launch_grad_pass(int mode, void* d, const void* y, const float* stat
                        g.CGb, g.rows_per_chunk, g.chunks, act, (int)(mode != 3))
     if (mode == 0 || mode == 3) GP(0);
     else if (mode == 1) GP(1);
+    else if (mode == 4) GP(4);
     else GP(2);
 #undef GP
 }
@@ -643,16 +678,16 @@ extern "C" int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const floa
                                     const float* add, float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp,
                                     int act, int dtype, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
-    PASN_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0, 1, 2 or 3");
+    PASN_REQUIRE(mode >= 0 && mode <= 4, "mode must be 0 .. 4");
     PASN_REQUIRE(d && y && stat && ws, "null pointer");
-    PASN_REQUIRE(mode == 1 || coef, "coef is required for modes 0 and 2");
-    PASN_REQUIRE(mode == 0 || mode == 3 || gate, "modes 1 and 2 need the gate");
+    PASN_REQUIRE(mode == 1 || mode == 4 || coef, "coef is required for modes 0, 2 and 3");
+    PASN_REQUIRE(mode == 0 || mode == 3 || gate, "modes 1, 2 and 4 need the gate");
     PASN_REQUIRE(mode != 3 || residual == nullptr, "mode 3 leaves d untouched: a residual branch needs the differentiated d of mode 0");
     const RowGeom g = row_geom(N, S, Cp);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16) launch_grad_pass<__bf16>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s);
     else launch_grad_pass<float>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s);
-    if (mode != 1)
+    if (mode != 1 && mode != 4)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, coef, dgamma, dbeta, N, S, C, Cp, g.chunks);
     return check_launch("unit_bwd_reduce");
 }
@@ -684,10 +719,100 @@ extern "C" int pasn_se_gate_bwd(const float* ws, const float* pool_u, const floa
     PASN_REQUIRE(lds <= 64 * 1024, "squeeze-excite width above the LDS budget");
     const RowGeom g = row_geom(N, S, Cp);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), lds, s, ws, g.chunks, pool_u, w1, b1, w2, b2, add, pn, S, C, Cp, Cse);
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), lds, s, ws, g.chunks, pool_u, w1, b1, w2, b2, add, pn, S, C, Cp, Cse, (const float*)nullptr,
+                       (float*)nullptr);
     const size_t len = 2 * (size_t)C * Cse + Cse + C;
     hipLaunchKernelGGL(se_sum_over_clips_kernel, dim3(ceil_div((long)len, 256)), dim3(256), 0, s, pn, dw1, db1, dw2, db2, N, C, Cse);
     return check_launch("se_gate_bwd");
+}
+
+// coef / dgamma / dbeta of a squeeze-excite unit's norm from the per-clip totals (A1, A2, A3) = (sum d', sum d' yhat, sum yhat) that
+// se_mlp_bwd_kernel left in chunk 0 of the mode-4 partials:  sum d'' = sum_n gate A1 + S add,  sum d'' yhat = sum_n gate A2 + add A3.
+__global__ __launch_bounds__(256) void se_bn_coef_kernel(const float* __restrict__ ws3, int chunks, const float* __restrict__ gate,
+                                                         const float* __restrict__ add, float* __restrict__ coef, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int N, int S, int C, int Cp) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cp) return;
+    float b1 = 0.0f, b2 = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        const float* q = ws3 + (size_t)n * chunks * 3 * Cp + c;
+        const float g = gate[(size_t)n * Cp + c], a = add[(size_t)n * Cp + c];
+        b1 += fmaf(g, q[0], (float)S * a);
+        b2 += fmaf(g, q[Cp], a * q[2 * Cp]);
+    }
+    const float R = (float)N * (float)S;
+    coef[c] = b1 / R;
+    coef[Cp + c] = b2 / R;
+    if (c < C) {
+        if (dgamma) dgamma[c] = b2;
+        if (dbeta) dbeta[c] = b1;
+    }
+}
+
+// dy = sc * (d'' - m1 - yhat * m2) with d'' = d' * gate[n][c] + add[n][c] formed on the fly (d' as left by mode 4)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
+                                                              const float* __restrict__ coef, const float* __restrict__ gate,
+                                                              const float* __restrict__ add, T* __restrict__ dy, int S, int Cp, int CG, int CGb,
+                                                              int rows_per_chunk) {
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    if (cg >= CG) return;
+    float mean[8], invstd[8], sc[8], m1[8], m2[8], g[8], ad[8];
+    load8(stat + cg * 8, mean);
+    load8(stat + Cp + cg * 8, invstd);
+    load8(stat + 2 * Cp + cg * 8, sc);
+    load8(coef + cg * 8, m1);
+    load8(coef + Cp + cg * 8, m2);
+    load8(gate + (size_t)n * Cp + cg * 8, g);
+    load8(add + (size_t)n * Cp + cg * 8, ad);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ad[j] -= m1[j];
+    const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
+    const size_t base = (size_t)n * S * Cp + cg * 8;
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const size_t o = base + (size_t)r * Cp;
+        float v[8], dv[8];
+        load8(y + o, v);
+        load8(d + o, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (fmaf(dv[j], g[j], ad[j]) - (v[j] - mean[j]) * invstd[j] * m2[j]);
+        store8(dy + o, dv);
+    }
+}
+
+extern "C" int pasn_se_gate_bwd_stat(float* ws3, const float* pool_u, const float* stat, const float* gate, const float* w1, const float* b1,
+                                     const float* w2, const float* b2, float* add, float* pn, float* dw1, float* db1, float* dw2, float* db2,
+                                     float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int Cse, void* stream) {
+    ROWS_ARGS_OK(N, S, C, Cp);
+    PASN_REQUIRE(Cse > 0 && ws3 && pool_u && stat && gate && w1 && b1 && w2 && b2 && add && pn && dw1 && db1 && dw2 && db2 && coef, "null pointer");
+    const size_t lds = (2 * (size_t)C + 2 * Cse) * sizeof(float);
+    PASN_REQUIRE(lds <= 64 * 1024, "squeeze-excite width above the LDS budget");
+    const RowGeom g = row_geom(N, S, Cp);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), lds, s, (const float*)nullptr, g.chunks, pool_u, w1, b1, w2, b2, add, pn, S, C, Cp, Cse,
+                       stat, ws3);
+    const size_t len = 2 * (size_t)C * Cse + Cse + C;
+    hipLaunchKernelGGL(se_sum_over_clips_kernel, dim3(ceil_div((long)len, 256)), dim3(256), 0, s, pn, dw1, db1, dw2, db2, N, C, Cse);
+    hipLaunchKernelGGL(se_bn_coef_kernel, dim3(ceil_div(Cp, 256)), dim3(256), 0, s, ws3, g.chunks, gate, add, coef, dgamma, dbeta, N, S, C, Cp);
+    return check_launch("se_gate_bwd_stat");
+}
+
+extern "C" int pasn_bn_bwd_apply_se(const void* d, const void* y, const float* stat, const float* coef, const float* gate, const float* add,
+                                    void* dy, int N, int S, int C, int Cp, int dtype, void* stream) {
+    ROWS_ARGS_OK(N, S, C, Cp);
+    PASN_REQUIRE(d && y && stat && coef && gate && add && dy, "null pointer");
+    const RowGeom g = row_geom(N, S, Cp);
+    const dim3 grid(g.chunks, N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASN_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_se_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)d, (const __bf16*)y, stat, coef, gate, add, (__bf16*)dy,
+                           S, Cp, g.CG, g.CGb, g.rows_per_chunk);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_se_kernel<float>, grid, dim3(256), 0, s, (const float*)d, (const float*)y, stat, coef, gate, add, (float*)dy, S,
+                           Cp, g.CG, g.CGb, g.rows_per_chunk);
+    return check_launch("bn_bwd_apply_se");
 }
 
 extern "C" int pasn_scatter_strided(const void* src, void* dst, const pasn_conv_desc* d, int accumulate, int dtype, void* stream) {

@@ -16,6 +16,7 @@ inference conv kernels (a 1x1x1 conv's input gradient is the same kernel with th
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -301,6 +302,7 @@ class TrainBuilder(PlanBuilder):
                     dg, db = 0, self.Gof(conv.bias)
                 else:
                     dg = db = 0
+                se_analytic = False
                 lazy = se is None and norm is not None and residual is None  # nobody but the apply pass reads the differentiated d
                 hook = self.red_hook.get(out.buf)
                 if hook is not None and hook["coef"] is not None:
@@ -308,6 +310,21 @@ class TrainBuilder(PlanBuilder):
                 elif se is None:
                     self._use(g.buf, y.buf, rb, stat_buf, ws, coef)
                     self._op(red, 3 if lazy else 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
+                elif residual is None and not os.environ.get("PASN_NO_SE_ANALYTIC"):
+                    # squeeze-excite unit, ONE pass over (d, y): mode 4 leaves d' = d act'(.) and per-clip (sum d', sum d' yhat, sum yhat);
+                    # the gate's gradient, the norm's coefficients and dgamma / dbeta follow from those per clip (d'' = d' gate + add is
+                    # affine in d'), and the apply pass forms d'' on the fly -- the second pass over the tensor (mode 2) is gone
+                    cse = se.fc1.out_channels
+                    se_analytic = True
+                    addb = self._new_buf(N * Cp * 4)
+                    pn = self._new_buf(int(lib.pasn_se_bwd_workspace_floats(N, C, cse)) * 4)
+                    ws3 = self._new_buf(N * chunks * 3 * Cp * 4)
+                    o = [self.Gof(t, nullable=False) for t in (se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)]
+                    self._use(g.buf, y.buf, stat_buf, gate_buf, ws3)
+                    self._op(red, 4, B(g.buf), B(y.buf), stat, 0, B(gate_buf), 0, B(ws3), 0, 0, 0, N, S, C, Cp, actc, code)
+                    self._use(ws3, pool_buf, stat_buf, gate_buf, addb, pn, coef)
+                    self._op(lib.pasn_se_gate_bwd_stat, B(ws3), B(pool_buf), stat, B(gate_buf), Pm(se.fc1.weight), Pm(se.fc1.bias),
+                             Pm(se.fc2.weight), Pm(se.fc2.bias), B(addb), B(pn), o[0], o[1], o[2], o[3], B(coef), dg, db, N, S, C, Cp, cse)
                 else:
                     cse = se.fc1.out_channels
                     addb = self._new_buf(N * Cp * 4)
@@ -324,7 +341,10 @@ class TrainBuilder(PlanBuilder):
                     self.add_grad(residual, g)  # after mode 0, g is the gradient of the pre-activation sum
                 if not (x_live or w_live):
                     return  # only this unit's norm / bias / SE parameters were trainable: their gradients are out already
-                if norm is not None:
+                if norm is not None and se_analytic:
+                    self._use(g.buf, y.buf, stat_buf, coef, gate_buf, addb)
+                    self._op(lib.pasn_bn_bwd_apply_se, B(g.buf), B(y.buf), stat, B(coef), B(gate_buf), B(addb), B(g.buf), N, S, C, Cp, code)
+                elif norm is not None:
                     dy = self.like(y) if residual is not None else g
                     self._use(g.buf, y.buf, stat_buf, coef, dy.buf)
                     self._op(lib.pasn_bn_bwd_apply, B(g.buf), B(y.buf), stat, B(coef), B(dy.buf), N, S, C, Cp, actc if lazy else 0, code)

@@ -151,6 +151,24 @@ def test_se_unit_forward_backward():
     for got, ref, name in zip(G, (gamma, beta, w1, b1, w2, b2), ("dgamma", "dbeta", "dfc1.w", "dfc1.b", "dfc2.w", "dfc2.b")):
         _rel(got, ref.grad, 2e-4, name)
     _rel(_ncl(dd, c), y.grad, 2e-4, "dy")
+    # the analytic form: ONE pass over (d, y) (mode 4), everything else from per-clip sums, d'' formed inside the apply pass
+    d4 = _cl(da)
+    ws3 = torch.zeros(n * chunks * 3 * cp, device=DEV)
+    add4, coef4 = torch.zeros(n * cp, device=DEV), torch.zeros(2 * cp, device=DEV)
+    G4 = [torch.zeros_like(t_) for t_ in P]
+    _lib.check(lib.pasn_unit_bwd_reduce(4, d4.data_ptr(), yd.data_ptr(), stat.data_ptr(), 0, gated.data_ptr(), 0, ws3.data_ptr(), 0, 0, 0, n, S, c,
+                                        cp, 3, F32, _st()))
+    _lib.check(lib.pasn_se_gate_bwd_stat(ws3.data_ptr(), pool_u.data_ptr(), stat.data_ptr(), gated.data_ptr(), P[2].data_ptr(), P[3].data_ptr(),
+                                         P[4].data_ptr(), P[5].data_ptr(), add4.data_ptr(), pn.data_ptr(), G4[2].data_ptr(), G4[3].data_ptr(),
+                                         G4[4].data_ptr(), G4[5].data_ptr(), coef4.data_ptr(), G4[0].data_ptr(), G4[1].data_ptr(), n, S, c, cp, cse,
+                                         _st()))
+    _lib.check(lib.pasn_bn_bwd_apply_se(d4.data_ptr(), yd.data_ptr(), stat.data_ptr(), coef4.data_ptr(), gated.data_ptr(), add4.data_ptr(),
+                                        d4.data_ptr(), n, S, c, cp, F32, _st()))
+    for got, ref, name in zip(G4, (gamma, beta, w1, b1, w2, b2), ("dgamma", "dbeta", "dfc1.w", "dfc1.b", "dfc2.w", "dfc2.b")):
+        _rel(got, ref.grad, 2e-4, name + " (analytic)")
+    _rel(coef4.view(2, cp)[:, :c], coef.view(2, cp)[:, :c], 1e-4, "coef, analytic vs two passes")
+    _rel(_ncl(d4, c), y.grad, 2e-4, "dy (analytic)")
+    assert float(d4[..., c:].abs().max()) == 0.0, "padded channels must stay zero"
 
 
 WGRAD_CASES = [
@@ -807,9 +825,10 @@ def test_video_x3d_train_unmodified_model_vs_oracle():
 
 
 @pytest.mark.parametrize("cfg,shape,spatial,env", [(CFG_VIDEO_X3D, SHAPE, SPATIAL, ""), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_DW_DGRAD_REDUCE"),
-                                                   (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_DW_STATS"), (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4), ""),
+                                                   (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_DW_STATS"), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_SE_ANALYTIC"),
+                                                   (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4), ""),
                                                    (CFG_XPROTO, (3, 3, 96, 96), (3, 3), "")],
-                         ids=["x3d_s", "x3d_s-dgrad+sums", "x3d_s-separate-stats", "r2plus1d", "resnet18"])
+                         ids=["x3d_s", "x3d_s-dgrad+sums", "x3d_s-separate-stats", "x3d_s-two-pass-se", "r2plus1d", "resnet18"])
 def test_train_bf16_activations_track_fp32(cfg, shape, spatial, env, monkeypatch):
     """bf16 activations / activation gradients (fp32 statistics, reductions, parameter gradients) against the fp32 mode, every trunk
     (bf16 takes other kernels: T-marching stencils with the batch statistics fused in -- and, opt-in, the producer unit's backward sums
