@@ -18,8 +18,8 @@
 //
 // Operand supply.  A first version read the B operands straight from global memory (16 positions x 2 x 32-byte pieces per
 // wave-instruction): 30 % SLOWER than the VALU kernel, bound by L1 tag lookups (~44 cycles per wave-load, ring depth irrelevant).  Here a
-// block owns BH x BW outputs (4 x 14) of one 64-channel quad and stages the (BH+2) x (BW+2) input region of every frame by LDS-DMA
-// (whole 128-byte position rows; cells outside the image are zeroed once per unit and never fetched) into a 3-frame ring; B operands are ds_read_b128 from a
+// block owns BH x BW outputs (7 x 14) of one 64-channel quad and stages the (BH+2) x (BW+2) input region of every frame by LDS-DMA
+// (whole 128-byte position rows; cells outside the image are zeroed once per unit and never fetched) into a 2-frame ring; B operands are ds_read_b128 from a
 // position stride of 160 bytes (10 slots: conflict-free for the read's four 16-lane groups, see the bank rule in the guide).  One
 // barrier per frame; a wave's DMA for frame t+2 is issued right after it, under the 60 MFMAs of frame t.
 //
@@ -36,10 +36,11 @@ typedef __attribute__((address_space(3))) void* dwm_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* dwm_gbl_ptr_t;
 
 constexpr int DWF_SLOTS = 10;   // 16-byte slots per staged position (8 used)
-constexpr int DWF_NTL = 4;      // position tiles per wave (4 x 14 outputs; 7 tiles = 84 accumulator registers spill at two waves per SIMD)
+constexpr int DWF_NTL = 7;      // position tiles per wave (7 x 14 outputs: the X3D planes are 56 / 28 / 14 / 7 high)
 constexpr int DWF_NE = 7;       // DMA instructions per wave and frame (<= 28 per block)
-constexpr int DWF_RING = 3;
+constexpr int DWF_RING = 2;      // frame images in LDS: frame t + 1 is requested right after the barrier of frame t (a step is ~2 us)
 constexpr int DWF_PITCH = 16;   // staged positions per region row
+constexpr int dwf_tiles(int rpt) { return rpt == 2 ? 4 : DWF_NTL; }  // two-row tiles (planes <= 8 wide): 4 x 2 rows, the LDS image stays <= 25 KB
 constexpr int DWF_OPITCH = 136; // bytes per position of the output image (128 used)
 constexpr int DWF_OBYTES = DWF_NTL * 16 * DWF_OPITCH;
 
@@ -123,10 +124,11 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     const long fstride = (long)Hi * Wi * Cp;  // elements per frame
     const __bf16* xclip = x + (long)n * Ti * fstride + cq * 64;
+    constexpr int NT = dwf_tiles(RPT);  // position tiles per wave
     constexpr int RW = DWF_PITCH;  // staged positions per region row (BW + 2 <= 16 used)
     // frame image size is a compile-time constant of the instance (the ring slots, the DMA destinations and the operand reads are then
     // immediates: as run-time scalars they cost ~90 spilled SGPRs, reloaded lane by lane at every frame)
-    constexpr int NI = ((DWF_NTL * RPT + 2) * DWF_PITCH * DWF_SLOTS + 63) / 64;
+    constexpr int NI = ((NT * RPT + 2) * DWF_PITCH * DWF_SLOTS + 63) / 64;
     constexpr int fbytes = NI * 1024;
     char* otile = ring + DWF_RING * fbytes;  // [2][NTL x 16 positions][136]: output images of two consecutive frames
     // tap offsets of this lane inside the staged region (pair j -> tap 2j + (q >> 1); the absent 10th tap reads the 9th's cell: its
@@ -200,18 +202,18 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         // stores of the previous frame to be acknowledged -- ~1.5 us per frame, the whole step serialised)
         unsigned fmask = 0;
 #pragma unroll
-        for (int l = 0; l < DWF_NTL; ++l)
+        for (int l = 0; l < NT; ++l)
             if (__builtin_amdgcn_ballot_w64(l * RPT + fl_lim < rows_valid) != 0) fmask |= 1u << l;
         const int kst = __builtin_popcount(fmask);
         const int fl_off = ((h0 + fl_row) * d.Wo + w0 + fl_col) * Cp + cq * 64 + (threadIdx.x & 15) * 4;
 
-        f32x4 S0[DWF_NTL], S1[DWF_NTL], S2[DWF_NTL];
+        f32x4 S0[NT], S1[NT], S2[NT];
         const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int l = 0; l < DWF_NTL; ++l) S0[l] = S1[l] = S2[l] = zero4;
+        for (int l = 0; l < NT; ++l) S0[l] = S1[l] = S2[l] = zero4;
 
         // one input frame ti from ring slot `slot`: P = output ti-1 (kt = 2), C = output ti (kt = 1), N = output ti+1 (kt = 0)
-        auto frame = [&](int ti, int slot, f32x4 (&P)[DWF_NTL], f32x4 (&C)[DWF_NTL], f32x4 (&N)[DWF_NTL]) {
+        auto frame = [&](int ti, int slot, f32x4 (&P)[NT], f32x4 (&C)[NT], f32x4 (&N)[NT]) {
             if (wave_live && ti >= 0 && ti < Ti && !(g.abl & 1)) {  // wave-uniform
                 // All three kt taps of every staged frame are applied: a set that belongs to an output frame outside this T chunk is
                 // simply never emitted and restarts from zero when it becomes N again (at most 2 of Tc + 2 frames carry such work).
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                 for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
                 __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
 #pragma unroll
-                for (int l = 0; l < DWF_NTL; ++l) {
-                    if (l + 1 < DWF_NTL) {
+                for (int l = 0; l < NT; ++l) {
+                    if (l + 1 < NT) {
 #pragma unroll
                         for (int j = 0; j < 5; ++j) Bq[(l + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ta[j] + (l + 1) * lstep);
                         __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
@@ -254,14 +256,15 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                 int mr = mrow_lim;
                 asm volatile("" : "+v"(mr));
 #pragma unroll
-                for (int l = 0; l < DWF_NTL; ++l)
+                for (int l = 0; l < NT; ++l)
                     if (l < ntl) {  // wave-uniform
                         float v[4];
                         const bool ok = l * RPT + mr < rows_valid;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            v[i] = P[l][i] * sc[i] + bs[i];
-                            psum[i] += ok ? v[i] : 0.0f;
+                        for (int i = 0; i < 4; ++i) v[i] = P[l][i] * sc[i] + bs[i];
+                        if (pool) {  // block-uniform
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) psum[i] += ok ? v[i] : 0.0f;
                         }
                         act_vec(v, d.act);
                         if (d.Cout - ce < 4) mask_tail(v, d.Cout - ce);
@@ -279,37 +282,44 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             const char* ob = otile + (to & 1) * DWF_OBYTES + (threadIdx.x >> 4) * DWF_OPITCH + (threadIdx.x & 15) * 8;
             int fr = fl_lim;
             asm volatile("" : "+v"(fr));
-            bf16x4 ov[DWF_NTL];
+            bf16x4 ov[NT];
 #pragma unroll
-            for (int l = 0; l < DWF_NTL; ++l) ov[l] = *reinterpret_cast<const bf16x4*>(ob + l * 16 * DWF_OPITCH);  // all reads, then the stores
+            for (int l = 0; l < NT; ++l) ov[l] = *reinterpret_cast<const bf16x4*>(ob + l * 16 * DWF_OPITCH);  // all reads, then the stores
 #pragma unroll
-            for (int l = 0; l < DWF_NTL; ++l)
+            for (int l = 0; l < NT; ++l)
                 if ((fmask >> l) & 1u)  // wave-uniform
                     if (l * RPT + fr < rows_valid) *reinterpret_cast<bf16x4*>(yf + fl_off + l * ystep) = ov[l];
         };
         // one pipeline step: this wave's pieces of frame ti have landed (everything it issued since is the group of frame ti+1), then
         // everyone's have and nobody still reads the slot of frame ti-1, which takes frame ti+2
-        auto step = [&](int ti, int slot, f32x4 (&P)[DWF_NTL], f32x4 (&C)[DWF_NTL], f32x4 (&N)[DWF_NTL]) {
+        auto step = [&](int ti, int slot, f32x4 (&P)[NT], f32x4 (&C)[NT], f32x4 (&N)[NT]) {
             if (!(g.abl & 8)) {
-                // younger than the group of frame ti: the stores of output ti-3 and the group of frame ti+1 (both issued in step ti-1)
+                // younger than the group of frame ti (issued in step ti-1 right after its barrier): the stores of output ti-3
                 const bool st3 = ti - 3 >= t0 && ti - 3 < t1 && !(g.abl & 4);
-                dwf_wait_all_but((st3 ? kst : 0) + (staged(ti + 1) && !(g.abl & 2) ? kdma : 0));
+                dwf_wait_all_but(st3 ? kst : 0);
                 dwf_barrier();
             }
-            flush(ti - 2);  // written by frame ti-1 before this barrier; its image is rewritten by frame ti+1, after the next one
-            issue(ti + 2, slot == 0 ? 2 : slot - 1);
+            issue(ti + 1, slot ^ 1);  // the other image was last read in step ti-1: everyone is past that now
+            flush(ti - 2);            // written by frame ti-1 before this barrier; its image is rewritten by frame ti+1, after the next one
             frame(ti, slot, P, C, N);
         };
 
         for (int o = threadIdx.x * 16; o < ((g.abl & 32) ? 0 : DWF_RING * fbytes); o += 256 * 16) *reinterpret_cast<dwm_u32x4*>(ring + o) = dwm_u32x4{0u, 0u, 0u, 0u};
         __syncthreads();  // zeros written (lgkmcnt drained) before any piece may land on them
         issue(t0 - 1, 0);
-        issue(t0, 1);
+        // ONE step per iteration, the accumulator sets rotated by register moves (2 x NTL x 4 per frame).  Unrolling by three with the
+        // sets passed by name (no moves) costs 70-250 VGPRs per extra copy of the step with this compiler (7 tiles: 156 VGPRs rolled, 225
+        // with two copies, 256 + 225 spilled with three), which is what limited the kernel to 4 tiles per wave.
+        int slot = 0;
 #pragma unroll 1
-        for (int ti = t0 - 1; ti <= ((g.abl & 64) ? t0 - 2 : t1); ti += 3) {
-            step(ti, 0, S0, S1, S2);
-            if (ti + 1 <= t1) step(ti + 1, 1, S1, S2, S0);
-            if (ti + 2 <= t1) step(ti + 2, 2, S2, S0, S1);
+        for (int ti = t0 - 1; ti <= ((g.abl & 64) ? t0 - 2 : t1); ++ti) {
+            step(ti, slot, S0, S1, S2);
+#pragma unroll
+            for (int l = 0; l < NT; ++l) {
+                S0[l] = S1[l];
+                S1[l] = S2[l];
+            }
+            slot ^= 1;
         }
         __syncthreads();  // the last output image is complete; nobody reads the ring any more
         flush(t1 - 1);
@@ -337,24 +347,27 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     DwMfmaGeom g = {};
     if (dtype != PASN_BF16) return g;
-    // OPT-IN (PASN_DWMFMA=1): parity-green but 15-30 % slower than the VALU stencil on the benchmark layers (profiles/README entry 45)
+    // Default: only the planes at most 8 wide (the 7 x 7 stage: 28.7 vs 34.5 us per launch, +1.2 % end to end); on the wider planes the
+    // kernel ties or loses against the VALU stencil (profiles/README entry 45).  PASN_DWMFMA=1: every stride-1 layer, =0: none.
     const char* on = getenv("PASN_DWMFMA");
-    if (!on || on[0] != '1') return g;
+    if (on && on[0] == '0') return g;
+    const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : ((on && on[0] == '1') ? (1 << 30) : 8);
+    if (d.Wo > maxw) return g;
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
                        d.pw == 1 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0;
     if (!shape) return g;
     if ((long)d.Hi * d.Wi * d.Cin_p >= (1L << 30)) return g;  // 32-bit element offsets inside a frame
     g.CT = ceil_div(d.Cout_p, 16);
     g.CQ = ceil_div(g.CT, 4);
-    // region = 4 rows x 14 columns of outputs (the X3D planes are 56 / 28 / 14 / 7 wide: no ragged strips); a 16-lane position tile
-    // is one output row (14 lanes used) or, on planes at most 8 wide, two (7 x 7: one region per frame)
+    // region = 7 rows x 14 columns of outputs (the X3D planes are 56 / 28 / 14 / 7 wide and high: no ragged regions); a 16-lane position
+    // tile is one output row (14 lanes used) or, on planes at most 8 wide, two
     g.BW = std::min(d.Wo, 14);
     g.RPT = g.BW <= 8 ? 2 : 1;
-    g.BH = std::min(d.Ho, DWF_NTL * g.RPT);
+    g.BH = std::min(d.Ho, dwf_tiles(g.RPT) * g.RPT);
     g.RTH = ceil_div(d.Ho, g.BH);
     g.RTW = ceil_div(d.Wo, g.BW);
     g.RP = (g.BH + 2) * DWF_PITCH;
-    g.NI = ceil_div((DWF_NTL * g.RPT + 2) * DWF_PITCH * DWF_SLOTS, 64);  // the instance's constant (region height DWF_NTL * RPT)
+    g.NI = ceil_div((dwf_tiles(g.RPT) * g.RPT + 2) * DWF_PITCH * DWF_SLOTS, 64);  // the instance's constant (region height tiles * RPT)
     // (Tc, upb): blocks run two per CU, a block costs a setup (weight operands, pipeline fill) plus upb units of Tc + 2 frames; at most
     // 64 chunks per clip where it costs nothing (the chunk count is the number of SE partial rows the gate has to sum)
     const int force_tc = getenv("PASN_DWMFMA_TC") ? atoi(getenv("PASN_DWMFMA_TC")) : 0;

@@ -546,7 +546,7 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     fp32 accumulation in both)."""
     tc, upb = geom.split(",")
     monkeypatch.delenv("PASN_DWM2", raising=False)
-    monkeypatch.setenv("PASN_DWMFMA", "1")  # opt-in kernel
+    monkeypatch.setenv("PASN_DWMFMA", "1")  # every stride-1 layer (default: only the planes at most 8 wide)
     if tc != "0":
         monkeypatch.setenv("PASN_DWMFMA_TC", tc)
         monkeypatch.setenv("PASN_DWMFMA_UPB", upb)
@@ -559,7 +559,7 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     want = pre.sum(dim=(2, 3, 4))
     assert_close(part.sum(dim=1)[:, :c].cpu(), want, 2e-2 * float(want.abs().max()), 0, "SE partial sums")
     assert float(out[..., c:].abs().max() if out.shape[-1] > c else 0.0) == 0.0, "padded channels must stay zero"
-    monkeypatch.delenv("PASN_DWMFMA")
+    monkeypatch.setenv("PASN_DWMFMA", "0")  # (unset, the planes at most 8 wide take the matrix-core stencil by default)
     out1, part1, kernel1 = _run_march(x, conv, bn, "swish")
     assert kernel1.startswith("dwconv3d_march_kernel<"), kernel1
     d = (out.float() - out1.float()).abs()

@@ -282,6 +282,7 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
     agent-scope arrival counter, acquire on the last arriver) against the stencil launch + stand-alone gate launch: same features up
     to the fp32 summation order of the pool, bitwise equal across repeated runs (the counters return to zero after every launch, the
     reduction order is fixed), and every SE layer really takes the fused launch."""
+    monkeypatch.setenv("PASN_DWMFMA", "0")  # the VALU stencil with and without the gate (the 7 x 7 stage otherwise takes the matrix-core one)
     x = synth.echo_clips(shape).to(DEV).bfloat16()
     # default routing: the gate rides in the stencil launch up to 128 channels (stages 2-3), the wider stages keep the stand-alone launch
     m0 = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)

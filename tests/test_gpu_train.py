@@ -300,10 +300,11 @@ def test_depthwise_dgrad_wgrad(c, k, s, p, shape):
 
 @pytest.mark.parametrize("c,s,shape,se", [(54, 1, (2, 5, 11, 13), True), (54, 2, (2, 4, 14, 18), False), (432, 1, (3, 9, 7, 7), True),
                                           (216, 2, (2, 3, 14, 14), False)])
-def test_depthwise_stencil_with_fused_batch_statistics(c, s, shape, se):
+def test_depthwise_stencil_with_fused_batch_statistics(c, s, shape, se, monkeypatch):
     """pasn_dwconv3d_stats_fwd (the stencil takes sum / sum of squares of its fp32 outputs per block; the finalize pass reads those
     partials): y identical to pasn_dwconv3d_fwd, the statistics table, the running estimates and the per-clip SE pool equal to
     pasn_bn_stats_fwd's on that y within fp32 / bf16-rounding noise, and to torch's batch_norm statistics of the fp32 conv output."""
+    monkeypatch.setenv("PASN_DWMFMA", "0")  # the separate pass on the same (VALU) stencil
     lib = _lib.lib()
     n, t, h, w = shape
     g = torch.Generator().manual_seed(c + s)
@@ -361,6 +362,7 @@ def test_depthwise_dgrad_with_fused_backward_sums(c, shape, act, monkeypatch):
     equal to pasn_unit_bwd_reduce(mode 3) on (dx, y_prev) within the bf16 rounding of dx (the fused sums see the fp32 dx); then checked
     end to end against autograd of  conv_dw(act(batch_norm(y_prev)))."""
     monkeypatch.setenv("PASN_DW_DGRAD_REDUCE", "1")
+    monkeypatch.setenv("PASN_DWMFMA", "0")  # the separate pass on the same (VALU) stencil
     lib = _lib.lib()
     n, t, h, w = shape
     g = torch.Generator().manual_seed(c)
