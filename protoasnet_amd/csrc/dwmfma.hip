@@ -71,7 +71,7 @@ __device__ __forceinline__ void dwf_wait_all_but(int n) {  // n wave-uniform: ev
 // from memory is waited for by count (dwf_wait_all_but) just before.
 __device__ __forceinline__ void dwf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int RPT>
+template <int RPT, bool ABLB = false>
 __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ scale, const float* __restrict__ bias,
                                                                __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     const long fstride = (long)Hi * Wi * Cp;  // elements per frame
     const __bf16* xclip = x + (long)n * Ti * fstride + cq * 64;
     constexpr int NT = dwf_tiles(RPT);  // position tiles per wave
+    const int abl = ABLB ? g.abl : 0;   // timing ablations: a separate instance, the product kernel carries none of the checks
     constexpr int RW = DWF_PITCH;  // staged positions per region row (BW + 2 <= 16 used)
     // frame image size is a compile-time constant of the instance (the ring slots, the DMA destinations and the operand reads are then
     // immediates: as run-time scalars they cost ~90 spilled SGPRs, reloaded lane by lane at every frame)
@@ -160,14 +161,14 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             const int rp = slot / DWF_SLOTS, c = slot - rp * DWF_SLOTS;
             const int rr = rp / RW, cc = rp - rr * RW;
             const int hi = h0 - 1 + rr, wi = w0 - 1 + cc;
-            const bool ok = !(g.abl & 16) && wave + 4 * e < NI && rp < g.RP && cc < g.BW + 2 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            const bool ok = !(abl & 16) && wave + 4 * e < NI && rp < g.RP && cc < g.BW + 2 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
             goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cp + c * 8) * 2) : ~0u;
             if (__builtin_amdgcn_ballot_w64(ok) != 0) emask |= 1u << e;
         }
         const int kdma = __builtin_popcount(emask);  // DMA instructions of this wave per frame
         auto staged = [&](int ti) -> bool { return ti >= 0 && ti < Ti && ti >= t0 - 1 && ti <= t1; };
         auto issue = [&](int ti, int slot) {
-            if (!staged(ti) || (g.abl & 2)) return;
+            if (!staged(ti) || (abl & 2)) return;
             const char* xf = reinterpret_cast<const char*>(xclip + (long)ti * fstride);
             char* dst = ring + slot * fbytes;
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 
         // one input frame ti from ring slot `slot`: P = output ti-1 (kt = 2), C = output ti (kt = 1), N = output ti+1 (kt = 0)
         auto frame = [&](int ti, int slot, f32x4 (&P)[NT], f32x4 (&C)[NT], f32x4 (&N)[NT]) {
-            if (wave_live && ti >= 0 && ti < Ti && !(g.abl & 1)) {  // wave-uniform
+            if (wave_live && ti >= 0 && ti < Ti && !(abl & 1)) {  // wave-uniform
                 // All three kt taps of every staged frame are applied: a set that belongs to an output frame outside this T chunk is
                 // simply never emitted and restarts from zero when it becomes N again (at most 2 of Tc + 2 frames carry such work).
                 // per-frame operand addresses (kept out of the loop-invariant hoisting: three slots x five taps of them otherwise stay live
@@ -240,16 +241,25 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
                         const bf16x8 B = Bq[l & 1][j];
-                        // N was emitted (or never touched) one frame ago: its first MFMA starts from a constant zero
+                        // The role rotation rides in the first MFMA of every chain (D and C are different registers there): the new P is
+                        // the old C plus this frame's kt = 2 taps, the new C the old N plus kt = 1, the new N starts from a constant zero.
+                        // No register moves (2 x NT x 4 per frame otherwise).  Order P, C, N: each reads a set before it is overwritten.
+                        P[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, j == 0 ? C[l] : P[l], 0, 0, 0);
+                        C[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, j == 0 ? N[l] : C[l], 0, 0, 0);
                         N[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : N[l], 0, 0, 0);
-                        C[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, C[l], 0, 0, 0);
-                        P[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, P[l], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
                 }
+            } else {  // a frame outside the clip (zero padding in T), or an idle wave: only the roles move on
+#pragma unroll
+                for (int l = 0; l < NT; ++l) {
+                    P[l] = C[l];
+                    C[l] = N[l];
+                    N[l] = zero4;
+                }
             }
             const int to = ti - 1;  // has now seen frames ti-2, ti-1, ti
-            if (wave_live && to >= t0 && to < t1 && !(g.abl & 4)) {
+            if (wave_live && to >= t0 && to < t1 && !(abl & 4)) {
                 // into the output image of frame `to` (LDS, position pitch 136 bytes: conflict-free 8-byte writes); the block stores it as
                 // whole channel rows after the next barrier (a wave owns 32 bytes of every position: 16 partial lines per wave-store before)
                 char* ob = otile + (to & 1) * DWF_OBYTES + m * DWF_OPITCH + wave * 32 + q * 8;
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         };
         // store output frame `to` from its LDS image: thread -> (position lane tid >> 4, 8-byte piece tid & 15) of every tile
         auto flush = [&](int to) {
-            if (to < t0 || to >= t1 || (g.abl & 4)) return;
+            if (to < t0 || to >= t1 || (abl & 4)) return;
             __bf16* yf = yclip + (long)to * ofs;
             const char* ob = otile + (to & 1) * DWF_OBYTES + (threadIdx.x >> 4) * DWF_OPITCH + (threadIdx.x & 15) * 8;
             int fr = fl_lim;
@@ -293,9 +303,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         // one pipeline step: this wave's pieces of frame ti have landed (everything it issued since is the group of frame ti+1), then
         // everyone's have and nobody still reads the slot of frame ti-1, which takes frame ti+2
         auto step = [&](int ti, int slot, f32x4 (&P)[NT], f32x4 (&C)[NT], f32x4 (&N)[NT]) {
-            if (!(g.abl & 8)) {
+            if (!(abl & 8)) {
                 // younger than the group of frame ti (issued in step ti-1 right after its barrier): the stores of output ti-3
-                const bool st3 = ti - 3 >= t0 && ti - 3 < t1 && !(g.abl & 4);
+                const bool st3 = ti - 3 >= t0 && ti - 3 < t1 && !(abl & 4);
                 dwf_wait_all_but(st3 ? kst : 0);
                 dwf_barrier();
             }
@@ -304,21 +314,16 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             frame(ti, slot, P, C, N);
         };
 
-        for (int o = threadIdx.x * 16; o < ((g.abl & 32) ? 0 : DWF_RING * fbytes); o += 256 * 16) *reinterpret_cast<dwm_u32x4*>(ring + o) = dwm_u32x4{0u, 0u, 0u, 0u};
+        for (int o = threadIdx.x * 16; o < ((abl & 32) ? 0 : DWF_RING * fbytes); o += 256 * 16) *reinterpret_cast<dwm_u32x4*>(ring + o) = dwm_u32x4{0u, 0u, 0u, 0u};
         __syncthreads();  // zeros written (lgkmcnt drained) before any piece may land on them
         issue(t0 - 1, 0);
-        // ONE step per iteration, the accumulator sets rotated by register moves (2 x NTL x 4 per frame).  Unrolling by three with the
-        // sets passed by name (no moves) costs 70-250 VGPRs per extra copy of the step with this compiler (7 tiles: 156 VGPRs rolled, 225
-        // with two copies, 256 + 225 spilled with three), which is what limited the kernel to 4 tiles per wave.
+        // ONE step per iteration with FIXED role registers (S0 = P, S1 = C, S2 = N; the rotation is done by the MFMAs, see frame()).
+        // Unrolling by three with the sets passed by name costs 70-250 VGPRs per extra copy of the step with this compiler (7 tiles: 156
+        // VGPRs rolled, 225 with two copies, 256 + 225 spilled with three), which is what limited the kernel to 4 tiles per wave.
         int slot = 0;
 #pragma unroll 1
-        for (int ti = t0 - 1; ti <= ((g.abl & 64) ? t0 - 2 : t1); ++ti) {
+        for (int ti = t0 - 1; ti <= ((abl & 64) ? t0 - 2 : t1); ++ti) {
             step(ti, slot, S0, S1, S2);
-#pragma unroll
-            for (int l = 0; l < NT; ++l) {
-                S0[l] = S1[l];
-                S1[l] = S2[l];
-            }
             slot ^= 1;
         }
         __syncthreads();  // the last output image is complete; nobody reads the ring any more
@@ -347,11 +352,12 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     DwMfmaGeom g = {};
     if (dtype != PASN_BF16) return g;
-    // Default: only the planes at most 8 wide (the 7 x 7 stage: 28.7 vs 34.5 us per launch, +1.2 % end to end); on the wider planes the
-    // kernel ties or loses against the VALU stencil (profiles/README entry 45).  PASN_DWMFMA=1: every stride-1 layer, =0: none.
+    // Default: the planes at most 14 wide (the 14 x 14 and 7 x 7 stages: 38.6 vs 41.1 and 27.6 vs 34.9 us per launch; end to end, three
+    // alternating runs each: none 8080 clips/s, <= 8 wide 8200, <= 14 wide 8365, <= 28 wide 8180, all 8190 -- profiles/README entry 45).
+    // PASN_DWMFMA=1: every stride-1 layer, =0: none, PASN_DWMFMA_MAXW: the width limit.
     const char* on = getenv("PASN_DWMFMA");
     if (on && on[0] == '0') return g;
-    const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : ((on && on[0] == '1') ? (1 << 30) : 8);
+    const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : ((on && on[0] == '1') ? (1 << 30) : 14);
     if (d.Wo > maxw) return g;
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
                        d.pw == 1 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0;
@@ -403,8 +409,9 @@ int launch_dw_mfma(const void* x, const float* w, const float* scale, const floa
                    const DwMfmaGeom& g, hipStream_t s) {
     const dim3 grid(g.bpc * d.N), block(256);
     const size_t lds = (size_t)DWF_RING * g.NI * 1024 + 2 * DWF_OBYTES;
-    if (g.RPT == 2) hipLaunchKernelGGL(dwconv3d_mfma_kernel<2>, grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
-    else hipLaunchKernelGGL(dwconv3d_mfma_kernel<1>, grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+    if (g.abl) hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+    else if (g.RPT == 2) hipLaunchKernelGGL((dwconv3d_mfma_kernel<2, false>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+    else hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, false>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
     return check_launch("dwconv3d_mfma_kernel");
 }
 

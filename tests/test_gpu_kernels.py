@@ -519,6 +519,7 @@ def test_dwconv3d_march2_instances(inst, tc, c, monkeypatch):
     stride = int(stride)
     x, conv, bn, pre = _march_case(stride, c)
     ref = pre * torch.sigmoid(pre)
+    monkeypatch.setenv("PASN_DWMFMA", "0")  # the VALU generations against each other (planes this narrow take the matrix-core stencil)
     monkeypatch.setenv("PASN_DWM2", f"{chwt},{tc}")
     out, part, kernel = _run_march(x, conv, bn, "swish")
     ch, wt = chwt.split(",")
@@ -572,7 +573,8 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
 def test_dwconv3d_march_variants(stride, tc, wt, monkeypatch):
     """T-marching stencil: every (outputs per strip, T chunk) instance on a shape with T = 9 (chunk halos, a partial last
     chunk), ragged W for both strip widths and SE partial sums; the cost model's own choice is covered by DW_CASES."""
-    monkeypatch.delenv("PASN_DWM2", raising=False)  # round 1's kernel (the second-generation and the matrix-core one are opt-in)
+    monkeypatch.delenv("PASN_DWM2", raising=False)  # round 1's kernel (the second-generation one is opt-in, the matrix-core one takes
+    monkeypatch.setenv("PASN_DWMFMA", "0")           # narrow planes by default)
     monkeypatch.setenv("PASN_DWM_WT", str(wt))
     monkeypatch.setenv("PASN_DWM_TC", str(tc))
     dtype = torch.bfloat16
