@@ -242,7 +242,10 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(dominant, {}).get("traffic_bytes_per_launch")
+                table = json.load(open(pmc_path))
+                # the profiler prints defaulted template arguments the plan's kernel names leave out (march stencil: "<1,3,false>")
+                entry = table.get(dominant) or table.get(dominant[:-1] + ",false>" if dominant.endswith(">") else dominant) or {}
+                traffic = entry.get("traffic_bytes_per_launch")
             except (ValueError, OSError):
                 traffic = None
         tflops = avg_flops / (avg_ms * 1e-3) / 1e12
