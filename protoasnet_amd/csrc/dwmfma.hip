@@ -42,7 +42,7 @@ constexpr int DWF_RING = 2;      // frame images in LDS: frame t + 1 is requeste
 constexpr int DWF_PITCH = 16;   // staged positions per region row
 constexpr int dwf_tiles(int rpt) { return rpt == 2 ? 4 : DWF_NTL; }  // two-row tiles (planes <= 8 wide): 4 x 2 rows, the LDS image stays <= 25 KB
 constexpr int DWF_OPITCH = 136; // bytes per position of the output image (128 used)
-constexpr int DWF_OBYTES = DWF_NTL * 16 * DWF_OPITCH;
+constexpr int dwf_obytes(int rpt) { return dwf_tiles(rpt) * 16 * DWF_OPITCH; }  // one output image (two-row instance: 4 tiles -- 69 KB per block, two blocks per CU)
 
 __device__ __forceinline__ unsigned bf16_bits_rne(float f) {
     const __bf16 b = (__bf16)f;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             if (wave_live && to >= t0 && to < t1 && !(abl & 4)) {
                 // into the output image of frame `to` (LDS, position pitch 136 bytes: conflict-free 8-byte writes); the block stores it as
                 // whole channel rows after the next barrier (a wave owns 32 bytes of every position: 16 partial lines per wave-store before)
-                char* ob = otile + (to & 1) * DWF_OBYTES + m * DWF_OPITCH + wave * 32 + q * 8;
+                char* ob = otile + (to & 1) * dwf_obytes(RPT) + m * DWF_OPITCH + wave * 32 + q * 8;
                 int mr = mrow_lim;
                 asm volatile("" : "+v"(mr));
 #pragma unroll
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         auto flush = [&](int to) {
             if (to < t0 || to >= t1 || (abl & 4)) return;
             __bf16* yf = yclip + (long)to * ofs;
-            const char* ob = otile + (to & 1) * DWF_OBYTES + (threadIdx.x >> 4) * DWF_OPITCH + (threadIdx.x & 15) * 8;
+            const char* ob = otile + (to & 1) * dwf_obytes(RPT) + (threadIdx.x >> 4) * DWF_OPITCH + (threadIdx.x & 15) * 8;
             int fr = fl_lim;
             asm volatile("" : "+v"(fr));
             bf16x4 ov[NT];
@@ -408,7 +408,7 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
                    const DwMfmaGeom& g, hipStream_t s) {
     const dim3 grid(g.bpc * d.N), block(256);
-    const size_t lds = (size_t)DWF_RING * g.NI * 1024 + 2 * DWF_OBYTES;
+    const size_t lds = (size_t)DWF_RING * g.NI * 1024 + 2 * dwf_obytes(g.RPT);
     if (g.abl) hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
     else if (g.RPT == 2) hipLaunchKernelGGL((dwconv3d_mfma_kernel<2, false>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
     else hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, false>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
