@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
         const int j = j0 + (tid >> 3), sub = tid & 7;
         float a = 0.0f;
         if (j < Cse)
+#pragma unroll 8
             for (int c = sub; c < C; c += 8) a = fmaf(w1[(size_t)j * C + c], pool[c], a);
         a += __shfl_xor(a, 1);
         a += __shfl_xor(a, 2);
@@ -383,11 +384,24 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
             // mode-4 partials [n][chunk][3][Cp]: clip totals (fixed order), left in chunk 0 for se_bn_coef_kernel; the gate's gradient
             // sum d' u with u = gamma yhat + beta
             float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            for (int ch = 0; ch < chunks; ++ch) {
-                const float* q = ws3 + ((size_t)n * chunks + ch) * 3 * Cp + c;
-                a1 += q[0];
-                a2 += q[Cp];
-                a3 += q[2 * Cp];
+            // batches of 8 chunks: 24 independent loads in flight, then the adds in chunk order (a rolled load -> add loop is one L2 round
+            // trip per chunk: ~1 us x 32 chunks per launch, 15 launches per step)
+            for (int ch0 = 0; ch0 < chunks; ch0 += 8) {
+                float t1[8], t2[8], t3[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* q = ws3 + ((size_t)n * chunks + min(ch0 + u, chunks - 1)) * 3 * Cp + c;
+                    t1[u] = q[0];
+                    t2[u] = q[Cp];
+                    t3[u] = q[2 * Cp];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (ch0 + u < chunks) {
+                        a1 += t1[u];
+                        a2 += t2[u];
+                        a3 += t3[u];
+                    }
             }
             float* q0 = ws3 + (size_t)n * chunks * 3 * Cp + c;
             q0[0] = a1;
@@ -396,14 +410,22 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
             const float scv = stat[2 * Cp + c], gamma = scv / stat[Cp + c], beta = fmaf(stat[c], scv, stat[3 * Cp + c]);
             dg = fmaf(gamma, a2, beta * a1);
         } else {
-            for (int ch = 0; ch < chunks; ++ch) dg += ws[((size_t)n * chunks + ch) * 2 * Cp + c];
+            for (int ch0 = 0; ch0 < chunks; ch0 += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ws[((size_t)n * chunks + min(ch0 + u, chunks - 1)) * 2 * Cp + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dg += ch0 + u < chunks ? t[u] : 0.0f;
+            }
         }
         float a = b2[c];
+#pragma unroll 8
         for (int j = 0; j < Cse; ++j) a = fmaf(w2[(size_t)c * Cse + j], h[j], a);
         const float g = 1.0f / (1.0f + expf(-a));
         const float d = dg * g * (1.0f - g);
         ds[c] = d;
         p_b2[c] = d;
+#pragma unroll 8
         for (int j = 0; j < Cse; ++j) p_w2[(size_t)c * Cse + j] = d * h[j];
     }
     __syncthreads();
@@ -411,6 +433,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
         const int j = j0 + (tid >> 3), sub = tid & 7;
         float a = 0.0f;
         if (j < Cse)
+#pragma unroll 8
             for (int c = sub; c < C; c += 8) a = fmaf(w2[(size_t)c * Cse + j], ds[c], a);
         a += __shfl_xor(a, 1);
         a += __shfl_xor(a, 2);
@@ -424,6 +447,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float a = 0.0f;
+#pragma unroll 8
         for (int j = 0; j < Cse; ++j) {
             a = fmaf(w1[(size_t)j * C + c], dh[j], a);
             p_w1[(size_t)j * C + c] = dh[j] * pool[c];
@@ -735,11 +759,24 @@ __global__ __launch_bounds__(256) void se_bn_coef_kernel(const float* __restrict
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Cp) return;
     float b1 = 0.0f, b2 = 0.0f;
-    for (int n = 0; n < N; ++n) {
-        const float* q = ws3 + (size_t)n * chunks * 3 * Cp + c;
-        const float g = gate[(size_t)n * Cp + c], a = add[(size_t)n * Cp + c];
-        b1 += fmaf(g, q[0], (float)S * a);
-        b2 += fmaf(g, q[Cp], a * q[2 * Cp]);
+    for (int n0 = 0; n0 < N; n0 += 8) {  // 8 clips' loads in flight, the sums in clip order
+        float q0[8], q1[8], q2[8], g[8], a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = min(n0 + u, N - 1);
+            const float* q = ws3 + (size_t)n * chunks * 3 * Cp + c;
+            q0[u] = q[0];
+            q1[u] = q[Cp];
+            q2[u] = q[2 * Cp];
+            g[u] = gate[(size_t)n * Cp + c];
+            a[u] = add[(size_t)n * Cp + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (n0 + u < N) {
+                b1 += fmaf(g[u], q0[u], (float)S * a[u]);
+                b2 += fmaf(g[u], q1[u], a[u] * q2[u]);
+            }
     }
     const float R = (float)N * (float)S;
     coef[c] = b1 / R;
