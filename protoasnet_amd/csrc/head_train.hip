@@ -87,51 +87,69 @@ __global__ __launch_bounds__(256) void xproto_tail_fwd_kernel(const float* __res
     }
 }
 
-// one block per prototype: dF[:, p, :], dproto[p, :], dfc_w[:, p]
+// one block per prototype: dF[:, p, :], dproto[p, :], dfc_w[:, p].  A WAVE owns a clip (clips wave, wave + 4, ...): the two dot products
+// are wave reductions (no block barrier), a lane holds D / 64 elements of the row, and the four clips of a batch are loaded before any
+// is reduced.  (First version: the block walked the clips one by one with two block-wide sums each -- 32 x (a load round trip + 4
+// barriers), 120 us of latency for 30 blocks.)  dproto: per-wave partial sums in clip order, combined in wave order (fixed).
 __global__ __launch_bounds__(256) void xproto_tail_bwd_kernel(const float* __restrict__ F, const float* __restrict__ protos,
                                                               const float* __restrict__ fc_w, const float* __restrict__ sim,
                                                               const float* __restrict__ dlogits, const float* __restrict__ dsim,
                                                               float* __restrict__ dF, float* __restrict__ dprotos, float* __restrict__ dfc_w, int N,
                                                               int D, int P, int K) {
-    __shared__ float red[4];
-    const int p = blockIdx.x;
+    constexpr int EL = 8;  // elements per lane: D <= 512
+    __shared__ float dqs[4][64 * EL];
+    const int p = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float q[EL], dq[EL];
     float np = 0.0f;
-    for (int dd = threadIdx.x; dd < D; dd += 256) {
-        const float q = protos[(size_t)p * D + dd];
-        np = fmaf(q, q, np);
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+        const int dd = lane + 64 * e;
+        q[e] = dd < D ? protos[(size_t)p * D + dd] : 0.0f;
+        np = fmaf(q[e], q[e], np);
+        dq[e] = 0.0f;
     }
-    np = block_sum(np, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o, 64);
     const float nP = fmaxf(sqrtf(np), COS_EPS);
     const bool p_clamped = sqrtf(np) < COS_EPS;
-    float dq[2] = {0.0f, 0.0f};  // dproto accumulators for d = tid, tid + 256
-    for (int n = 0; n < N; ++n) {
+    for (int n = wave; n < N; n += 4) {
+        float f[EL];
         float dot = 0.0f, nf = 0.0f;
-        for (int dd = threadIdx.x; dd < D; dd += 256) {
-            const float f = F[((size_t)n * P + p) * D + dd], q = protos[(size_t)p * D + dd];
-            dot = fmaf(f, q, dot);
-            nf = fmaf(f, f, nf);
+#pragma unroll
+        for (int e = 0; e < EL; ++e) {
+            const int dd = lane + 64 * e;
+            f[e] = dd < D ? F[((size_t)n * P + p) * D + dd] : 0.0f;
         }
-        dot = block_sum(dot, red);
-        nf = block_sum(nf, red);
-        const float nF = fmaxf(sqrtf(nf), COS_EPS);
-        const bool f_clamped = sqrtf(nf) < COS_EPS;
         float ds = dsim ? dsim[(size_t)n * P + p] : 0.0f;
         for (int k = 0; k < K; ++k) ds = fmaf(dlogits[(size_t)n * K + k], fc_w[(size_t)k * P + p], ds);
+#pragma unroll
+        for (int e = 0; e < EL; ++e) {
+            dot = fmaf(f[e], q[e], dot);
+            nf = fmaf(f[e], f[e], nf);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dot += __shfl_xor(dot, o, 64);
+            nf += __shfl_xor(nf, o, 64);
+        }
+        const float nF = fmaxf(sqrtf(nf), COS_EPS);
+        const bool f_clamped = sqrtf(nf) < COS_EPS;
         const float dc = 0.5f * ds;
         const float inv = 1.0f / (nF * nP);
-        int slot = 0;
-        for (int dd = threadIdx.x; dd < D; dd += 256, ++slot) {
-            const float f = F[((size_t)n * P + p) * D + dd], q = protos[(size_t)p * D + dd];
+#pragma unroll
+        for (int e = 0; e < EL; ++e) {
+            const int dd = lane + 64 * e;
             // c = dot / (nF nP); a clamped norm is a constant
-            const float gf = q * inv - (f_clamped ? 0.0f : dot * f * inv / (nF * nF));
-            const float gq = f * inv - (p_clamped ? 0.0f : dot * q * inv / (nP * nP));
-            dF[((size_t)n * P + p) * D + dd] = dc * gf;
-            if (slot < 2) dq[slot] = fmaf(dc, gq, dq[slot]);
+            const float gf = q[e] * inv - (f_clamped ? 0.0f : dot * f[e] * inv / (nF * nF));
+            const float gq = f[e] * inv - (p_clamped ? 0.0f : dot * q[e] * inv / (nP * nP));
+            if (dd < D) dF[((size_t)n * P + p) * D + dd] = dc * gf;
+            dq[e] = fmaf(dc, gq, dq[e]);
         }
     }
-    int slot = 0;
-    for (int dd = threadIdx.x; dd < D; dd += 256, ++slot)
-        if (slot < 2) dprotos[(size_t)p * D + dd] = dq[slot];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) dqs[wave][lane + 64 * e] = dq[e];
+    __syncthreads();
+    for (int dd = threadIdx.x; dd < D; dd += 256) dprotos[(size_t)p * D + dd] = ((dqs[0][dd] + dqs[1][dd]) + dqs[2][dd]) + dqs[3][dd];
     for (int k = threadIdx.x; k < K; k += 256) {
         float a = 0.0f;
         for (int n = 0; n < N; ++n) a = fmaf(dlogits[(size_t)n * K + k], sim[(size_t)n * P + p], a);
@@ -168,7 +186,8 @@ __global__ __launch_bounds__(256) void xproto_pool_bwd_kernel(const T* __restric
 #pragma unroll
         for (int i = 0; i < PB_ROWS; ++i) acc[i] = 0.0f;
         if (dd < D) {
-            for (int p = 0; p < P; ++p) {
+#pragma unroll 10
+            for (int p = 0; p < P; ++p) {  // (unrolled: the loads of a batch of prototypes are in flight together)
                 const float f = dFn[(size_t)p * D + dd];
 #pragma unroll
                 for (int i = 0; i < PB_ROWS; ++i) acc[i] = fmaf(f, fabsf(rt[i * Pp + p]), acc[i]);
@@ -183,6 +202,7 @@ __global__ __launch_bounds__(256) void xproto_pool_bwd_kernel(const T* __restric
         float a = 0.0f;
         if (p < P && row < rows) {
             const float* f = dFn + (size_t)p * D;
+#pragma unroll 16
             for (int dd = 0; full && dd < D; ++dd) a = fmaf(f[dd], zt[row * D + dd], a);
             if (docc) a += docc[((size_t)n * P + p) * S + s0 + row];
             const float rv = rt[row * Pp + p];
