@@ -71,7 +71,7 @@ __device__ __forceinline__ void dwf_wait_all_but(int n) {  // n wave-uniform: ev
 // from memory is waited for by count (dwf_wait_all_but) just before.
 __device__ __forceinline__ void dwf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int RPT, bool ABLB = false>
+template <int RPT, bool ABLB = false, int ACT = -1>  // ACT: the epilogue activation compiled in (none / Swish: what X3D uses), -1 = the descriptor's
 __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ scale, const float* __restrict__ bias,
                                                                __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     const int Cp = d.Cout_p;
     const int c0 = (cq * 4 + wave) * 16;
     const bool wave_live = c0 < Cp;                  // wave-uniform: the last channel quad may be short (the wave still stages and syncs)
+    const bool wave_tail = c0 + 16 > d.Cout;         // wave-uniform: this tile holds channels beyond the real count (stored as zeros)
     const int npieces = min(8, (Cp - cq * 64) / 8);  // 16-byte pieces per position of this quad
 
     // ---- block-diagonal weight operands A[kt][pair]: lane (m, q) holds k = 8q .. 8q+7 = tap (q >> 1) of the pair, channels 8 (q & 1) ..;
@@ -276,8 +277,14 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 #pragma unroll
                             for (int i = 0; i < 4; ++i) psum[i] += ok ? v[i] : 0.0f;
                         }
-                        act_vec(v, d.act);
-                        if (d.Cout - ce < 4) mask_tail(v, d.Cout - ce);
+                        // (a run-time activation switch per tile is ~10 scalar branches x NT per frame on a kernel bound by instruction issue)
+                        if constexpr (ACT == PASN_ACT_SWISH) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = v[i] * sigmoidf_(v[i]);
+                        } else if constexpr (ACT != PASN_ACT_NONE) {
+                            act_vec(v, d.act);
+                        }
+                        if (wave_tail) mask_tail(v, d.Cout - ce);  // wave-uniform: only the tile that holds the padded channels pays the selects
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
@@ -409,9 +416,19 @@ int launch_dw_mfma(const void* x, const float* w, const float* scale, const floa
                    const DwMfmaGeom& g, hipStream_t s) {
     const dim3 grid(g.bpc * d.N), block(256);
     const size_t lds = (size_t)DWF_RING * g.NI * 1024 + 2 * dwf_obytes(g.RPT);
-    if (g.abl) hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
-    else if (g.RPT == 2) hipLaunchKernelGGL((dwconv3d_mfma_kernel<2, false>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
-    else hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, false>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+#define PASN_DWF(RPT_, ABL_, ACT_) \
+    hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
+    if (g.abl) PASN_DWF(1, true, -1);
+    else if (g.RPT == 2) {
+        if (d.act == PASN_ACT_NONE) PASN_DWF(2, false, PASN_ACT_NONE);
+        else if (d.act == PASN_ACT_SWISH) PASN_DWF(2, false, PASN_ACT_SWISH);
+        else PASN_DWF(2, false, -1);
+    } else {
+        if (d.act == PASN_ACT_NONE) PASN_DWF(1, false, PASN_ACT_NONE);
+        else if (d.act == PASN_ACT_SWISH) PASN_DWF(1, false, PASN_ACT_SWISH);
+        else PASN_DWF(1, false, -1);
+    }
+#undef PASN_DWF
     return check_launch("dwconv3d_mfma_kernel");
 }
 
