@@ -172,6 +172,7 @@ int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype);
  * bitwise equal).  counter: int32 [N], zero before the FIRST launch (the kernel leaves it zero).  Supported only where
  * pasn_dwconv3d_se_supported returns 1 (bf16 3x3x3 layers on the T-marching kernel). */
 int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse);
+int pasn_dwconv3d_se_pool_blocks(const pasn_conv_desc* d, int dtype); /* rows of pool_partial per clip for pasn_dwconv3d_se_fwd */
 int pasn_dwconv3d_se_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool_partial,
                          const pasn_conv_desc* d, int dtype, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                          const float* fc2_b, int Cse, float* gate, int32_t* counter, void* stream);

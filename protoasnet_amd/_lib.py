@@ -49,6 +49,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_variant": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "pasn_dwconv3d_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
+    "pasn_dwconv3d_se_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_variant": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_se_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "pasn_dwconv3d_se_fwd": (c_int, [c_void_p] * 6 + [POINTER(ConvDesc), c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),

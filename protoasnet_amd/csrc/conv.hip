@@ -862,6 +862,12 @@ extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype) {
     return dw_geom(*d).blocks;
 }
 
+// Partial rows written by pasn_dwconv3d_se_fwd (always the T-marching VALU stencil, whatever pasn_dwconv3d_fwd would take for the layer).
+extern "C" int pasn_dwconv3d_se_pool_blocks(const pasn_conv_desc* d, int dtype) {
+    if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    return dw_march_geom(*d, dtype).bpc;
+}
+
 extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                                  float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream) {
     PASN_REQUIRE(x && w && scale && bias && y, "null pointer");

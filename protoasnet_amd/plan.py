@@ -430,7 +430,7 @@ class PlanBuilder:
         b2 = fc2.bias.detach().float().contiguous()
         counter = torch.zeros(y.N, dtype=torch.int32, device=self.device)  # zero before the first launch; the kernel leaves it zero
         self.keep += [wp, scale, bias, w1, b1, w2, b2, counter]
-        pool_blocks = int(self.lib.pasn_dwconv3d_pool_blocks(ctypes.byref(d), self.code))
+        pool_blocks = int(self.lib.pasn_dwconv3d_se_pool_blocks(ctypes.byref(d), self.code))
         pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4)
         gate = self._new_buf(y.N * y.Cp * 4)
         fn, code = self.lib.pasn_dwconv3d_se_fwd, self.code
@@ -439,7 +439,9 @@ class PlanBuilder:
         self._use(xb, yb, pb_, gate)
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
-        self._note("dwconv+se", f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>",  # the same kernel instance as the plain stencil
+        # the T-marching VALU stencil's instance (the layer's plain launch may be routed elsewhere: then only the stride is known here)
+        kname = f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>" if 3000 <= dv < 40000 else f"dwconv3d_march_kernel<{s[2]},se>"
+        self._note("dwconv+se", kname,
                    (self._touched(x, y, k, s) + out_pos) * y.C * self.es + (y.N * pool_blocks * y.C * 8 + y.N * c * 4 + 2 * c * cse * 4),
                    2 * out_pos * y.C * taps + 4 * y.N * c * cse)
         self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], ptrs[pb_], dref, code, a[3], a[4], a[5], a[6],

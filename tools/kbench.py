@@ -48,7 +48,7 @@ def run(kind, a, b, T, H, W, N=32, dtype=torch.bfloat16, reps=20):
     else:
         conv = nn.Conv3d(cin, cin, 3, (1, b, b), 1, groups=cin, bias=False).to(DEV)
         bn = nn.BatchNorm3d(cin).to(DEV).eval()
-        y = pb.dwconv(xa, conv, bn, "none")
+        y = pb.dwconv(xa, conv, bn, os.environ.get("PASN_KB_ACT", "none"))  # PASN_KB_ACT=swish: the non-SE blocks' epilogue
         ra = None
     plan = pb.finish(xa, y)
     if ra is not None:
