@@ -1,4 +1,5 @@
-// Depthwise 3x3x3 stencil (stride 1, pad 1, bf16) on the MATRIX CORES -- the X3D conv_b of every stride-1 block, third generation.
+// Depthwise 3x3x3 stencil (stride 1, pad 1, bf16) on the MATRIX CORES -- third generation of the X3D conv_b stencil; default on the
+// planes up to 14 wide (X3D-S stages 4-5), where it also wins end to end (dw_mfma_geom; profiles/README entry 45).
 //
 // Why: both VALU generations (dwmarch.hip, dwmarch2.hip) are bound by vector-instruction issue, not by bytes: per output element 27
 // fp32 FMAs plus the bf16->fp32 conversions, padding selects and accumulator moves around them (FMAs are ~1/3 of the issued
@@ -14,14 +15,18 @@
 // 1/16 of every MFMA is useful work, which is still 27 useful MACs per 16 x 16 outputs per 15 MFMAs x 16 cycles -- what the packed fp32
 // FMAs alone would take if nothing else had to be issued -- and the vector unit is left to the epilogue (scale, bias, Swish, SE partial
 // sums, bf16 stores).  As in dwmarch.hip a wave MARCHES ALONG T with three accumulator sets per position tile (outputs t-1, t, t+1):
-// every operand read feeds the three kt taps.
+// every operand read feeds the three kt taps.  The sets have FIXED registers per role and the rotation is done by the MFMAs themselves
+// (the first MFMA of a chain reads the previous role's set as C and writes its own): no register moves, 239 VGPRs with 7 tiles per wave.
+// The kernel is bound by vector-instruction ISSUE next to the MFMAs (per frame and wave ~180 VALU + ~180 SALU around 105 MFMAs), not by
+// MFMA time: what is compiled in (activation), hoisted (pad masking per wave) or counted (vmcnt) below is there for that reason.
 //
 // Operand supply.  A first version read the B operands straight from global memory (16 positions x 2 x 32-byte pieces per
 // wave-instruction): 30 % SLOWER than the VALU kernel, bound by L1 tag lookups (~44 cycles per wave-load, ring depth irrelevant).  Here a
 // block owns BH x BW outputs (7 x 14) of one 64-channel quad and stages the (BH+2) x (BW+2) input region of every frame by LDS-DMA
-// (whole 128-byte position rows; cells outside the image are zeroed once per unit and never fetched) into a 2-frame ring; B operands are ds_read_b128 from a
-// position stride of 160 bytes (10 slots: conflict-free for the read's four 16-lane groups, see the bank rule in the guide).  One
-// barrier per frame; a wave's DMA for frame t+2 is issued right after it, under the 60 MFMAs of frame t.
+// (whole 128-byte position rows; cells outside the image are zeroed once per unit and never fetched) into a 2-frame ring; B operands are
+// ds_read_b128 from a position stride of 160 bytes (10 slots: conflict-free for the read's four 16-lane groups, see the bank rule in
+// the guide).  One fence-free barrier per frame; a wave's DMA for frame t+1 is issued right after it, under the 105 MFMAs of frame t;
+// outputs go through a two-frame LDS image so that the block stores whole 128-byte channel rows.
 //
 // Weights are rounded to bf16 here (round-to-nearest-even), like the weights of every other bf16 conv of the path; accumulation is
 // fp32.  A zero weight times a non-finite activation of ANOTHER channel of the tile would leak (0 x inf); the trunk's activations are
