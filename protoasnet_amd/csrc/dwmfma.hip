@@ -25,8 +25,7 @@
 // block owns BH x BW outputs (7 x 14) of one 64-channel quad and stages the (BH+2) x (BW+2) input region of every frame by LDS-DMA
 // (whole 128-byte position rows; cells outside the image are zeroed once per unit and never fetched) into a 2-frame ring; B operands are
 // ds_read_b128 from a position stride of 160 bytes (10 slots: conflict-free for the read's four 16-lane groups, see the bank rule in
-// the guide).  One fence-free barrier per frame; a wave's DMA for frame t+1 is issued right after it, under the 105 MFMAs of frame t;
-// outputs go through a two-frame LDS image so that the block stores whole 128-byte channel rows.
+// the guide).  One fence-free barrier per frame; a wave's DMA for frame t+1 is issued right after it, under the 105 MFMAs of frame t.
 //
 // Weights are rounded to bf16 here (round-to-nearest-even), like the weights of every other bf16 conv of the path; accumulation is
 // fp32.  A zero weight times a non-finite activation of ANOTHER channel of the tile would leak (0 x inf); the trunk's activations are
@@ -43,11 +42,9 @@ typedef const __attribute__((address_space(1))) void* dwm_gbl_ptr_t;
 constexpr int DWF_SLOTS = 10;   // 16-byte slots per staged position (8 used)
 constexpr int DWF_NTL = 7;      // position tiles per wave (7 x 14 outputs: the X3D planes are 56 / 28 / 14 / 7 high)
 constexpr int DWF_NE = 7;       // DMA instructions per wave and frame (<= 28 per block)
-constexpr int DWF_RING = 2;      // frame images in LDS: frame t + 1 is requested right after the barrier of frame t (a step is ~2 us)
+constexpr int DWF_RING = 2;      // frame images in LDS: frame t + RING - 1 is requested right after the barrier of frame t (3: measured 4-5 % slower)
 constexpr int DWF_PITCH = 16;   // staged positions per region row
 constexpr int dwf_tiles(int rpt) { return rpt == 2 ? 4 : DWF_NTL; }  // two-row tiles (planes <= 8 wide): 4 x 2 rows, the LDS image stays <= 25 KB
-constexpr int DWF_OPITCH = 136; // bytes per position of the output image (128 used)
-constexpr int dwf_obytes(int rpt) { return dwf_tiles(rpt) * 16 * DWF_OPITCH; }  // one output image (two-row instance: 4 tiles -- 69 KB per block, two blocks per CU)
 
 __device__ __forceinline__ unsigned bf16_bits_rne(float f) {
     const __bf16 b = (__bf16)f;
@@ -67,7 +64,17 @@ __device__ __forceinline__ void dwf_wait_all_but(int n) {  // n wave-uniform: ev
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;  // n <= DWF_NE + DWF_NTL = 11
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;  // n <= (DWF_RING - 1) * DWF_NTL + (DWF_RING - 2) * DWF_NE = 21
     }
 }
 
@@ -137,7 +144,6 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     // immediates: as run-time scalars they cost ~90 spilled SGPRs, reloaded lane by lane at every frame)
     constexpr int NI = ((NT * RPT + 2) * DWF_PITCH * DWF_SLOTS + 63) / 64;
     constexpr int fbytes = NI * 1024;
-    char* otile = ring + DWF_RING * fbytes;  // [2][NTL x 16 positions][136]: output images of two consecutive frames
     // tap offsets of this lane inside the staged region (pair j -> tap 2j + (q >> 1); the absent 10th tap reads the 9th's cell: its
     // weights are zero)
     int tapoff[5];
@@ -201,18 +207,15 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         const int ystep = RPT * d.Wo * Cp;
         __bf16* yclip = y + (long)n * d.To * d.Ho * d.Wo * Cp;
         const long ofs = (long)d.Ho * d.Wo * Cp;
-        const int fl_m = threadIdx.x >> 4, fl_row = fl_m / g.BW, fl_col = fl_m - fl_row * g.BW;
-        const bool fl_ok = fl_m < RPT * g.BW && w0 + fl_col < d.Wo && (int)(threadIdx.x & 15) < 2 * npieces;
-        const int fl_lim = fl_ok ? fl_row : (1 << 20);
         // tiles of which this WAVE stores anything (wave-uniform): exactly those store instructions are issued, so that the wave can count
         // them (vmcnt retires in issue order: the wait for a frame's DMA group must name every younger DMA AND store, or it waits for the
         // stores of the previous frame to be acknowledged -- ~1.5 us per frame, the whole step serialised)
-        unsigned fmask = 0;
+        unsigned dmask = 0;
 #pragma unroll
         for (int l = 0; l < NT; ++l)
-            if (__builtin_amdgcn_ballot_w64(l * RPT + fl_lim < rows_valid) != 0) fmask |= 1u << l;
-        const int kst = __builtin_popcount(fmask);
-        const int fl_off = ((h0 + fl_row) * d.Wo + w0 + fl_col) * Cp + cq * 64 + (threadIdx.x & 15) * 4;
+            if (__builtin_amdgcn_ballot_w64(l * RPT + mrow_lim < rows_valid) != 0) dmask |= 1u << l;
+        const int yoff0 = ((h0 + mrow) * d.Wo + w0 + mcol) * Cp + ce;
+        const int kst = wave_live ? __builtin_popcount(dmask) : 0;
 
         f32x4 S0[NT], S1[NT], S2[NT];
         const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -266,9 +269,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             }
             const int to = ti - 1;  // has now seen frames ti-2, ti-1, ti
             if (wave_live && to >= t0 && to < t1 && !(abl & 4)) {
-                // into the output image of frame `to` (LDS, position pitch 136 bytes: conflict-free 8-byte writes); the block stores it as
-                // whole channel rows after the next barrier (a wave owns 32 bytes of every position: 16 partial lines per wave-store before)
-                char* ob = otile + (to & 1) * dwf_obytes(RPT) + m * DWF_OPITCH + wave * 32 + q * 8;
+                // straight to memory: a wave owns 32 bytes (16 channels) of each of its 16 positions per store.  (Routing the outputs through
+                // an LDS image so that the block stores whole 128-byte rows was measured 2-4 % SLOWER once the stores were counted in
+                // the vmcnt wait: 7 ds_write + 7 ds_read + the second pass cost more than the partial lines.)
                 int mr = mrow_lim;
                 asm volatile("" : "+v"(mr));
 #pragma unroll
@@ -293,42 +296,32 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-                        *reinterpret_cast<bf16x4*>(ob + l * 16 * DWF_OPITCH) = o;
+                        if ((dmask >> l) & 1u)  // wave-uniform: exactly these stores are issued and counted
+                            if (ok) *reinterpret_cast<bf16x4*>(yclip + (long)to * ofs + yoff0 + l * ystep) = o;
                     }
             }
-        };
-        // store output frame `to` from its LDS image: thread -> (position lane tid >> 4, 8-byte piece tid & 15) of every tile
-        auto flush = [&](int to) {
-            if (to < t0 || to >= t1 || (abl & 4)) return;
-            __bf16* yf = yclip + (long)to * ofs;
-            const char* ob = otile + (to & 1) * dwf_obytes(RPT) + (threadIdx.x >> 4) * DWF_OPITCH + (threadIdx.x & 15) * 8;
-            int fr = fl_lim;
-            asm volatile("" : "+v"(fr));
-            bf16x4 ov[NT];
-#pragma unroll
-            for (int l = 0; l < NT; ++l) ov[l] = *reinterpret_cast<const bf16x4*>(ob + l * 16 * DWF_OPITCH);  // all reads, then the stores
-#pragma unroll
-            for (int l = 0; l < NT; ++l)
-                if ((fmask >> l) & 1u)  // wave-uniform
-                    if (l * RPT + fr < rows_valid) *reinterpret_cast<bf16x4*>(yf + fl_off + l * ystep) = ov[l];
         };
         // one pipeline step: this wave's pieces of frame ti have landed (everything it issued since is the group of frame ti+1), then
         // everyone's have and nobody still reads the slot of frame ti-1, which takes frame ti+2
         auto step = [&](int ti, int slot, f32x4 (&P)[NT], f32x4 (&C)[NT], f32x4 (&N)[NT]) {
+            constexpr int LA = DWF_RING - 1;  // frames of look-ahead: group(ti) was issued in step ti - LA, right after that step's barrier
             if (!(abl & 8)) {
-                // younger than the group of frame ti (issued in step ti-1 right after its barrier): the stores of output ti-3
-                const bool st3 = ti - 3 >= t0 && ti - 3 < t1 && !(abl & 4);
-                dwf_wait_all_but(st3 ? kst : 0);
+                // younger than the group of frame ti: that step's stores (output ti-LA-1), then per later step its group and its stores
+                auto stored = [&](int to) -> int { return (to >= t0 && to < t1 && !(abl & 4)) ? kst : 0; };
+                int younger = stored(ti - LA - 1);
+#pragma unroll
+                for (int j = 1; j < LA; ++j) younger += (staged(ti + j) && !(abl & 2) ? kdma : 0) + stored(ti - LA - 1 + j);
+                dwf_wait_all_but(younger);
                 dwf_barrier();
             }
-            issue(ti + 1, slot ^ 1);  // the other image was last read in step ti-1: everyone is past that now
-            flush(ti - 2);            // written by frame ti-1 before this barrier; its image is rewritten by frame ti+1, after the next one
+            issue(ti + LA, slot + LA >= DWF_RING ? slot + LA - DWF_RING : slot + LA);  // that image was last read in step ti-1: everyone is past it
             frame(ti, slot, P, C, N);
         };
 
         for (int o = threadIdx.x * 16; o < ((abl & 32) ? 0 : DWF_RING * fbytes); o += 256 * 16) *reinterpret_cast<dwm_u32x4*>(ring + o) = dwm_u32x4{0u, 0u, 0u, 0u};
         __syncthreads();  // zeros written (lgkmcnt drained) before any piece may land on them
-        issue(t0 - 1, 0);
+#pragma unroll
+        for (int j = 0; j < DWF_RING - 1; ++j) issue(t0 - 1 + j, j);
         // ONE step per iteration with FIXED role registers (S0 = P, S1 = C, S2 = N; the rotation is done by the MFMAs, see frame()).
         // Unrolling by three with the sets passed by name costs 70-250 VGPRs per extra copy of the step with this compiler (7 tiles: 156
         // VGPRs rolled, 225 with two copies, 256 + 225 spilled with three), which is what limited the kernel to 4 tiles per wave.
@@ -336,10 +329,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 #pragma unroll 1
         for (int ti = t0 - 1; ti <= ((abl & 64) ? t0 - 2 : t1); ++ti) {
             step(ti, slot, S0, S1, S2);
-            slot ^= 1;
+            slot = slot + 1 == DWF_RING ? 0 : slot + 1;
         }
-        __syncthreads();  // the last output image is complete; nobody reads the ring any more
-        flush(t1 - 1);
+        __syncthreads();  // nobody reads the ring any more (the next unit zeroes it)
     }
 
     if (pool && wave_live) {
@@ -420,7 +412,7 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
                    const DwMfmaGeom& g, hipStream_t s) {
     const dim3 grid(g.bpc * d.N), block(256);
-    const size_t lds = (size_t)DWF_RING * g.NI * 1024 + 2 * dwf_obytes(g.RPT);
+    const size_t lds = (size_t)DWF_RING * g.NI * 1024;
 #define PASN_DWF(RPT_, ABL_, ACT_) \
     hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
     if (g.abl) PASN_DWF(1, true, -1);
