@@ -893,7 +893,7 @@ extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, in
     if (const char* e = getenv("PASN_NO_SE_FUSE"))
         if (e[0] == '1') return 0;
     if (dw_march2_geom(*d, dtype).WT) return 0;  // the opt-in second-generation kernel has no fused gate
-    // (the matrix-core stencil has no fused gate either: where the fusion pays -- up to 128 channels -- the VALU stencil keeps the layer)
+    if (dw_mfma_geom(*d, dtype).ok) return 0;    // the matrix-core stencil + the stand-alone gate beat the fused VALU launch (8669 vs 8623 clips/s)
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     // The last block of a clip computes the gate alone, at the END of the launch: atomic + acquire, the partial rows (agent-scope loads:
     // memory-side round trips), two FCs -- an exposed tail of 5-30 us that grows with the channel count (432 channels: +29 us per launch,

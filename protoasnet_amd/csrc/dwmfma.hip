@@ -1,5 +1,5 @@
-// Depthwise 3x3x3 stencil (stride 1, pad 1, bf16) on the MATRIX CORES -- third generation of the X3D conv_b stencil; default on the
-// planes up to 14 wide (X3D-S stages 4-5), where it also wins end to end (dw_mfma_geom; profiles/README entry 45).
+// Depthwise 3x3x3 stencil (stride 1, pad 1, bf16) on the MATRIX CORES -- third generation of the X3D conv_b stencil, the default for
+// every stride-1 layer that does not ride the fused SE-gate launch (dw_mfma_geom; profiles/README entry 45).
 //
 // Why: both VALU generations (dwmarch.hip, dwmarch2.hip) are bound by vector-instruction issue, not by bytes: per output element 27
 // fp32 FMAs plus the bf16->fp32 conversions, padding selects and accumulator moves around them (FMAs are ~1/3 of the issued
@@ -356,12 +356,13 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     DwMfmaGeom g = {};
     if (dtype != PASN_BF16) return g;
-    // Default: the planes at most 14 wide (the 14 x 14 and 7 x 7 stages: 38.6 vs 41.1 and 27.6 vs 34.9 us per launch; end to end, three
-    // alternating runs each: none 8080 clips/s, <= 8 wide 8200, <= 14 wide 8365, <= 28 wide 8180, all 8190 -- profiles/README entry 45).
-    // PASN_DWMFMA=1: every stride-1 layer, =0: none, PASN_DWMFMA_MAXW: the width limit.
+    // Default: every stride-1 layer (per launch, with / without the Swish epilogue: 118 vs 150 / 141 vs 170 us at 56 x 56, 57 vs 70 /
+    // 68 vs 79 at 28 x 28, 35 vs 41 / 40 vs 44 at 14 x 14, 25 vs 35 / 27 vs 37 at 7 x 7; end to end, three alternating runs each
+    // without event bracketing: planes <= 14 wide 8582 clips/s, <= 28 wide 8611, all 8633 -- profiles/README entry 45).
+    // PASN_DWMFMA=0: none; PASN_DWMFMA_MAXW: only planes up to this width.
     const char* on = getenv("PASN_DWMFMA");
     if (on && on[0] == '0') return g;
-    const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : ((on && on[0] == '1') ? (1 << 30) : 14);
+    const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : (1 << 30);
     if (d.Wo > maxw) return g;
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
                        d.pw == 1 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0;
