@@ -554,7 +554,7 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     x, conv, bn, pre = _march_case(1, c, thw=thw)
     ref = pre * torch.sigmoid(pre)
     out, part, kernel = _run_march(x, conv, bn, "swish")
-    assert kernel == "dwconv3d_mfma_kernel", kernel
+    assert kernel.startswith("dwconv3d_mfma_kernel<"), kernel
     atol, rtol = _tols(torch.bfloat16)
     assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"mfma stencil {thw} {geom} c{c}")
     want = pre.sum(dim=(2, 3, 4))
