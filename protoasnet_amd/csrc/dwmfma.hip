@@ -36,6 +36,7 @@
 namespace pasn {
 
 typedef __attribute__((ext_vector_type(4))) unsigned dwm_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned dwm_u32x2;
 typedef __attribute__((address_space(3))) void* dwm_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* dwm_gbl_ptr_t;
 
@@ -137,6 +138,10 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     const long fstride = (long)Hi * Wi * Cp;  // elements per frame
     const __bf16* xclip = x + (long)n * Ti * fstride + cq * 64;
+    const unsigned fr_in_bytes = (unsigned)(fstride * 2);
+    // this clip from the quad's first channel on; the last bytes of the clip's last row belong to the quad's own channels or lie beyond
+    // num_records (channels of LATER quads sit below offset fr_in_bytes * Ti - cq * 128: reading them as "padding slots" is harmless)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(xclip), 0, (unsigned)Ti * fr_in_bytes - (unsigned)(cq * 128), 0x00020000);
     constexpr int NT = dwf_tiles(RPT);  // position tiles per wave
     const int abl = ABLB ? g.abl : 0;   // timing ablations: a separate instance, the product kernel carries none of the checks
     constexpr int RW = DWF_PITCH;  // staged positions per region row (BW + 2 <= 16 used)
@@ -163,10 +168,11 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         const int t0 = tch * g.Tc, t1 = min(t0 + g.Tc, d.To);
         const int h0 = rth * g.BH, w0 = rtw * g.BW;
         // ---- DMA roles: instruction i = wave + 4e covers ring slots 64 i .. 64 i + 63; this lane's slot -> (region position, piece).
-        // Pieces outside the image are NOT fetched: their cells were zeroed below and stay zero for the whole unit (same lanes every frame).
-        // The source is a wave-uniform frame base + this 32-bit byte offset: no per-frame pointer arithmetic in the vector unit.
-        unsigned goff[DWF_NE];  // byte offset inside a frame (this quad), ~0 = not fetched
-        unsigned emask = 0;     // instructions with any fetching lane (wave-uniform): exactly those are issued and counted
+        // Buffer addressing (descriptor = this clip's quad of channels, all frames): the source is a wave-uniform frame offset (SGPR) + this
+        // lane's 32-bit offset; pieces outside the image carry an out-of-range offset and are dropped by the hardware -- their cells were
+        // zeroed below and stay zero for the whole unit.  No predicate, exec juggling or pointer arithmetic per instruction, and every
+        // instruction is issued: the wave counts them.
+        unsigned goff[DWF_NE];  // byte offset inside a frame (this quad), 2^31 = not fetched
 #pragma unroll
         for (int e = 0; e < DWF_NE; ++e) {
             const int slot = (wave + 4 * e) * 64 + lane;
@@ -174,26 +180,18 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             const int rr = rp / RW, cc = rp - rr * RW;
             const int hi = h0 - 1 + rr, wi = w0 - 1 + cc;
             const bool ok = !(abl & 16) && wave + 4 * e < NI && rp < g.RP && cc < g.BW + 2 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
-            goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cp + c * 8) * 2) : ~0u;
-            if (__builtin_amdgcn_ballot_w64(ok) != 0) emask |= 1u << e;
+            goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cp + c * 8) * 2) : 0x80000000u;
         }
-        const int kdma = __builtin_popcount(emask);  // DMA instructions of this wave per frame
+        const int kdma = max(0, (NI - wave + 3) >> 2);  // DMA instructions of this wave per frame (i = wave + 4e < NI)
         auto staged = [&](int ti) -> bool { return ti >= 0 && ti < Ti && ti >= t0 - 1 && ti <= t1; };
         auto issue = [&](int ti, int slot) {
             if (!staged(ti) || (abl & 2)) return;
-            const char* xf = reinterpret_cast<const char*>(xclip + (long)ti * fstride);
+            const unsigned foff = (unsigned)ti * fr_in_bytes;  // wave-uniform
             char* dst = ring + slot * fbytes;
 #pragma unroll
-            for (int e = 0; e < DWF_NE; ++e) {
-                if ((emask >> e) & 1u) {    // wave-uniform
-                    // (the lane predicates of this kernel are recomputed where they are used -- one v_cmp -- behind an opaque copy: hoisted
-                    // out of the frame loop they are ~25 SGPR pairs, spilled and reloaded lane by lane at every frame)
-                    unsigned gv = goff[e];
-                    asm volatile("" : "+v"(gv));
-                    if (gv != ~0u)          // per lane: the others keep the cell's zero
-                        __builtin_amdgcn_global_load_lds((dwm_gbl_ptr_t)(xf + gv), (dwm_lds_ptr_t)(dst + (wave + 4 * e) * 1024), 16, 0, 0);
-                }
-            }
+            for (int e = 0; e < DWF_NE; ++e)
+                if (wave + 4 * e < NI)  // wave-uniform
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (dwm_lds_ptr_t)(dst + (wave + 4 * e) * 1024), 16, (int)goff[e], (int)foff, 0, 0);
         };
         // ---- fragment roles: position tile l holds RPT whole output rows of the region (rows l RPT ..), lane m -> (row m / BW, column
         // m % BW): every per-tile address is the tile-0 address plus a wave-uniform multiple of l
@@ -207,15 +205,14 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         const int ystep = RPT * d.Wo * Cp;
         __bf16* yclip = y + (long)n * d.To * d.Ho * d.Wo * Cp;
         const long ofs = (long)d.Ho * d.Wo * Cp;
-        // tiles of which this WAVE stores anything (wave-uniform): exactly those store instructions are issued, so that the wave can count
-        // them (vmcnt retires in issue order: the wait for a frame's DMA group must name every younger DMA AND store, or it waits for the
-        // stores of the previous frame to be acknowledged -- ~1.5 us per frame, the whole step serialised)
-        unsigned dmask = 0;
-#pragma unroll
-        for (int l = 0; l < NT; ++l)
-            if (__builtin_amdgcn_ballot_w64(l * RPT + mrow_lim < rows_valid) != 0) dmask |= 1u << l;
-        const int yoff0 = ((h0 + mrow) * d.Wo + w0 + mcol) * Cp + ce;
-        const int kst = wave_live ? __builtin_popcount(dmask) : 0;
+        // Output stores go through a per-frame buffer descriptor (num_records = one output frame): rows below the plane fall out of range
+        // and are dropped by the hardware, lanes that hold no output position carry an out-of-range offset -- no per-tile predicate, exec
+        // juggling or 64-bit address arithmetic in the epilogue, and every tile's store is ISSUED, so the wave can count them: vmcnt retires
+        // in issue order, the wait for a frame's DMA group must name every younger DMA and store (otherwise it waits for the previous
+        // frame's stores to be acknowledged: ~1.5 us per frame, the whole step serialised)
+        const unsigned yvoff = lane_ok ? (unsigned)((((h0 + mrow) * d.Wo + w0 + mcol) * Cp + ce) * 2) : 0x80000000u;
+        const unsigned fr_bytes = (unsigned)(ofs * 2);
+        const int kst = wave_live ? ntl : 0;
 
         f32x4 S0[NT], S1[NT], S2[NT];
         const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -274,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                 // the vmcnt wait: 7 ds_write + 7 ds_read + the second pass cost more than the partial lines.)
                 int mr = mrow_lim;
                 asm volatile("" : "+v"(mr));
+                const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yclip + (long)to * ofs, 0, fr_bytes, 0x00020000);
 #pragma unroll
                 for (int l = 0; l < NT; ++l)
                     if (l < ntl) {  // wave-uniform
@@ -296,8 +294,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-                        if ((dmask >> l) & 1u)  // wave-uniform: exactly these stores are issued and counted
-                            if (ok) *reinterpret_cast<bf16x4*>(yclip + (long)to * ofs + yoff0 + l * ystep) = o;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dwm_u32x2, o), yrsrc, (int)yvoff, l * ystep * 2, 0);
                     }
             }
         };
