@@ -23,7 +23,7 @@
 // Operand supply.  A first version read the B operands straight from global memory (16 positions x 2 x 32-byte pieces per
 // wave-instruction): 30 % SLOWER than the VALU kernel, bound by L1 tag lookups (~44 cycles per wave-load, ring depth irrelevant).  Here a
 // block owns BH x BW outputs (7 x 14) of one 64-channel quad and stages the (BH+2) x (BW+2) input region of every frame by LDS-DMA
-// (whole 128-byte position rows; cells outside the image are zeroed once per unit and never fetched) into a 2-frame ring; B operands are
+// (whole 128-byte position rows through a buffer descriptor; cells outside the image are out-of-range lanes: zero-filled by the hardware) into a 2-frame ring; B operands are
 // ds_read_b128 from a position stride of 160 bytes (10 slots: conflict-free for the read's four 16-lane groups, see the bank rule in
 // the guide).  One fence-free barrier per frame; a wave's DMA for frame t+1 is issued right after it, under the 105 MFMAs of frame t.
 //
@@ -169,8 +169,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         const int h0 = rth * g.BH, w0 = rtw * g.BW;
         // ---- DMA roles: instruction i = wave + 4e covers ring slots 64 i .. 64 i + 63; this lane's slot -> (region position, piece).
         // Buffer addressing (descriptor = this clip's quad of channels, all frames): the source is a wave-uniform frame offset (SGPR) + this
-        // lane's 32-bit offset; pieces outside the image carry an out-of-range offset and are dropped by the hardware -- their cells were
-        // zeroed below and stay zero for the whole unit.  No predicate, exec juggling or pointer arithmetic per instruction, and every
+        // lane's 32-bit offset; pieces outside the image carry an out-of-range offset: the hardware fetches nothing and writes ZEROS to their cells.  No predicate, exec juggling or pointer arithmetic per instruction, and every
         // instruction is issued: the wave counts them.
         unsigned goff[DWF_NE];  // byte offset inside a frame (this quad), 2^31 = not fetched
 #pragma unroll
@@ -315,8 +314,8 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             frame(ti, slot, P, C, N);
         };
 
-        for (int o = threadIdx.x * 16; o < ((abl & 32) ? 0 : DWF_RING * fbytes); o += 256 * 16) *reinterpret_cast<dwm_u32x4*>(ring + o) = dwm_u32x4{0u, 0u, 0u, 0u};
-        __syncthreads();  // zeros written (lgkmcnt drained) before any piece may land on them
+        // (no zeroing of the images: out-of-range lanes of `buffer_load ... lds` WRITE ZEROS to their cells -- every cell of a frame image,
+        // padding slots included, is rewritten by every frame's DMA; verified by the ragged-shape tests, which fail on stale border cells)
 #pragma unroll
         for (int j = 0; j < DWF_RING - 1; ++j) issue(t0 - 1 + j, j);
         // ONE step per iteration with FIXED role registers (S0 = P, S1 = C, S2 = N; the rotation is done by the MFMAs, see frame()).
