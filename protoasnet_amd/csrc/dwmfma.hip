@@ -363,7 +363,7 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
                        d.pw == 1 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0;
     if (!shape) return g;
-    if ((long)d.Hi * d.Wi * d.Cin_p >= (1L << 30)) return g;  // 32-bit element offsets inside a frame
+    if ((long)d.Ti * d.Hi * d.Wi * d.Cin_p * 2 >= (1L << 31)) return g;  // one clip per buffer descriptor, 2^31 marks "outside"
     g.CT = ceil_div(d.Cout_p, 16);
     g.CQ = ceil_div(g.CT, 4);
     // region = 7 rows x 14 columns of outputs (the X3D planes are 56 / 28 / 14 / 7 wide and high: no ragged regions); a 16-lane position
