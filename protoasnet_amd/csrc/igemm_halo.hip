@@ -26,7 +26,6 @@ namespace pasn {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-__device__ __attribute__((aligned(256))) unsigned int halo_zero_page[64];  // zero-initialised: the source of every masked piece
 
 constexpr int HG_MAX = 8;  // 16-row DMA groups of the halo tile per wave (tile <= 512 rows)
 
@@ -99,7 +98,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
         woff[i] = n < d.w_rows ? n * Ktot + q * 8 : -1;
         wdst[i] = g < WGROUPS ? g * 1024 : -1;  // -1: this wave has no i-th group
     }
-    const __bf16* zero = reinterpret_cast<const __bf16*>(halo_zero_page);
+    // descriptors over the whole activation / weight tensors (the host guarantees both below 2^31 elements: 32-bit byte offsets)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, (unsigned)min((long)M * Cin_p * 2, 0xffffffe0L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w), 0, (unsigned)min((long)d.w_rows * taps * kc * 2, 0xffffffe0L), 0x00020000);
 
     auto issue_a = [&](int cs, int i) -> int {  // this wave's i-th halo group of slice cs into stage cs & 1; returns the DMAs issued
         char* xb = smem + (cs & 1) * XBYTES;
@@ -108,8 +109,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
         if (g >= ngroups) return 0;
         const int off = src_off(g);
         const bool ok = ci < Cin_p && off >= 0;
-        const __bf16* src = ok ? x + (off + ci) : zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xb + g * 1024), 16, 0, 0);
+        // buffer addressing: a masked piece carries an out-of-range offset, the hardware then writes ZEROS to its LDS cell (no zero page, no
+        // 64-bit pointer select per piece)
+        const unsigned vo = ok ? (unsigned)(off + ci) * 2u : 0xfffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xb + g * 1024), 16, (int)vo, 0, 0, 0);
         return 1;
     };
     auto issue_w = [&](int cs, int tap, int stage) -> int {  // weight tile of step (cs, tap)
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
         for (int i = 0; i < WD; ++i) {
             if (wdst[i] >= 0) {  // wave-uniform
                 const bool ok = kok && woff[i] >= 0;
-                const __bf16* src = ok ? w + (woff[i] + koff) : zero;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wb + wdst[i]), 16, 0, 0);
+                const unsigned vo = ok ? (unsigned)(woff[i] + koff) * 2u : 0xfffffff0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(wb + wdst[i]), 16, (int)vo, 0, 0, 0);
                 ++n;
             }
         }
