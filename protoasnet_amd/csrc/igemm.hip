@@ -25,7 +25,6 @@ namespace pasn {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-__device__ __attribute__((aligned(256))) unsigned int igemm_zero_page[64];  // zero-initialised: the source of every masked piece
 
 constexpr int IG_BK = 32;
 
@@ -97,7 +96,11 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
         f_db = r2 / d.kw;
         f_de = r2 - f_db * d.kw;
     }
-    const __bf16* zero = reinterpret_cast<const __bf16*>(igemm_zero_page);
+    // descriptors over the whole activation / weight tensors (igemm_nt guarantees both below 2^31 elements: 32-bit byte offsets)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(x), 0, (unsigned)min((long)d.N * d.Ti * d.Hi * d.Wi * Cin_p * 2, 0xffffffe0L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w), 0, (unsigned)min((long)d.w_rows * Ktot * 2, 0xffffffe0L), 0x00020000);
 
     auto issue = [&](int kt, int buf) {  // called with kt = 0, 1, 2, ... in order
         char* xb = smem + buf * STAGE;
@@ -108,15 +111,16 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
 #pragma unroll
         for (int i = 0; i < XG; ++i) {
             const bool ok = kvalid && ((tapmask[i] >> (f_tap & 31)) & 1u);
-            const __bf16* src = ok ? x + (xoff[i] + tapoff) : zero;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xb + (wave * XG + i) * 1024), 16, 0, 0);
+            // buffer addressing: a masked piece carries an out-of-range offset and the hardware zero-fills its LDS cell
+            const unsigned vo = ok ? (unsigned)(xoff[i] + tapoff) * 2u : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xb + (wave * XG + i) * 1024), 16, (int)vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (wave + 4 * i < WGROUPS) {  // wave-uniform
                 const bool ok = wrow_ok[i] && k < Ktot;
-                const __bf16* src = ok ? w + (woff[i] + k) : zero;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wb + (wave + 4 * i) * 1024), 16, 0, 0);
+                const unsigned vo = ok ? (unsigned)(woff[i] + k) * 2u : 0xfffffff0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(wb + (wave + 4 * i) * 1024), 16, (int)vo, 0, 0, 0);
             }
         }
         f_ci += IG_BK;  // advance (tap, ci) by one slice
