@@ -109,8 +109,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
         if (tile + stride < ntiles) load_rows(tile + stride, Bn);  // next tile's rows: in flight during everything below
         // this tile's residual rows, requested before the MFMAs that hide them
         // raw (unconverted), unconditional, clamped: see load_rows.  Compile-time RES: expand convs pay no registers.
-        typename RawQuad<T>::type rq[RES ? NT : 1][4];
-        if (RES) {
+        // bf16: the tile's 32 residual rows are ONE contiguous range, like the output: whole 16-byte pieces, lane-contiguous (the quad
+        // loads below are 8 bytes per lane at the row stride: 32 partial lines per wave-load, what held the residual instances at
+        // 3.2-4.3 TB/s); added in the copy-out loop on the rounded pre-activation sums, as igemm_epilogue does
+        constexpr bool RCOPY = RES && sizeof(T) == 2;
+        constexpr int RPL = 2 * NT;  // 16-byte pieces per lane: 32 rows x NT*32 channels / 8 / 64
+        uint4 rp[RCOPY ? RPL : 1];
+        if (RCOPY) {
+            const long base = tile * 32 * (long)Cout_p, lim = M * (long)Cout_p;
+            const int pieces = 32 * Cout_p / 8;
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const int q = lane + 64 * u;
+                const bool ok = q < pieces && base + (long)q * 8 < lim;
+                rp[u] = *reinterpret_cast<const uint4*>(res + (ok ? base + (long)q * 8 : 0));
+            }
+        }
+        typename RawQuad<T>::type rq[(RES && !RCOPY) ? NT : 1][4];
+        if (RES && !RCOPY) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -172,15 +188,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
                 load4(sbl + NT * 32 + col, bs);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = acc[nt][4 * g + j] * sc[j] + bs[j];
-                if (RES) {
+                if (RES && !RCOPY) {
                     float r4[4];
                     RawQuad<T>::to_f4(rq[nt][g], r4);
                     const bool ok = mv && co_base + col < Cout_p;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] += ok ? r4[j] : 0.0f;
                 }
-                act_vec(o, act);
-                mask_tail(o, Cout - col);
+                if (!RCOPY) {
+                    act_vec(o, act);
+                    mask_tail(o, Cout - col);
+                }
                 store4(st + (size_t)c * Cout_p + col, o);
             }
         __builtin_amdgcn_wave_barrier();
@@ -189,9 +207,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
             const long base = tile * 32 * (long)Cout_p;           // first element of the tile in y
             const long lim = M * (long)Cout_p;                    // rows beyond M do not exist
             const int pieces = 32 * Cout_p / CPL;
-            for (int q = lane; q < pieces; q += 64) {
-                if (base + (long)q * CPL < lim)
-                    *reinterpret_cast<uint4*>(y + base + (long)q * CPL) = *reinterpret_cast<const uint4*>(st + (size_t)q * CPL);
+            if (RCOPY) {
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) {
+                    const int q = lane + 64 * u;
+                    if (q < pieces && base + (long)q * CPL < lim) {
+                        uint4 iv[1] = {*reinterpret_cast<const uint4*>(st + (size_t)q * CPL)}, rv[1] = {rp[u]};
+                        float v[8], r8[8];
+                        raw_to_f8<__bf16>(iv, v);
+                        raw_to_f8<__bf16>(rv, r8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                        act_vec(v, act);
+                        const int ch = (q * 8) % Cout_p;  // first channel of the piece
+                        mask_tail(v, Cout - ch);
+                        store8(reinterpret_cast<__bf16*>(y) + base + (long)q * CPL, v);
+                    }
+                }
+            } else {
+                for (int q = lane; q < pieces; q += 64) {
+                    if (base + (long)q * CPL < lim)
+                        *reinterpret_cast<uint4*>(y + base + (long)q * CPL) = *reinterpret_cast<const uint4*>(st + (size_t)q * CPL);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();  // the image is reused by this wave's next tile
