@@ -718,9 +718,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __rest
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     const int tco = wave >> 1, tci = wave & 1;  // this wave's tile inside the 2 x 2 group
-    for (long rb = r0; rb < r1; rb += WT_KT) {
-        uint4 pre[8];
-        unsigned okbits = 0;  // applied after ALL loads are issued (a select next to a load serialises the batch)
+    // The rows of step s + 1 are requested BEFORE the MFMAs of step s (register double buffer): a block's steps no longer each expose a
+    // memory round trip, so fewer, longer blocks do the job -- and every block ends in 4 x 1024 fp32 atomics on the same small matrix.
+    uint4 pre[8];
+    unsigned okbits = 0;  // applied after ALL loads are issued (a select next to a load serialises the batch)
+    auto request = [&](long rb) {
+        okbits = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long r = rb + r8 * 8 + i;
@@ -728,6 +731,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __rest
             pre[i] = *reinterpret_cast<const uint4*>(src + (ok ? r : r0) * cp);
             okbits |= (ok ? 1u : 0u) << i;
         }
+    };
+    if (r0 < r1) request(r0);
+    for (long rb = r0; rb < r1; rb += WT_KT) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (!((okbits >> i) & 1u)) pre[i] = make_uint4(0, 0, 0, 0);
@@ -735,6 +741,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __rest
         transpose8x8_bf16(pre, out);
 #pragma unroll
         for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst + c * WT_PITCH) = out[c];
+        if (rb + WT_KT < r1) request(rb + WT_KT);  // in flight under the barrier and the 8 MFMAs below
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < WT_KT / 16; ++kk) {
@@ -764,7 +771,8 @@ static bool pw_wgrad_tile(const void* x, const void* dy, float* dw, const pasn_c
     const long R = (long)d.N * d.To * d.Ho * d.Wo;
     const int gy = co_pairs * ci_pairs;
     // row partitions: about four blocks per CU in flight, at least two 128-row steps each
-    long parts = std::max<long>(1, std::min<long>(1024 / gy + 1, R / (2 * WT_KT)));
+    const long target = getenv("PASN_WGT_BLOCKS") ? atol(getenv("PASN_WGT_BLOCKS")) : 1024;
+    long parts = std::max<long>(1, std::min<long>(target / gy + 1, R / (2 * WT_KT)));
     long rpb = (ceil_div(R, parts) + WT_KT - 1) / WT_KT * WT_KT;
     const dim3 grid((unsigned)ceil_div(R, rpb), gy);
     hipLaunchKernelGGL(pw_wgrad_tile_kernel, grid, dim3(256), (size_t)128 * WT_PITCH, s, (const __bf16*)x, (const __bf16*)dy, dw, d, co_pairs,
