@@ -102,7 +102,7 @@ struct DwRedArgs {
 };
 // dwmfma.hip: the stride-1 depthwise 3x3x3 stencil on the matrix cores (block-diagonal bf16 weight operands, LDS-DMA frame ring, T-marching); ok = 0: not covered
 struct DwMfmaGeom {
-    int ok, CT, CQ;            // channel tiles of 16, quads of 4 tiles (one block owns a quad)
+    int ok, SS, CT, CQ;        // stride in H and W (1 / 2), channel tiles of 16, quads of 4 tiles (one block owns a quad)
     int BH, BW, RPT, RTH, RTW;  // outputs per region, output rows per 16-lane position tile, regions per frame
     int RP, NI;                // staged positions per frame, 1-KiB DMA instructions per frame
     int Tc, nT, upb, chunks, bpc;  // T chunk (+count), units (T chunk x region) per block, SE partial rows per clip, blocks per clip

@@ -844,7 +844,7 @@ extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
     const Dw2Geom m2 = dw_march2_geom(*d, dtype);
     if (m2.WT) return 40000 + m2.CH * 1000 + m2.WT * 10 + d->sw;  // dwconv3d_march2_kernel<SW, WT, CH>
-    if (dw_mfma_geom(*d, dtype).ok) return 50000;                     // dwconv3d_mfma_kernel
+    if (const DwMfmaGeom mf = dw_mfma_geom(*d, dtype); mf.ok) return 50000 + mf.SS;  // dwconv3d_mfma_kernel<.., SS>
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return 3000 + m.WT * 10 + d->sw;  // dwconv3d_march_kernel<SW, WT>
     const DwGeom g = dw_geom(*d);

@@ -40,12 +40,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned dwm_u32x2;
 typedef __attribute__((address_space(3))) void* dwm_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* dwm_gbl_ptr_t;
 
-constexpr int DWF_SLOTS = 10;   // 16-byte slots per staged position (8 used)
 constexpr int DWF_NTL = 7;      // position tiles per wave (7 x 14 outputs: the X3D planes are 56 / 28 / 14 / 7 high)
-constexpr int DWF_NE = 7;       // DMA instructions per wave and frame (<= 28 per block)
 constexpr int DWF_RING = 2;      // frame images in LDS: frame t + RING - 1 is requested right after the barrier of frame t (3: measured 4-5 % slower)
-constexpr int DWF_PITCH = 16;   // staged positions per region row
-constexpr int dwf_tiles(int rpt) { return rpt == 2 ? 4 : DWF_NTL; }  // two-row tiles (planes <= 8 wide): 4 x 2 rows, the LDS image stays <= 25 KB
+// two-row tiles (planes <= 8 wide): 4 x 2 rows, the LDS image stays <= 25 KB; stride 2: 3 rows of 14 outputs = 7 x 29 staged positions
+constexpr int dwf_tiles(int rpt, int ss = 1) { return ss == 2 ? 3 : rpt == 2 ? 4 : DWF_NTL; }
+constexpr int dwf_pitch(int ss) { return ss == 2 ? 32 : 16; }  // staged positions per region row
+// 16-byte slots per staged position (8 used).  The 16 lanes of an operand read are SS positions apart: SS * slots = 2 (mod 4) keeps
+// them on different banks (10 at stride 1, 9 at stride 2: 20 slots apart would put lanes m and m + 4 on the same banks)
+constexpr int dwf_slots(int ss) { return ss == 2 ? 9 : 10; }
+constexpr int dwf_rows(int rpt, int ss) { return (dwf_tiles(rpt, ss) * rpt - 1) * ss + 3; }  // staged rows per region
+constexpr int dwf_ni(int rpt, int ss) { return (dwf_rows(rpt, ss) * dwf_pitch(ss) * dwf_slots(ss) + 63) / 64; }  // 1-KiB DMA instructions per frame
 
 __device__ __forceinline__ unsigned bf16_bits_rne(float f) {
     const __bf16 b = (__bf16)f;
@@ -84,7 +88,9 @@ __device__ __forceinline__ void dwf_wait_all_but(int n) {  // n wave-uniform: ev
 // from memory is waited for by count (dwf_wait_all_but) just before.
 __device__ __forceinline__ void dwf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int RPT, bool ABLB = false, int ACT = -1>  // ACT: the epilogue activation compiled in (none / Swish: what X3D uses), -1 = the descriptor's
+// ACT: the epilogue activation compiled in (none / Swish: what X3D uses), -1 = the descriptor's.  SS: the stride in H and W (1 or 2; stride 2:
+// one output row of 14 per tile, 3 tiles, the staged rows 32 positions wide and 9 slots apart -- see dwf_slots)
+template <int RPT, bool ABLB = false, int ACT = -1, int SS = 1>
 __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ scale, const float* __restrict__ bias,
                                                                __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
@@ -142,12 +148,14 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     // this clip from the quad's first channel on; the last bytes of the clip's last row belong to the quad's own channels or lie beyond
     // num_records (channels of LATER quads sit below offset fr_in_bytes * Ti - cq * 128: reading them as "padding slots" is harmless)
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(xclip), 0, (unsigned)Ti * fr_in_bytes - (unsigned)(cq * 128), 0x00020000);
-    constexpr int NT = dwf_tiles(RPT);  // position tiles per wave
+    constexpr int NT = dwf_tiles(RPT, SS);  // position tiles per wave
     const int abl = ABLB ? g.abl : 0;   // timing ablations: a separate instance, the product kernel carries none of the checks
-    constexpr int RW = DWF_PITCH;  // staged positions per region row (BW + 2 <= 16 used)
+    constexpr int RW = dwf_pitch(SS);  // staged positions per region row ((BW - 1) SS + 3 <= RW used)
+    constexpr int SLOTS = dwf_slots(SS);
+    constexpr int NE = (dwf_ni(RPT, SS) + 3) / 4;  // DMA instructions per wave and frame
     // frame image size is a compile-time constant of the instance (the ring slots, the DMA destinations and the operand reads are then
     // immediates: as run-time scalars they cost ~90 spilled SGPRs, reloaded lane by lane at every frame)
-    constexpr int NI = ((NT * RPT + 2) * DWF_PITCH * DWF_SLOTS + 63) / 64;
+    constexpr int NI = dwf_ni(RPT, SS);
     constexpr int fbytes = NI * 1024;
     // tap offsets of this lane inside the staged region (pair j -> tap 2j + (q >> 1); the absent 10th tap reads the 9th's cell: its
     // weights are zero)
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int tap9 = min(2 * j + (q >> 1), 8);
-        tapoff[j] = ((tap9 / 3) * RW + (tap9 % 3)) * (DWF_SLOTS * 16);
+        tapoff[j] = ((tap9 / 3) * RW + (tap9 % 3)) * (SLOTS * 16);
     }
     const int regions = g.RTH * g.RTW;
     const int units = g.nT * regions;
@@ -171,14 +179,14 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         // Buffer addressing (descriptor = this clip's quad of channels, all frames): the source is a wave-uniform frame offset (SGPR) + this
         // lane's 32-bit offset; pieces outside the image carry an out-of-range offset: the hardware fetches nothing and writes ZEROS to their cells.  No predicate, exec juggling or pointer arithmetic per instruction, and every
         // instruction is issued: the wave counts them.
-        unsigned goff[DWF_NE];  // byte offset inside a frame (this quad), 2^31 = not fetched
+        unsigned goff[NE];  // byte offset inside a frame (this quad), 2^31 = not fetched
 #pragma unroll
-        for (int e = 0; e < DWF_NE; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int slot = (wave + 4 * e) * 64 + lane;
-            const int rp = slot / DWF_SLOTS, c = slot - rp * DWF_SLOTS;
+            const int rp = slot / SLOTS, c = slot - rp * SLOTS;
             const int rr = rp / RW, cc = rp - rr * RW;
-            const int hi = h0 - 1 + rr, wi = w0 - 1 + cc;
-            const bool ok = !(abl & 16) && wave + 4 * e < NI && rp < g.RP && cc < g.BW + 2 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            const int hi = h0 * SS - 1 + rr, wi = w0 * SS - 1 + cc;
+            const bool ok = !(abl & 16) && wave + 4 * e < NI && rp < g.RP && cc < (g.BW - 1) * SS + 3 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
             goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cp + c * 8) * 2) : 0x80000000u;
         }
         const int kdma = max(0, (NI - wave + 3) >> 2);  // DMA instructions of this wave per frame (i = wave + 4e < NI)
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             const unsigned foff = (unsigned)ti * fr_in_bytes;  // wave-uniform
             char* dst = ring + slot * fbytes;
 #pragma unroll
-            for (int e = 0; e < DWF_NE; ++e)
+            for (int e = 0; e < NE; ++e)
                 if (wave + 4 * e < NI)  // wave-uniform
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (dwm_lds_ptr_t)(dst + (wave + 4 * e) * 1024), 16, (int)goff[e], (int)foff, 0, 0);
         };
@@ -199,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         const int mrow_lim = lane_ok ? mrow : (1 << 20);  // row of this lane inside its tile, or "never valid"
         const int rows_valid = min(g.BH, d.Ho - h0);                                       // output rows of this region
         const int ntl = (rows_valid + RPT - 1) / RPT;                                      // tiles that hold any of them (wave-uniform)
-        const int lbase0 = ((min(mrow, RPT - 1) * RW + min(mcol, g.BW - 1)) * DWF_SLOTS + 2 * wave + (q & 1)) * 16;
-        constexpr int lstep = RPT * RW * DWF_SLOTS * 16;                                   // bytes between tiles in the staged image: an immediate
+        const int lbase0 = ((min(mrow, RPT - 1) * SS * RW + min(mcol, g.BW - 1) * SS) * SLOTS + 2 * wave + (q & 1)) * 16;
+        constexpr int lstep = RPT * SS * RW * SLOTS * 16;                                   // bytes between tiles in the staged image: an immediate
         const int ystep = RPT * d.Wo * Cp;
         __bf16* yclip = y + (long)n * d.To * d.Ho * d.Wo * Cp;
         const long ofs = (long)d.Ho * d.Wo * Cp;
@@ -360,9 +368,18 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     if (on && on[0] == '0') return g;
     const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : (1 << 30);
     if (d.Wo > maxw) return g;
-    const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
-                       d.pw == 1 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0;
+    const int ss = d.sh;
+    const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && (ss == 1 || ss == 2) && d.sw == ss && d.pt == 1 && d.ph == 1 &&
+                       d.pw == 1 && d.To == d.Ti && d.Ho == (d.Hi - 1) / ss + 1 && d.Wo == (d.Wi - 1) / ss + 1 && d.Cin_p == d.Cout_p &&
+                       d.Cout_p % 8 == 0;
     if (!shape) return g;
+    // stride 2 (the first stencil of an X3D stage): OPT-IN (PASN_DWMFMA_S2=1), planes more than 8 wide only (one output row per tile).
+    // Measured (N = 32, profiles/README entry 52): 54 channels 112 -> 56: 210 us vs 224 VALU (200 with one unit per block), 108
+    // channels 56 -> 28: 123 vs 113, 216 channels 28 -> 14: 54 vs 52; end to end 8727 / 8735 vs 8796 / 8804 clips/s (the two narrow
+    // layers also lose their fused gate).  Both kernels sit at ~4-4.3 TB/s of algorithmic bytes plus the halo rows they re-read
+    // (7 staged rows per 3 output rows here): these layers are at the fabric's practical rate, not at an issue limit.
+    if (ss == 2 && (d.Wo <= 8 || !(getenv("PASN_DWMFMA_S2") && getenv("PASN_DWMFMA_S2")[0] == '1'))) return g;
+    g.SS = ss;
     if ((long)d.Ti * d.Hi * d.Wi * d.Cin_p * 2 >= (1L << 31)) return g;  // one clip per buffer descriptor, 2^31 marks "outside"
     g.CT = ceil_div(d.Cout_p, 16);
     g.CQ = ceil_div(g.CT, 4);
@@ -370,11 +387,11 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     // tile is one output row (14 lanes used) or, on planes at most 8 wide, two
     g.BW = std::min(d.Wo, 14);
     g.RPT = g.BW <= 8 ? 2 : 1;
-    g.BH = std::min(d.Ho, dwf_tiles(g.RPT) * g.RPT);
+    g.BH = std::min(d.Ho, dwf_tiles(g.RPT, ss) * g.RPT);
     g.RTH = ceil_div(d.Ho, g.BH);
     g.RTW = ceil_div(d.Wo, g.BW);
-    g.RP = (g.BH + 2) * DWF_PITCH;
-    g.NI = ceil_div((dwf_tiles(g.RPT) * g.RPT + 2) * DWF_PITCH * DWF_SLOTS, 64);  // the instance's constant (region height tiles * RPT)
+    g.RP = ((g.BH - 1) * ss + 3) * dwf_pitch(ss);
+    g.NI = dwf_ni(g.RPT, ss);  // the instance's constant
     // (Tc, upb): blocks run two per CU, a block costs a setup (weight operands, pipeline fill) plus upb units of Tc + 2 frames; at most
     // 64 chunks per clip where it costs nothing (the chunk count is the number of SE partial rows the gate has to sum)
     const int force_tc = getenv("PASN_DWMFMA_TC") ? atoi(getenv("PASN_DWMFMA_TC")) : 0;
@@ -410,9 +427,14 @@ int launch_dw_mfma(const void* x, const float* w, const float* scale, const floa
                    const DwMfmaGeom& g, hipStream_t s) {
     const dim3 grid(g.bpc * d.N), block(256);
     const size_t lds = (size_t)DWF_RING * g.NI * 1024;
-#define PASN_DWF(RPT_, ABL_, ACT_) \
-    hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
-    if (g.abl) PASN_DWF(1, true, -1);
+#define PASN_DWF(RPT_, ABL_, ACT_) PASN_DWFS(RPT_, ABL_, ACT_, 1)
+#define PASN_DWFS(RPT_, ABL_, ACT_, SS_) \
+    hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_, SS_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
+    if (g.SS == 2) {
+        if (d.act == PASN_ACT_NONE) PASN_DWFS(1, false, PASN_ACT_NONE, 2);
+        else if (d.act == PASN_ACT_SWISH) PASN_DWFS(1, false, PASN_ACT_SWISH, 2);
+        else PASN_DWFS(1, false, -1, 2);
+    } else if (g.abl) PASN_DWF(1, true, -1);
     else if (g.RPT == 2) {
         if (d.act == PASN_ACT_NONE) PASN_DWF(2, false, PASN_ACT_NONE);
         else if (d.act == PASN_ACT_SWISH) PASN_DWF(2, false, PASN_ACT_SWISH);
@@ -423,6 +445,7 @@ int launch_dw_mfma(const void* x, const float* w, const float* scale, const floa
         else PASN_DWF(1, false, -1);
     }
 #undef PASN_DWF
+#undef PASN_DWFS
     return check_launch("dwconv3d_mfma_kernel");
 }
 

@@ -567,6 +567,37 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     assert float(d.max()) <= 2.0 ** -6 * max(1.0, float(out1.float().abs().max())), float(d.max())
 
 
+@pytest.mark.parametrize("c", [24, 56, 108, 432])
+@pytest.mark.parametrize("geom", ["0,0", "4,1", "4,3", "2,1000"])
+@pytest.mark.parametrize("thw", [(9, 22, 26), (9, 28, 44), (5, 19, 33), (4, 60, 18)])
+def test_dwconv3d_mfma_stride2(thw, geom, c, monkeypatch):
+    """Matrix-core stencil at stride 2 in H and W (the first stencil of every X3D stage): staged rows 32 positions wide, operand reads
+    two positions apart, 3 output rows per region -- even and odd input planes (the last staged row / column inside or outside the
+    image), ragged regions in both directions, T chunks, partial channel tiles and quads, Swish epilogue and SE partial sums, against
+    torch and against the VALU stencil within the bf16 rounding of the weights."""
+    tc, upb = geom.split(",")
+    monkeypatch.delenv("PASN_DWM2", raising=False)
+    monkeypatch.setenv("PASN_DWMFMA", "1")
+    monkeypatch.setenv("PASN_DWMFMA_S2", "1")  # opt-in: the stride-2 layers sit at the memory system's rate on either kernel
+    if tc != "0":
+        monkeypatch.setenv("PASN_DWMFMA_TC", tc)
+        monkeypatch.setenv("PASN_DWMFMA_UPB", upb)
+    x, conv, bn, pre = _march_case(2, c, thw=thw)
+    ref = pre * torch.sigmoid(pre)
+    out, part, kernel = _run_march(x, conv, bn, "swish")
+    assert kernel.startswith("dwconv3d_mfma_kernel<1,false,") and kernel.endswith(",2>"), kernel
+    atol, rtol = _tols(torch.bfloat16)
+    assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"mfma stencil stride 2 {thw} {geom} c{c}")
+    want = pre.sum(dim=(2, 3, 4))
+    assert_close(part.sum(dim=1)[:, :c].cpu(), want, 2e-2 * float(want.abs().max()), 0, "SE partial sums")
+    assert float(out[..., c:].abs().max() if out.shape[-1] > c else 0.0) == 0.0, "padded channels must stay zero"
+    monkeypatch.setenv("PASN_DWMFMA_S2", "0")
+    out1, part1, kernel1 = _run_march(x, conv, bn, "swish")
+    assert kernel1.startswith("dwconv3d_march_kernel<"), kernel1
+    d = (out.float() - out1.float()).abs()
+    assert float(d.max()) <= 2.0 ** -6 * max(1.0, float(out1.float().abs().max())), float(d.max())
+
+
 @pytest.mark.parametrize("wt", [2, 3])
 @pytest.mark.parametrize("tc", [4, 8, 16])
 @pytest.mark.parametrize("stride", [1, 2])
