@@ -4,7 +4,7 @@
 //
 // The VALU stem (stem.hip) spends 648 fp32 FMAs + a 5-frame register ring per output position: 245 us at 32 x 3 x 16 x 224 x 224, 6 %
 // of the step, for 462 MB of traffic (HBM floor ~100 us).  Here a block owns 4 output rows x 64 output columns of one clip and MARCHES
-// ALONG T: every input frame's patch (C x 9 rows x 192 columns, bf16, normalised, zero outside the image / the clip) is staged ONCE
+// ALONG T: every input frame's patch (C x 9 rows x 132 columns, bf16, normalised, zero outside the image / the clip) is staged ONCE
 // into a ring of 6 LDS slots, and output frame t is 12 k-steps (C = 3; 4 for a grey clip) of v_mfma_f32_32x32x16_bf16 over the five
 // slots t-2 .. t+2: per lane a fragment is two 4-byte-aligned 8-byte LDS reads (first_conv_mfma.hip's window-slot trick with a 4-wide
 // window: patch columns 2 ow - 2 .. 2 ow + 1 hold the three taps of a stride-2 3-wide window in slots 1 .. 3), the weights sit
@@ -17,7 +17,11 @@
 
 namespace pasn {
 
-constexpr int SM_ROWS = 4, SM_COLS = 64, SM_PC = 192, SM_PR = 2 * (SM_ROWS - 1) + 3, SM_RING = 6;
+// SM_PC: patch columns staged per row = 2 * 64 + 4 (the last window ends at patch column 131).  It was 192: 72.5 KB of LDS, two blocks per
+// CU with every wave of a block in the same phase (stage / barrier / MFMA / epilogue) -- nothing above 40 % busy.  132: 53 KB, THREE
+// blocks per CU (145-153 VGPRs), a third fewer staging loads: stem 191 -> ~150 us, 8.80 k -> 8.91 k clips/s end to end.
+constexpr int SM_ROWS = 4, SM_COLS = 64, SM_PC = 132, SM_PR = 2 * (SM_ROWS - 1) + 3, SM_RING = 6;
+static_assert(SM_PC % 4 == 0 && SM_PC >= 2 * SM_COLS + 4, "whole 4-column staging units, every window inside the patch");
 constexpr int SM_PF = 3;  // k-steps of fragment reads in flight ahead of the MFMAs
 
 template <typename TIN>
