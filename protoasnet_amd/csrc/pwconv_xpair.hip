@@ -91,10 +91,10 @@ void pwconv_xpair_kernel(const __bf16* __restrict__ x, const __bf16* __restrict_
     }
 
     // ---- stage the gate rows, then the X tile -------------------------------------------------------------------------------
-    if (XF && gate) {
+    if (XF) {  // (no gate: rows of 1.0 -- the transform below has no per-element condition)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (tid + 256 * u < 2 * w1_kc) gl[tid + 256 * u] = gv[u];
+            if (tid + 256 * u < 2 * w1_kc) gl[tid + 256 * u] = gate ? gv[u] : 1.0f;
         __syncthreads();
     }
 #pragma unroll
@@ -108,11 +108,20 @@ void pwconv_xpair_kernel(const __bf16* __restrict__ x, const __bf16* __restrict_
         xv.w = ok ? xv.w : 0u;
         if (XF && pcol * CH < Cin_p) {
             __bf16* e = reinterpret_cast<__bf16*>(&xv);
-            const float* gp = gate ? gl + ((r0 + prow >= S) ? w1_kc : 0) + pcol * CH : nullptr;
+            // the piece's gate values as whole 16-byte reads, all before the arithmetic: `if (gp) f *= gp[j]` compiled to one predicated
+            // ds_read_b32 + s_waitcnt per ELEMENT (NP x CH serialised LDS round trips per thread: the gated instances ran 13-17 us longer
+            // than the plain ones)
+            const float* gp = gl + ((r0 + prow >= S) ? w1_kc : 0) + pcol * CH;
+            float gq[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j += 4) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(gp + j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gq[j + i] = q4[i];
+            }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                float f = (float)e[j];
-                if (gp) f *= gp[j];
+                float f = (float)e[j] * gq[j];
                 if (in_swish) f = f * sigmoidf_(f);
                 e[j] = (__bf16)f;
             }
