@@ -436,6 +436,25 @@ int pasn_affine_warp_fwd(const void* x, void* y, long planes, int H, int W, floa
 int pasn_affine_warp_bwd(const float* dy, float* dx, long planes, int H, int W, float angle_deg, float scale, void* stream);
 
 /*
+ * Training: all conv weights of a step packed from the live fp32 parameters into the layouts the forward kernels read, in ONE launch
+ * (replaces the per-parameter torch expressions of the host side: the reference has no counterpart -- cuDNN reads the parameters as they
+ * are, model/XProtoNet.py keeps nn.Conv modules).  `jobs`, `block_job`, `block_chunk` are DEVICE arrays: block b packs destination
+ * elements [block_chunk[b], block_chunk[b] + 1) x pasn_pack_chunk() of job block_job[b]; every destination element is written.
+ *   mode 0: dense forward   dst[row = co][tap][k = ci]  = src[co][ci][tap]              (src [cout][cin][taps], dst [rows][taps][kc])
+ *   mode 1: dense dX        dst[row = ci][tap][k = co]  = src[co][ci][taps - 1 - tap]   (transposed, taps reversed)
+ *   mode 2 / 3: depthwise   dst[tap][c] = src[c][tap] / src[c][taps - 1 - tap]          (fp32 dst [taps][kc = Cp])
+ *   frag = 1 (taps == 1): dst is fragment-major [rows/32][kc/kstep][2][32][ch] (the x-tile pointwise kernels, w_frag = 1)
+ */
+typedef struct pasn_pack_job {
+    const float* src;
+    void* dst;
+    long n;  /* destination elements */
+    int mode, cout, cin, taps, rows, kc, frag, bf16, kstep, ch;
+} pasn_pack_job;
+int pasn_pack_chunk(void);
+int pasn_pack_weights(const pasn_pack_job* jobs, const int* block_job, const int* block_chunk, int nblocks, void* stream);
+
+/*
  * Data-parallel gradient exchange on RCCL (xGMI), without torch.distributed in the data path: ONE in-place sum all-reduce of the
  * flat fp32 gradient bucket per optimizer step.  The reference trains on one GPU and has no collective
  * (SURVEY section 0); these four calls are what a trainer needs around protoasnet_amd/dp.py.  librccl.so is resolved at run time.

@@ -69,6 +69,8 @@ SIGNATURES = {
     "pasn_train_chunks": (c_int, [c_int, c_int, c_int]),
     "pasn_se_gate_bwd_stat": (c_int, [c_void_p] * 17 + [c_int] * 5 + [c_void_p]),
     "pasn_bn_bwd_apply_se": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    "pasn_pack_chunk": (c_int, []),
+    "pasn_pack_weights": (c_int, [c_void_p] * 3 + [c_int, c_void_p]),
     "pasn_dwconv3d_stats_rows": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_dgrad_reduce_rows": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_dgrad_reduce": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 4 + [POINTER(ConvDesc), c_int, c_void_p]),

@@ -43,6 +43,10 @@ class TrainBuilder(PlanBuilder):
         self.readers: Dict[int, int] = {}      # activation buffer id -> number of ops that consume it (conv input, residual, pool, head)
         self.red_hook: Dict[int, dict] = {}    # activation buffer id -> how its producer unit's backward sums can be taken by a fused dgrad
         self.refresh: List[Callable[[], None]] = []
+        # weights packed by the native one-launch packer (pasn_pack_weights): (parameter, destination, mode, cout, cin, taps, rows, kc,
+        # frag, kstep, ch) -- source dims as the PARAMETER has them.  PASN_NO_PACK=1: torch expressions per parameter (the old path)
+        self.pack_jobs: List[tuple] = []
+        self.native_pack = os.environ.get("PASN_NO_PACK") != "1"
         self.pslots: List[Tuple[torch.Tensor, int, int]] = []
         self._slot_of: Dict[int, int] = {}
         self.gsize = 0
@@ -131,7 +135,8 @@ class TrainBuilder(PlanBuilder):
 
     # ---- dense conv launch with a weight that is re-packed from the live parameter every step --------------------------
     def _dense(self, x: Act, y: Act, k, s, p, cout: int, cin: int, weight_fn: Callable[[], torch.Tensor],
-               residual: Optional[Act] = None) -> ConvDesc:
+               residual: Optional[Act] = None, pack: Optional[Tuple[torch.Tensor, int]] = None) -> ConvDesc:
+        """``pack`` = (parameter [cout][cin][taps...] fp32, mode 0 forward / 1 input gradient): what ``weight_fn`` computes, for the native packer."""
         taps = k[0] * k[1] * k[2]
         kstep, ch = (16, 8) if self.dtype == torch.bfloat16 else (8, 4)
         kc, rows = round_up(x.Cp, kstep), round_up(round_up(cout, 8), 128)
@@ -148,7 +153,13 @@ class TrainBuilder(PlanBuilder):
             if frag:
                 wf.view(rows // 32, kc // kstep, 2, 32, ch).copy_(wp.view(rows // 32, 32, kc // kstep, 2, ch).permute(0, 2, 3, 1, 4))
 
-        self.refresh.append(refresh)
+        if pack is not None and self.native_pack and pack[0].is_contiguous() and (not frag or taps == 1):
+            param, mode = pack
+            src_cout, src_cin = (cout, cin) if mode == 0 else (cin, cout)
+            assert param.numel() == src_cout * src_cin * taps
+            self.pack_jobs.append((param, wf if frag else wp, mode, src_cout, src_cin, taps, rows, kc, int(frag), kstep, ch))
+        else:
+            self.refresh.append(refresh)
         one, zero = self.const(rows, 1.0), self.const(rows, 0.0)
         self.keep += [wp, wf, one, zero]
         rb = residual.buf if residual is not None else None
@@ -203,7 +214,10 @@ class TrainBuilder(PlanBuilder):
             assert conv.groups == cin == cout == x.C and not x.planar
             dw_w = torch.zeros(taps, Cp, dtype=torch.float32, device=self.device)
             d = self._desc(x, y, k, s, p, "none")
-            self.refresh.append(lambda: dw_w[:, :C].copy_(conv.weight.detach().reshape(C, taps).t()))
+            if self.native_pack and conv.weight.is_contiguous():
+                self.pack_jobs.append((conv.weight, dw_w, 2, C, 1, taps, taps, Cp, 0, 0, 0))
+            else:
+                self.refresh.append(lambda: dw_w[:, :C].copy_(conv.weight.detach().reshape(C, taps).t()))
             one, zero = self.const(Cp, 1.0), self.const(Cp, 0.0)
             self.keep += [dw_w, one, zero]
             # the stencil can take the unit's batch statistics in the same pass over y (saves the read of y by pasn_bn_stats_fwd)
@@ -213,7 +227,7 @@ class TrainBuilder(PlanBuilder):
                 self._op(lib.pasn_dwconv3d_fwd, B(x.buf), dw_w.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), 0, ctypes.byref(d), code)
         else:
             assert conv.groups == 1 and not x.planar
-            d = self._dense(x, y, k, s, p, cout, cin, lambda: conv.weight.detach())
+            d = self._dense(x, y, k, s, p, cout, cin, lambda: conv.weight.detach(), pack=(conv.weight, 0))
         dref = ctypes.byref(d)
         # ---------------- statistics / affine ----------------
         plain = norm is None and conv.bias is None and act == "none" and residual is None and se is None
@@ -372,7 +386,10 @@ class TrainBuilder(PlanBuilder):
                     # stride-1 "same" depthwise conv: its input gradient is the forward stencil with the taps reversed
                     # (the T-marching forward kernel, not the generic gather)
                     wflip = torch.zeros(taps, Cp, dtype=torch.float32, device=self.device)
-                    self.refresh.append(lambda: wflip[:, :C].copy_(conv.weight.detach().reshape(C, taps).flip(1).t()))
+                    if self.native_pack and conv.weight.is_contiguous():
+                        self.pack_jobs.append((conv.weight, wflip, 3, C, 1, taps, taps, Cp, 0, 0, 0))
+                    else:
+                        self.refresh.append(lambda: wflip[:, :C].copy_(conv.weight.detach().reshape(C, taps).flip(1).t()))
                     one_, zero_ = self.const(Cp, 1.0), self.const(Cp, 0.0)
                     dflip = self._desc(dy, dx, k, s, p, "none")
                     self.keep += [wflip]
@@ -410,11 +427,11 @@ class TrainBuilder(PlanBuilder):
                 wt = lambda: conv.weight.detach().reshape(cout, cin).t()
                 if s == one:
                     dx = self.like(x)
-                    self._dense(dy, dx, one, one, (0, 0, 0), cin, cout, wt, residual=have)
+                    self._dense(dy, dx, one, one, (0, 0, 0), cin, cout, wt, residual=have, pack=(conv.weight, 1))
                     self.grads[x.buf] = dx
                 else:
                     compact = Act(y.N, y.T, y.H, y.W, cin, x.Cp, self._new_buf(y.N * y.positions * x.Cp * self.es))
-                    self._dense(dy, compact, one, one, (0, 0, 0), cin, cout, wt)
+                    self._dense(dy, compact, one, one, (0, 0, 0), cin, cout, wt, pack=(conv.weight, 1))
                     dst = have if have is not None else self.like(x)
                     self._use(compact.buf, dst.buf)
                     self._op(lib.pasn_scatter_strided, B(compact.buf), B(dst.buf), dref, int(have is not None), code)
@@ -437,7 +454,7 @@ class TrainBuilder(PlanBuilder):
             else:
                 assert (y.T, y.H, y.W) == Z
             dx = self.like(x)
-            self._dense(src, dx, k, one, padb, cin, cout, wtf, residual=have)
+            self._dense(src, dx, k, one, padb, cin, cout, wtf, residual=have, pack=(conv.weight, 1))
             self.grads[x.buf] = dx
 
         self.tape.append(backward)
@@ -557,6 +574,28 @@ class TrainBuilder(PlanBuilder):
         return TrainPlan(self, x_in, ext, total)
 
 
+def build_pack_tables(jobs: List[tuple], device) -> tuple:
+    """Device tables of ``pasn_pack_weights`` for jobs (parameter, destination, mode, cout, cin, taps, rows, kc, frag, kstep, ch):
+    (job structs as bytes, job of each block, chunk of each block, number of blocks)."""
+    import numpy as np
+
+    chunk = int(_lib.lib().pasn_pack_chunk())
+    jt = np.zeros(len(jobs), dtype=np.dtype(
+        [("src", "u8"), ("dst", "u8"), ("n", "i8"), ("mode", "i4"), ("cout", "i4"), ("cin", "i4"), ("taps", "i4"), ("rows", "i4"),
+         ("kc", "i4"), ("frag", "i4"), ("bf16", "i4"), ("kstep", "i4"), ("ch", "i4")], align=True))
+    assert jt.dtype.itemsize == 64  # struct pasn_pack_job
+    bj, bc = [], []
+    for i, (param, dst, mode, cout, cin, taps, rows, kc, frag, kstep, ch) in enumerate(jobs):
+        assert param.dtype == torch.float32 and param.is_contiguous() and dst.is_contiguous()
+        jt[i] = (param.data_ptr(), dst.data_ptr(), dst.numel(), mode, cout, cin, taps, rows, kc, frag, int(dst.dtype == torch.bfloat16),
+                 kstep, ch)
+        nb = (dst.numel() + chunk - 1) // chunk
+        bj += [i] * nb
+        bc += list(range(nb))
+    return (torch.from_numpy(jt.view(np.uint8).copy()).to(device), torch.tensor(bj, dtype=torch.int32, device=device),
+            torch.tensor(bc, dtype=torch.int32, device=device), len(bj))
+
+
 class TrainPlan:
     def __init__(self, tb: TrainBuilder, x_in: Act, ext: Dict[str, int], arena_bytes: int):
         self.ops, self.n_fwd, self.keep, self.refresh, self.op_names = tb.ops, tb.n_fwd, tb.keep, tb.refresh, tb.op_names
@@ -567,6 +606,19 @@ class TrainPlan:
         self.arena_bytes = arena_bytes
         self.naive_bytes = sum(b.nbytes for b in tb.bufs if not b.external)
         self.device, self.dtype = tb.device, tb.dtype
+        self.pack_jobs, self._pack_key, self._pack_tables = tb.pack_jobs, None, None
+
+    def _pack_weights(self, st) -> None:
+        """All conv weights of the step from the live parameters, one launch (csrc/pack.hip).  The job table holds device pointers: it is
+        rebuilt when a parameter's storage has moved (``.to()``, ``.data = ...``); in-place optimizer updates keep it."""
+        if not self.pack_jobs:
+            return
+        key = tuple(j[0].data_ptr() for j in self.pack_jobs)
+        if key != self._pack_key:
+            self._pack_tables = build_pack_tables(self.pack_jobs, self.device)
+            self._pack_key = key
+        jobs, bj, bc, nb = self._pack_tables
+        _lib.check(_lib.lib().pasn_pack_weights(jobs.data_ptr(), bj.data_ptr(), bc.data_ptr(), nb, st))
 
     def _ptrs(self, arena: torch.Tensor) -> List[int]:
         base = round_up(arena.data_ptr(), ALIGN)
@@ -578,6 +630,7 @@ class TrainPlan:
                 r()
             if self.nbt:
                 torch._foreach_add_(self.nbt, 1)
+        self._pack_weights(_lib.current_stream())
         arena = torch.empty(self.arena_bytes + ALIGN, dtype=torch.uint8, device=x.device)
         ptrs = self._ptrs(arena)
         ptrs[self.in_buf] = x.data_ptr()

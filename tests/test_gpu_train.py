@@ -528,6 +528,68 @@ def test_weight_gradient_kernels_at_full_benchmark_shapes(layer, monkeypatch):
     _rel(outs[0], outs[2], 2e-4, f"{layer}: partial-buffer kernel vs the atomic per-tap kernel")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_weights_one_launch(dtype):
+    """The native weight packer (one launch for all conv weights of a step) against the torch expressions it replaces, BIT-EXACT: dense
+    forward and input-gradient layouts (padded [row][tap][k]; 27 / 9 / 3 / 1 taps; transposed with reversed taps), the fragment-major
+    layout of the x-tile pointwise kernels, the depthwise [tap][Cp] layouts (plain and reversed), destinations that span several blocks
+    and ones smaller than a block, channel counts that are not multiples of the paddings -- all in the same table."""
+    from protoasnet_amd.plan import round_up
+    from protoasnet_amd.train import build_pack_tables
+
+    torch.manual_seed(5)
+    kstep, ch = (16, 8) if dtype == torch.bfloat16 else (8, 4)
+    jobs, want = [], []
+
+    def dense(cout, cin, k, mode, frag):
+        taps = k[0] * k[1] * k[2]
+        w = torch.randn(cout, cin, *k, device=DEV)
+        dc, di = (cout, cin) if mode == 0 else (cin, cout)  # the packed conv's (rows, k) extents
+        kc, rows = round_up(round_up(di, 8), kstep), round_up(round_up(dc, 8), 128)
+        wp = torch.zeros(rows, taps, kc, dtype=dtype, device=DEV)
+        src = w if mode == 0 else w.transpose(0, 1).flip(2, 3, 4)
+        wp[:dc, :, :di] = src.reshape(dc, di, taps).permute(0, 2, 1)
+        ref = wp
+        if frag:
+            ref = torch.empty_like(wp)
+            ref.view(rows // 32, kc // kstep, 2, 32, ch).copy_(wp.view(rows // 32, 32, kc // kstep, 2, ch).permute(0, 2, 3, 1, 4))
+        dst = torch.full_like(wp, float("nan"))  # every element must be written
+        jobs.append((w, dst, mode, cout, cin, taps, rows, kc, int(frag), kstep, ch))
+        want.append(ref)
+
+    def depthwise(c, k, flip):
+        taps = k[0] * k[1] * k[2]
+        cp = round_up(c, 8)
+        w = torch.randn(c, 1, *k, device=DEV)
+        ref = torch.zeros(taps, cp, device=DEV)
+        ref[:, :c] = (w.reshape(c, taps).flip(1) if flip else w.reshape(c, taps)).t()
+        dst = torch.full_like(ref, float("nan"))
+        jobs.append((w, dst, 3 if flip else 2, c, 1, taps, taps, cp, 0, 0, 0))
+        want.append(ref)
+
+    dense(54, 24, (1, 1, 1), 0, False)
+    dense(54, 24, (1, 1, 1), 0, True)
+    dense(54, 24, (1, 1, 1), 1, False)
+    dense(432, 192, (1, 1, 1), 1, True)
+    dense(144, 64, (1, 3, 3), 0, False)
+    dense(144, 64, (1, 3, 3), 1, False)
+    dense(64, 45, (3, 1, 1), 1, False)
+    dense(20, 12, (3, 3, 3), 0, False)
+    dense(20, 12, (3, 3, 3), 1, False)
+    dense(3, 5, (1, 1, 1), 0, False)
+    depthwise(54, (3, 3, 3), False)
+    depthwise(54, (3, 3, 3), True)
+    depthwise(24, (5, 1, 1), True)
+    depthwise(432, (3, 3, 3), False)
+    tables = build_pack_tables(jobs, torch.device(DEV))
+    tj, bj, bc, nb = tables
+    assert nb == sum((j[1].numel() + 2047) // 2048 for j in jobs)
+    _lib.check(_lib.lib().pasn_pack_weights(tj.data_ptr(), bj.data_ptr(), bc.data_ptr(), nb, _lib.current_stream()))
+    torch.cuda.synchronize()
+    for i, (job, ref) in enumerate(zip(jobs, want)):
+        assert torch.equal(job[1], ref), f"job {i}: mode {job[2]} cout {job[3]} cin {job[4]} taps {job[5]} frag {job[8]}"
+
+
 def test_scatter_strided_and_add():
     lib = _lib.lib()
     src = torch.randn(2, 2, 4, 5, 16, device=DEV)
@@ -828,9 +890,10 @@ def test_video_x3d_train_unmodified_model_vs_oracle():
 
 @pytest.mark.parametrize("cfg,shape,spatial,env", [(CFG_VIDEO_X3D, SHAPE, SPATIAL, ""), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_DW_DGRAD_REDUCE"),
                                                    (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_DW_STATS"), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_SE_ANALYTIC"),
+                                                   (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_PACK"),
                                                    (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4), ""),
                                                    (CFG_XPROTO, (3, 3, 96, 96), (3, 3), "")],
-                         ids=["x3d_s", "x3d_s-dgrad+sums", "x3d_s-separate-stats", "x3d_s-two-pass-se", "r2plus1d", "resnet18"])
+                         ids=["x3d_s", "x3d_s-dgrad+sums", "x3d_s-separate-stats", "x3d_s-two-pass-se", "x3d_s-torch-packed-weights", "r2plus1d", "resnet18"])
 def test_train_bf16_activations_track_fp32(cfg, shape, spatial, env, monkeypatch):
     """bf16 activations / activation gradients (fp32 statistics, reductions, parameter gradients) against the fp32 mode, every trunk
     (bf16 takes other kernels: T-marching stencils with the batch statistics fused in -- and, opt-in, the producer unit's backward sums

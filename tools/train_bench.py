@@ -101,6 +101,15 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(loss), "non-finite loss"
+    if rank == 0 and os.environ.get("PASN_TB_TORCHPROF"):
+        # which torch-side ops (weight repacking, gradient accumulation, optimizer) a step issues, with their Python call sites
+        from torch.profiler import ProfilerActivity, profile
+
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+            step()
+            step()
+        with open(os.environ["PASN_TB_TORCHPROF"], "w") as fh:
+            fh.write(prof.key_averages(group_by_stack_n=4).table(sort_by="self_cpu_time_total", row_limit=60, max_name_column_width=40))
     runner = next(r for r in model._train_runners.values() if r.mode == 0)
     roofline = per_entry = None
     if rank == 0:
