@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = nt * 32 + 8 * g + 4 * h;
-                if (col >= Cout_p) continue;
+                if (nt * 32 + 8 * g >= Cout_p) continue;  // wave-uniform (Cout_p is a multiple of 8: both lane halves of a group exist or neither)
                 float o[4], sc[4], bs[4];
                 load4(sbl + col, sc);
                 load4(sbl + NT * 32 + col, bs);
@@ -197,7 +197,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
                 }
                 if (!RCOPY) {
                     act_vec(o, act);
-                    mask_tail(o, Cout - col);
+                    // only the group that holds padded channels pays the selects (wave-uniform test: as a per-lane one the compiler hoists a
+                    // predicate per group out of the tile loop -- 30-150 spilled SGPRs per instance, read back lane by lane every tile)
+                    if (nt * 32 + 8 * g + 8 > Cout) {
+                        int left = Cout - col;
+                        asm volatile("" : "+v"(left));  // computed here, on the path that needs it (not hoisted per group and kept in SGPRs)
+                        mask_tail(o, left);
+                    }
                 }
                 store4(st + (size_t)c * Cout_p + col, o);
             }
@@ -219,8 +225,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r8[e];
                         act_vec(v, act);
-                        const int ch = (q * 8) % Cout_p;  // first channel of the piece
-                        mask_tail(v, Cout - ch);
+                        if (Cout != Cout_p) {  // block-uniform: the project convs' channel counts (24 / 48 / 96 / 192) have no padding
+                            int left = Cout - (q * 8) % Cout_p;  // channels left from the piece's first one
+                            asm volatile("" : "+v"(left));
+                            mask_tail(v, left);
+                        }
                         store8(reinterpret_cast<__bf16*>(y) + base + (long)q * CPL, v);
                     }
                 }
