@@ -12,8 +12,20 @@
 // An LDS-staged variant (coalesced whole-row loads and stores through LDS) was built first and measured SLOWER
 // (3 barriers per 128-row tile; 260 us of pure per-block latency on the 6.4 M-row layer): profiles/README.md.
 #include "common.h"
+#include <type_traits>
 
 namespace pasn {
+
+// act_vec with the activation optionally compiled in (ACTC = -1: the run-time switch)
+template <int ACTC, int N>
+__device__ __forceinline__ void act_vec_c(float (&v)[N], int act) {
+    if constexpr (ACTC == PASN_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.0f);
+    } else {
+        act_vec(v, act);
+    }
+}
 
 // 4 consecutive channels of a residual row, kept as loaded until the epilogue
 template <typename T>
@@ -176,6 +188,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
         // stores scattered at the row stride -- measured at ~1.7 TB/s of writes.  The 32 rows of a tile are ONE contiguous
         // global range, so bounce the finished tile through a WAVE-PRIVATE LDS image of exactly that range (no block
         // barrier: a wave's DS operations execute in order) and write it back as 16 bytes per lane, fully coalesced.
+        // The activation is dispatched ONCE per tile (ReLU -- every X3D / ResNet pointwise unit -- compiled in): `act_vec(o, act)` inside the
+        // unrolled (channel tile, group) loops was a ladder of scalar compares and branches per group, 4 NT of them per tile.
+        auto epilogue = [&](auto actc) {
+            constexpr int ACTC = decltype(actc)::value;
         T* st = stage + (size_t)wave * 32 * Cout_p;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
                     for (int j = 0; j < 4; ++j) o[j] += ok ? r4[j] : 0.0f;
                 }
                 if (!RCOPY) {
-                    act_vec(o, act);
+                    act_vec_c<ACTC>(o, act);
                     // only the group that holds padded channels pays the selects (wave-uniform test: as a per-lane one the compiler hoists a
                     // predicate per group out of the tile loop -- 30-150 spilled SGPRs per instance, read back lane by lane every tile)
                     if (nt * 32 + 8 * g + 8 > Cout) {
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
                         raw_to_f8<__bf16>(rv, r8);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r8[e];
-                        act_vec(v, act);
+                        act_vec_c<ACTC>(v, act);
                         if (Cout != Cout_p) {  // block-uniform: the project convs' channel counts (24 / 48 / 96 / 192) have no padding
                             int left = Cout - (q * 8) % Cout_p;  // channels left from the piece's first one
                             asm volatile("" : "+v"(left));
@@ -240,6 +256,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
                 }
             }
         }
+        };
+        if (act == PASN_ACT_RELU) epilogue(std::integral_constant<int, PASN_ACT_RELU>{});
+        else epilogue(std::integral_constant<int, -1>{});
         __builtin_amdgcn_wave_barrier();  // the image is reused by this wave's next tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) Bc[ks] = Bn[ks];
