@@ -54,7 +54,7 @@ typedef struct pasn_conv_desc {
     int32_t w_rows;           /* conv3d: rows of the packed weight / scale / bias arrays   */
     int32_t w_frag;           /* conv3d: 0 = w is [w_rows][taps][w_kc]; 1 = MFMA-fragment-major
                                  [w_rows/32][w_kc/KSTEP][2][32][CH] (KSTEP/CH = 16/8 bf16, 8/4 fp32):
-                                 only where pasn_conv3d_variant() reports >= 2500           */
+                                 only where pasn_conv3d_variant() reports 2500..5999 or >= 7000 */
 } pasn_conv_desc;
 
 /*
@@ -151,9 +151,11 @@ int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* scale1, con
  * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); 2500 + 2*KS (+1 with in_swish) = pwconv_xtile_kernel<dtype, KS, ..>
  * (1x1x1 stride-1 convs with Cin_p >= 64: whole-K position tiles in LDS); 2000 / 2001 = gemm_conv_kernel<dtype, pointwise /
  * windowed> (LDS-tiled implicit GEMM); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT> (output-channel /
- * position tiles per wave); 0 on a bad descriptor.  has_gate = whether `gate` will be non-NULL (the choice between the
- * two pointwise kernels depends on it).  For profilers, benchmarks and the weight packing (w_frag). */
-int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int has_gate);
+ * position tiles per wave); 7000 + KS*10 + MT = pwconv_ws_kernel<KS, MT, ..> (bf16 1x1x1 stride-1 convs with Cin_p >= 48:
+ * weight-stationary persistent blocks, LDS-DMA stage ring; fragment-major weights like 2500+); 0 on a bad descriptor.
+ * flags: bit 0 = `gate` will be non-NULL, bit 1 = `residual` will be non-NULL (the choice between the pointwise kernels and
+ * their tile sizes depend on both).  For profilers, benchmarks and the weight packing (w_frag). */
+int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags);
 
 /*
  * Depthwise convolution (groups = C), channels-last, fused scale/bias/activation; optionally also

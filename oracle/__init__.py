@@ -27,4 +27,4 @@ Pin status (DESIGN.md section "Oracle"):
   their published definitions and checked for self-consistency only.
 """
 
-from . import backbones, heads, losses, nets, push, receptive_field  # noqa: F401
+from . import backbones, heads, losses, nets, push, receptive_field, trainer  # noqa: F401

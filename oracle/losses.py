@@ -52,3 +52,91 @@ def transform_loss(x, occurrence_map, occurrence_map_of, angle, scale, loss_weig
     if reduction == "mean":
         loss = loss / (occ_t.shape[0] * occ_t.shape[1])
     return loss_weight * loss
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# The scalar loss terms of the reference's training step (src/loss/loss.py), restated as plain functions for oracle/trainer.py.
+# PINNED: tests/test_cpu_losses.py::test_oracle_loss_terms_match_reference_golden compares value and gradient of every one with
+# tests/golden/g6_losses.npz, which tests/golden/make_golden_losses.py produced by RUNNING the reference's classes here.
+# --------------------------------------------------------------------------------------------------------------------------
+def _zero(t):
+    return torch.tensor(0, device=t.device)  # loss.py:29,52,82,... the reference's zero-weight return value
+
+
+def ce_loss(logits, target, loss_weight=1, reduction="mean"):
+    """``CeLoss.compute`` (loss.py:23-34)."""
+    if loss_weight == 0:
+        return _zero(target)
+    return loss_weight * F.cross_entropy(logits, target, reduction=reduction)
+
+
+def ce_loss_abstain(logits, target, loss_weight=1, ab_weight=0.3, reduction="sum", ab_logitpath="joined"):
+    """``CeLossAbstain.compute`` (loss.py:323-371): the K+1-th logit is a learned abstention probability."""
+    if loss_weight == 0:
+        return _zero(target)
+    k = logits.shape[1] - 1
+    if ab_logitpath == "joined":
+        abstention = logits.softmax(dim=1)[:, k:k + 1]
+    else:
+        abstention = logits.sigmoid()[:, k:k + 1]
+    pred = logits[:, :k].softmax(dim=1)
+    virtual = (1 - abstention) * pred + abstention * F.one_hot(target, num_classes=k)
+    loss_pred = F.nll_loss(torch.log(virtual), target, reduction=reduction)
+    loss_abs = -torch.log(1 - abstention).squeeze()
+    if reduction == "mean":
+        loss_abs = loss_abs.mean()
+    elif reduction == "sum":
+        loss_abs = loss_abs.sum()
+    return loss_weight * (loss_pred + ab_weight * loss_abs)
+
+
+def _class_max(similarities, num_classes):
+    return similarities.reshape(similarities.shape[0], num_classes, -1).max(dim=2)[0]  # (N, classes): loss.py:127-129
+
+
+def _reduce(per_class, reduction):
+    return per_class.mean(dim=0).sum() if reduction == "mean" else per_class.sum()  # loss.py:134-137
+
+
+def cluster_roi_feat(similarities, target, loss_weight, num_classes=4, reduction="sum"):
+    """``ClusterRoiFeat.compute`` (loss.py:98-138)."""
+    if loss_weight == 0:
+        return _zero(target)
+    positives = _class_max(similarities, num_classes) * F.one_hot(target, num_classes=num_classes)
+    return loss_weight * _reduce(-1 * positives, reduction)
+
+
+def separation_roi_feat(similarities, target, loss_weight, num_classes=4, reduction="sum", abstain_class=True):
+    """``SeparationRoiFeat.compute`` (loss.py:141-183): the last class's prototypes are never penalised under ``abstain_class``."""
+    if loss_weight == 0:
+        return _zero(target)
+    one_hot = F.one_hot(target, num_classes=num_classes)
+    if abstain_class:
+        one_hot[:, -1] = 1
+    return loss_weight * _reduce(_class_max(similarities, num_classes) * (1 - one_hot), reduction)
+
+
+def orthogonality(prototype_vectors, loss_weight, num_classes=4, mode="per_class"):
+    """``OrthogonalityLoss.compute`` (loss.py:186-229)."""
+    if loss_weight == 0:
+        return _zero(prototype_vectors)
+    if mode == "per_class":
+        p = prototype_vectors.reshape(num_classes, -1, prototype_vectors.shape[1])
+        sim = F.cosine_similarity(p.unsqueeze(1), p.unsqueeze(2), dim=3)
+    else:
+        p = prototype_vectors.squeeze()
+        sim = F.cosine_similarity(p.unsqueeze(1), p.unsqueeze(0), dim=2)
+    return loss_weight * torch.triu(sim, diagonal=1).sum()
+
+
+def l_norm(tensor, dim=None, mask=None, p=1, loss_weight=1e-4, reduction="sum"):
+    """``L_norm.compute`` (loss.py:232-254)."""
+    if loss_weight == 0:
+        return _zero(tensor)
+    t = tensor if mask is None else mask.to(tensor.device) * tensor
+    loss = t.norm(p=p, dim=dim)
+    if reduction == "mean":
+        loss = loss.mean(dim=0).sum()
+    elif reduction == "sum":
+        loss = loss.sum()
+    return loss_weight * loss

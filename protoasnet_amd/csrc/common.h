@@ -61,6 +61,16 @@ int pw_xtile_ks(const pasn_conv_desc& d, int dtype);  // template k-steps of the
 template <typename T>
 int launch_pw_xtile(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                     void* y, const pasn_conv_desc& d, hipStream_t s);
+// pwconv_ws.hip: weight-stationary pointwise conv (bf16, fragment-major weights): persistent blocks, LDS-DMA stage ring; ok = 0: not covered
+struct WsGeom {
+    int ok, KS, MT, CT, PT, NW, gy, NS;    // template k-steps, 32-position sub-tiles per wave, waves along channels / positions, channel groups, stages
+    int rpb, nslots, abl;                  // rows (positions) per block, blocks per channel group, timing ablations (PASN_WS_ABL)
+    int xreg, greg, rreg, stage_bytes, lds_bytes;  // stage regions (X tile, gate rows, residual tile), whole KiB each
+};
+WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res);
+int pw_ws_variant(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res);  // 7000 + KS * 10 + MT, or 0
+int launch_pw_ws(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate, void* y,
+                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s);
 // x3d_front.hip: fused expand conv + depthwise stencil for small spatial planes (bf16).  ok = 0: not covered.
 struct XfrontGeom {
     int ok, ks, nT, ctiles, lds;

@@ -794,6 +794,8 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     PASN_REQUIRE(d->w_rows % 128 == 0 && d->w_rows >= d->Cout_p, "w_rows must be a multiple of 128 covering Cout_p");
     hipStream_t s = (hipStream_t)stream;
     PASN_REQUIRE(dtype == PASN_F32 || dtype == PASN_BF16, "unknown dtype");
+    if (const WsGeom wg = pw_ws_geom(*d, dtype, gate != nullptr, residual != nullptr); wg.ok)  // weight-stationary persistent blocks (bf16, fragment-major weights)
+        return launch_pw_ws(x, w, scale, bias, residual, gate, y, *d, wg, s);
     const bool xt_first = prefer_xtile(*d, dtype, gate != nullptr);
     const PwGeom pg = xt_first ? PwGeom{0, 0, 0, 0} : pw_geom(*d, dtype);  // 1x1x1 stride-1 convs: the row-streaming kernel
     PASN_REQUIRE(d->w_frag == 0 || (pw_xtile_applicable(*d, dtype) && !pg.TM),
@@ -831,8 +833,14 @@ extern "C" int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* 
     return launch_pw_xpair(x, w1, scale1, bias1, residual, gate, y1, *d1, w2, scale2, bias2, y2, *d2, (hipStream_t)stream);
 }
 
-extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int has_gate) {
+extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags) {
     if (!conv_desc_ok(d)) return 0;
+    const int has_gate = flags & 1, has_res = (flags >> 1) & 1;  // bit 0: an SE gate tensor is passed, bit 1: a residual is passed
+    {  // asked before the host has packed the weights: the weight-stationary kernel reads them fragment-major like the X-tile kernel
+        pasn_conv_desc df = *d;
+        df.w_frag = 1;
+        if (const int v = pw_ws_variant(df, dtype, has_gate != 0, has_res != 0)) return v;
+    }
     const PwGeom pg = prefer_xtile(*d, dtype, has_gate != 0) ? PwGeom{0, 0, 0, 0} : pw_geom(*d, dtype);
     if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
     if (pw_xtile_applicable(*d, dtype))               // pwconv_xtile_kernel<dtype, input transform?>

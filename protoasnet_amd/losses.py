@@ -63,8 +63,14 @@ class TransformLoss(object):
             return torch.tensor(0, device=x.device)
         cfg = config or get_affine_config()
         transformed_x = affine_warp(x, cfg["angle"], cfg["scale"])  # per-frame 2-D warp of (N,3,[T,]H,W)
-        occ_t = model.compute_occurence_map(transformed_x).squeeze(2)  # (N, P, [T',] H', W')
-        warped = affine_warp(occurrence_map.squeeze(2), cfg["angle"], cfg["scale"])
+        return self.compute_from_maps(occurrence_map, model.compute_occurence_map(transformed_x), cfg)
+
+    def compute_from_maps(self, occurrence_map, occurrence_map_transformed, config):
+        """loss.py:302-320 once both sets of maps exist: ``occurrence_map_transformed`` = the model's maps of the warped clip (the
+        caller may have produced them in the same pass as the originals: eval mode uses running statistics, so a 2N-clip batch of
+        [clips, warped clips] gives each clip exactly what two N-clip passes give)."""
+        occ_t = occurrence_map_transformed.squeeze(2)  # (N, P, [T',] H', W')
+        warped = affine_warp(occurrence_map.squeeze(2), config["angle"], config["scale"])
         loss = (occ_t - warped).abs().sum()
         if self.reduction == "mean":
             loss = loss / (occ_t.shape[0] * occ_t.shape[1])

@@ -111,6 +111,11 @@ class PlanBuilder:
         self.meta: List[dict] = []  # per launch: kernel instance name, algorithmic bytes and flops (DESIGN.md "Measurement")
         self.lib = _lib.lib()
         self.tname = "bf16" if dtype == torch.bfloat16 else "f32"
+        # arrival counters of the fused SE-gate launches, one [N] slice per launch, packed so that Plan.run clears them with ONE fill before
+        # the first launch (a launch that was aborted, or a replay that raced on a second stream, would otherwise leave a counter non-zero
+        # and every later gate of that layer stale: a Plan is single-stream, and self-healing)
+        self.se_counters: Optional[torch.Tensor] = None
+        self.se_counters_used = 0
 
     # ---- buffers ---------------------------------------------------------------------------------
     def _new_buf(self, nbytes: int, external: bool = False) -> int:
@@ -294,8 +299,8 @@ class PlanBuilder:
         a = (wp.data_ptr(), scale.data_ptr(), bias.data_ptr())
         xb, yb, rb, gb, dref = x.buf, y.buf, (residual.buf if residual is not None else None), in_gate, ctypes.byref(d)
         self._use(xb, yb, rb, gb)
-        variant = int(self.lib.pasn_conv3d_variant(dref, self.code, int(in_gate is not None)))
-        if 2500 <= variant < 6000:
+        variant = int(self.lib.pasn_conv3d_variant(dref, self.code, int(in_gate is not None) | (2 if residual is not None else 0)))
+        if 2500 <= variant < 6000 or variant >= 7000:
             # pwconv_xtile_kernel reads its weights as MFMA fragments: store them fragment-major, so a wave's fragment
             # load is one contiguous 1 KB run instead of a 32-row gather (the gather saturated the CU's address unit)
             kstep, ch = (16, 8) if self.dtype == torch.bfloat16 else (8, 4)
@@ -304,7 +309,8 @@ class PlanBuilder:
             a = (wf.data_ptr(), a[1], a[2])
             d.w_frag = 1
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", _igemm_name(variant - 6000) if variant >= 6000 else f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if 2500 <= variant < 6000 else
+        self._note("conv", f"pwconv_ws_kernel<{(variant - 7000) // 10},{variant % 10},{'true' if (in_gate is not None or in_swish) else 'false'},{'true' if residual is not None else 'false'}>" if variant >= 7000 else
+                   _igemm_name(variant - 6000) if variant >= 6000 else f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if 2500 <= variant < 6000 else
                    f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
                    f"pwconv_persist_kernel<{self.tname},{(variant - 1000) // 10},{variant % 10},{'true' if residual is not None else 'false'}>" if variant >= 1000 else
                    f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",
@@ -429,7 +435,11 @@ class PlanBuilder:
         b1 = fc1.bias.detach().float().contiguous()
         w2 = fc2.weight.detach().float().reshape(c, cse).contiguous()
         b2 = fc2.bias.detach().float().contiguous()
-        counter = torch.zeros(y.N, dtype=torch.int32, device=self.device)  # zero before the first launch; the kernel leaves it zero
+        if self.se_counters is None:
+            self.se_counters = torch.zeros(4096, dtype=torch.int32, device=self.device)
+        assert self.se_counters_used + y.N <= self.se_counters.numel(), "too many fused SE-gate launches for the counter block"
+        counter = self.se_counters[self.se_counters_used: self.se_counters_used + y.N]  # the kernel leaves it zero; Plan.run clears it anyway
+        self.se_counters_used += (y.N + 3) // 4 * 4
         self.keep += [wp, scale, bias, w1, b1, w2, b2, counter]
         pool_blocks = int(self.lib.pasn_dwconv3d_se_pool_blocks(ctypes.byref(d), self.code))
         pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4)
@@ -551,6 +561,7 @@ class Plan:
         self.dtype = pb.dtype
         self.arena_bytes = arena_bytes
         self.naive_bytes = sum(b.nbytes for b in pb.bufs if not b.external)
+        self.se_counters = pb.se_counters[: pb.se_counters_used] if pb.se_counters is not None else None
         self.arena = torch.empty(arena_bytes + ALIGN, dtype=torch.uint8, device=pb.device)
         base = round_up(self.arena.data_ptr(), ALIGN)
         self.ptrs = [0 if b.external else base + b.offset for b in pb.bufs]
@@ -564,6 +575,8 @@ class Plan:
         ptrs[self.in_buf] = x.data_ptr()
         ptrs[self.out_buf] = y.data_ptr()
         st = _lib.current_stream()
+        if self.se_counters is not None:
+            self.se_counters.zero_()  # one 16-byte-multiple fill on the launch stream (see PlanBuilder.__init__)
         if not timers:
             for op in self.ops:
                 op(ptrs, st)

@@ -129,6 +129,12 @@ def _iter_shard(dataloader, rank: int, world_size: int):
     n = len(dataloader)
     mine = shard_batches(n, rank, world_size)
     if isinstance(dataloader, torch.utils.data.DataLoader) and dataloader.batch_sampler is not None:
+        inner = getattr(dataloader.batch_sampler, "sampler", None)
+        if world_size > 1 and inner is not None and not isinstance(inner, torch.utils.data.SequentialSampler):
+            # every rank iterates the batch sampler on its own: a random sampler would hand each rank a different permutation, the
+            # contiguous shards would overlap / miss clips and the global indices would not name the same clips across ranks
+            raise ValueError("sharded push needs a push loader with a SequentialSampler (shuffle=False, as the reference's push loader is); "
+                             f"got {type(inner).__name__}")
         index_lists = [list(b) for b in dataloader.batch_sampler]
         offsets = np.concatenate([[0], np.cumsum([len(b) for b in index_lists])])
         sub = torch.utils.data.DataLoader(dataloader.dataset, batch_sampler=index_lists[mine.start:mine.stop],

@@ -23,7 +23,15 @@ What it changes, because it has to scale:
   (``Video_XProtoNet_e2e.py:112-135,143-153``); here predictions feed a confusion matrix that stays on the device, the loss terms
   accumulate in a device vector, and both come to the host once per epoch (after one tiny all-reduce across ranks, so every rank
   takes the same scheduler / best-model decisions);
-* ``TransformLoss`` is skipped when its ``loss_weight`` is 0 (the reference still pays its second trunk pass for a zero term).
+* ``TransformLoss`` is skipped when its ``loss_weight`` is 0 (the reference returns before the second trunk pass too: loss.py:284);
+  in ``val`` / ``val_push`` epochs -- where the reference computes the term as well (``Video_XProtoNet_e2e.py:72,98``) -- the warped clips
+  ride in the SAME forward as the originals (one 2N-clip launch list; exact in eval mode, where the norm layers use running statistics);
+* **every rank holds the same model**: parameters and buffers are broadcast from rank 0 at construction; the norm layers' running
+  estimates (updated per rank from its own micro-batches, as under plain BatchNorm) are averaged over the ranks before every
+  evaluation epoch, push and checkpoint, so all ranks evaluate, project and save ONE model;
+* every rank must bring the same number of micro-batches per epoch (checked with one MIN/MAX all-reduce at the start of the epoch: a
+  rank with fewer would issue fewer gradient all-reduces and hang the job); gradients of a trailing partial accumulation are kept
+  across the epoch boundary, as the reference keeps them (it never zeroes at the start of an epoch).
 
 Out of scope: wandb / CSV logging, AUC, the diversity counters with their hard-coded ``[:30]`` split, plots.
 """
@@ -80,6 +88,47 @@ class DPTrainer:
         self.get_optimizer()
         self.scheduler = self.get_lr_scheduler()
         self.params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        self.sync_model_state()  # ranks built from different seeds / checkpoints would otherwise stay different models for ever
+
+    # ---- one model on every rank ------------------------------------------------------------------------------------------------
+    def sync_model_state(self) -> None:
+        """Broadcast every parameter and buffer from rank 0 (what DistributedDataParallel does at construction)."""
+        if self.world_size <= 1:
+            return
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                buf = push_mod._for_collective(t.detach())
+                dist.broadcast(buf, src=0)
+                if buf is not t:
+                    t.copy_(buf.to(t.device))
+        if hasattr(self.model, "cnn_backbone") and hasattr(self.model.cnn_backbone, "invalidate_plans"):
+            self.model.cnn_backbone.invalidate_plans()  # copy_ bumps the version counters too; this is belt and braces
+
+    def sync_norm_buffers(self) -> None:
+        """Average the floating-point buffers (norm running means / variances) over the ranks and take the largest batch counter:
+        each rank's estimates saw only its own micro-batches; evaluation, push and the checkpoint must use ONE model."""
+        if self.world_size <= 1:
+            return
+        bufs = [b for b in self.model.buffers()]
+        fl = [b for b in bufs if b.is_floating_point()]
+        it = [b for b in bufs if not b.is_floating_point()]
+        with torch.no_grad():
+            if fl:
+                flat = push_mod._for_collective(torch.cat([b.detach().float().flatten() for b in fl]))
+                dist.all_reduce(flat)
+                flat = (flat / self.world_size).to(self.device)
+                o = 0
+                for b in fl:
+                    b.copy_(flat[o:o + b.numel()].view_as(b).to(b.dtype))
+                    o += b.numel()
+            if it:
+                flat = push_mod._for_collective(torch.cat([b.detach().flatten().to(torch.int64) for b in it]))
+                dist.all_reduce(flat, op=dist.ReduceOp.MAX)
+                flat = flat.to(self.device)
+                o = 0
+                for b in it:
+                    b.copy_(flat[o:o + b.numel()].view_as(b).to(b.dtype))
+                    o += b.numel()
 
     # ---- reference surface: XProtoNet_Base.py:54-81 ---------------------------------------------------------------------------
     def get_criterion(self) -> None:
@@ -128,7 +177,10 @@ class DPTrainer:
                 "optimizer": self.optimizer.state_dict()}
 
     def save_checkpoint(self, is_best: bool = False) -> None:
-        if not self.train_config.get("save", True) or self.rank != 0:
+        if not self.train_config.get("save", True):
+            return
+        self.sync_norm_buffers()  # a collective: every rank takes part before rank 0 writes
+        if self.rank != 0:
             return
         state, d = self.get_state(), self.config["save_dir"]
         os.makedirs(d, exist_ok=True)
@@ -151,7 +203,7 @@ class DPTrainer:
         return True
 
     # ---- Video_XProtoNet_e2e.py:36-361, minus the per-batch host work ------------------------------------------------------------
-    def compute_loss(self, inp, target, logit, similarities, occurrence_map):
+    def compute_loss(self, inp, target, logit, similarities, occurrence_map, occurrence_map_transformed=None, affine_config=None):
         terms = [
             self.CeLoss.compute(logits=logit, target=target),
             self.Cluster.compute(similarities, target),
@@ -159,10 +211,12 @@ class DPTrainer:
             self.Orthogonality.compute(self.model.prototype_vectors),
             self.Lnorm_occurrence.compute(occurrence_map, dim=(-3, -2, -1) if occurrence_map.dim() == 6 else (-2, -1)),
         ]
-        if self.Trans_occurrence.loss_weight != 0 and self.model.training:
-            terms.append(self.Trans_occurrence.compute(inp, occurrence_map, self.model))
-        else:  # a zero-weight term: the reference still runs the second trunk pass for it (loss.py:302)
+        if self.Trans_occurrence.loss_weight == 0:
             terms.append(torch.zeros((), device=logit.device))
+        elif occurrence_map_transformed is not None:  # eval epochs: the warped clips rode in the same forward (run_epoch)
+            terms.append(self.Trans_occurrence.compute_from_maps(occurrence_map, occurrence_map_transformed, affine_config))
+        else:
+            terms.append(self.Trans_occurrence.compute(inp, occurrence_map, self.model))
         terms.append(self.Lnorm_fc.compute(self.model.last_layer.weight))
         return sum(terms), torch.stack([t.detach().float().reshape(()) for t in terms])
 
@@ -173,14 +227,31 @@ class DPTrainer:
         cm = torch.zeros(K * K, dtype=torch.int64, device=self.device)
         loss_sum = torch.zeros(7, dtype=torch.float32, device=self.device)
         n_batches = 0
-        if mode == "train":
-            self.optimizer.zero_grad(set_to_none=True)
+        if self.world_size > 1:
+            if hasattr(loader, "__len__"):  # a rank with fewer micro-batches would issue fewer collectives: the job would hang in RCCL
+                n = torch.tensor([len(loader), -len(loader)], dtype=torch.int64, device=self.device)
+                n = push_mod._for_collective(n)
+                dist.all_reduce(n, op=dist.ReduceOp.MAX)
+                if int(n[0]) != -int(n[1]):
+                    raise RuntimeError(f"{mode} epoch {epoch}: the ranks' loaders hold between {-int(n[1])} and {int(n[0])} batches; every rank "
+                                       "must bring the same number (shard with a DistributedSampler(drop_last=True) or equal file lists)")
+            if mode != "train":
+                self.sync_norm_buffers()
+        warp_in_batch = mode != "train" and self.Trans_occurrence.loss_weight != 0
         with torch.set_grad_enabled(mode == "train"):
             for i, sample in enumerate(loader):
                 inp = sample["cine"].to(self.device, non_blocking=True)
                 target = sample["target_AS"].to(self.device, non_blocking=True)
-                logit, similarities, occurrence_map = self.model(inp)
-                loss, terms = self.compute_loss(inp, target, logit, similarities, occurrence_map)
+                if warp_in_batch:  # the reference's second trunk pass (loss.py:302) shares the launch list of the first
+                    cfg = losses.get_affine_config()
+                    nb = inp.shape[0]
+                    logit, similarities, occurrence_map = self.model(torch.cat([inp, losses.affine_warp(inp, cfg["angle"], cfg["scale"])]))
+                    occ_t = occurrence_map[nb:]
+                    logit, similarities, occurrence_map = logit[:nb], similarities[:nb], occurrence_map[:nb]
+                    loss, terms = self.compute_loss(inp, target, logit, similarities, occurrence_map, occ_t, cfg)
+                else:
+                    logit, similarities, occurrence_map = self.model(inp)
+                    loss, terms = self.compute_loss(inp, target, logit, similarities, occurrence_map)
                 pred = logit[:, :K].argmax(dim=1)  # softmax is monotone: the class of the largest real-class logit
                 cm += torch.bincount(target.clamp(0, K - 1) * K + pred, minlength=K * K)
                 loss_sum += terms
@@ -206,6 +277,7 @@ class DPTrainer:
 
     def push(self, replace_prototypes: bool = True):
         abstain = bool(self.config.get("abstain_class"))
+        self.sync_norm_buffers()  # every shard of the sweep must see the same eval-mode statistics
         return push_mod.push_prototypes(
             self.data_loaders["train_push"], self.model, class_specific=True, abstain_class=abstain,
             root_dir_for_saving_prototypes=self.config.get("save_dir") and os.path.join(self.config["save_dir"], "img"),

@@ -138,3 +138,53 @@ def test_optimizer_groups_scheduler_and_checkpoint_follow_the_reference(tmp_path
     assert m["accuracy"] == pytest.approx((2 / 3 + 1) / 2) and m["f1"] == pytest.approx([0.8, 6 / 7, 0.0])
     with pytest.raises(ValueError, match="multiple of the world size"):
         DPTrainer(Toy(), {"abstain_class": True, "save_dir": "", "train": dict(TRAIN_CFG, accumulation_steps=3)}, {}, world_size=2)
+
+
+def test_oracle_reference_trainer_step_semantics():
+    """``oracle.trainer.ReferenceTrainer`` (the checker of the GPU trainer-parity test) against the semantics of the reference step spelled
+    out by hand: the losses of the ``accumulation_steps`` micro-batches are summed UNDIVIDED (Video_XProtoNet_e2e.py:99-107,137-141), the
+    trunk / add-on / occurrence-module groups carry ``weight_decay=1e-3``, prototypes and last layer none (XProtoNet_e2e.py:38-62), the
+    transform term draws one affine configuration per micro-batch (loss.py:257-269, 283-320), and norm statistics move twice per micro-batch
+    (forward + ``compute_occurence_map`` of the warped clip).  X3D-S + head B on two tiny clips, SGD so that the update IS the gradient."""
+    import random
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle
+    from protoasnet_amd import synth
+    from util import CFG_VIDEO_X3D, synth_model
+
+    m = synth_model(CFG_VIDEO_X3D)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    lr = {"cnn_backbone": 1e-3, "add_on_layers": 3e-3, "occurrence_module": 3e-3, "prototype_vectors": 3e-3, "last_layer": 1e-5}
+    tc = dict(TRAIN_CFG, accumulation_steps=2, optimizer={"name": "SGD", "mode": "lr_disjoint", "lr_disjoint": lr})
+    tc["criterion"] = dict(tc["criterion"], trans_occurrence={"loss_weight": 1e-2, "reduction": "mean"})
+    batches = [{"cine": synth.echo_clips((2, 3, 4, 64, 64), seed=10 + b), "target_AS": (torch.arange(2) + b) % 3} for b in range(2)]
+    ref = oracle.trainer.ReferenceTrainer(sd0, tc, arch="x3d_s", num_classes=3)
+    random.seed(5)
+    out = ref.run_epoch(batches, "train")
+    assert ref.iteration == 2 and float(out["loss_terms_sum"][5]) > 0
+
+    # by hand: gradients of loss(batch 0) + loss(batch 1), statistics carried from one pass to the next, one SGD step
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k and k != "ones" else v.clone()) for k, v in sd0.items()}
+    random.seed(5)
+    helper = oracle.trainer.ReferenceTrainer(sd0, tc, arch="x3d_s", num_classes=3)
+    helper.sd = sd
+    total = 0
+    for b in batches:
+        o = oracle.nets.xprotonet_train_forward(sd, b["cine"], "x3d_s")
+        total = total + sum(helper.loss_terms(b["cine"], b["target_AS"], o, True))
+    total.backward()
+    for k, p0 in sd0.items():
+        if not p0.is_floating_point():
+            continue  # num_batches_tracked: the functional oracle does not keep the counter (momentum is fixed, nothing reads it)
+        if "running_" in k:
+            assert torch.allclose(ref.sd[k], sd[k], rtol=1e-6, atol=1e-7), k
+            continue
+        if k == "ones":
+            assert torch.equal(ref.sd[k], p0)
+            continue
+        group = next(g for g in lr if k.startswith(g))
+        wd = 1e-3 if group in ("cnn_backbone", "add_on_layers", "occurrence_module") else 0.0
+        want = p0 - lr[group] * (sd[k].grad + wd * p0)
+        assert torch.allclose(ref.sd[k].detach(), want, rtol=1e-5, atol=1e-8), k

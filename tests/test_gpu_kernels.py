@@ -281,6 +281,102 @@ def test_conv_pair_chained(c0, c1, c2, gate, monkeypatch):
             assert float(o[..., c:].float().abs().max()) == 0.0, "padded channels must stay zero"
 
 
+WS_CASES = [
+    # cin, cout, (N, T, H, W), residual, gate+swish, activation -- weight-stationary pointwise kernel (pwconv_ws.hip): every template k-step count,
+    # both sub-tile counts, every (channel waves, position waves) split; M never a multiple of the block tile, clips shorter than two tiles so
+    # that tiles straddle clips (two staged gate rows), blocks that walk several tiles (PASN_WS_BPC=1 + small tiles in the second pass)
+    (48, 108, (3, 3, 9, 11), False, False, "relu"),    # KS 4, CT 4 x PT 2, MT 2, padded output channels (108 -> 112)
+    (108, 48, (3, 3, 9, 11), True, True, "relu"),      # KS 8, CT 2 x PT 4, MT 1, gate + residual, half-empty second channel tile
+    (108, 48, (3, 3, 9, 11), True, False, "relu"),     # ... without the input transform
+    (96, 216, (2, 5, 7, 9), False, False, "relu"),     # KS 6, CT 7
+    (216, 96, (3, 3, 8, 9), True, True, "relu"),       # KS 14, CT 3 x PT 2, MT 2
+    (216, 96, (3, 3, 8, 9), True, False, "none"),
+    (192, 432, (2, 4, 7, 7), False, False, "relu"),    # KS 12, 14 channel tiles in two groups of CT 7
+    (432, 192, (3, 4, 7, 7), True, True, "relu"),      # KS 28, CT 6, MT 1
+    (432, 192, (3, 4, 7, 7), True, False, "relu"),
+    (192, 256, (2, 4, 7, 7), False, False, "relu"),    # head B: CT 8
+    (256, 256, (2, 4, 7, 7), False, False, "none"),    # KS 16
+    (256, 128, (2, 4, 7, 7), False, False, "relu"),    # CT 4 x PT 2
+    (128, 30, (2, 8, 7, 7), False, False, "abs"),      # one channel tile: CT 1 x PT 8, 30 -> 32 padded channels
+    (56, 24, (2, 4, 12, 12), True, True, "relu"),      # stage-2 shape class (Cin_p 56)
+    (216, 96, (3, 3, 8, 9), False, True, "sigmoid"),   # Swish input without residual; sigmoid(0) != 0: the padded-channel mask must act
+]
+
+
+@pytest.mark.parametrize("shrink", [False, True])
+@pytest.mark.parametrize("case", WS_CASES)
+def test_pwconv_ws(case, shrink, monkeypatch):
+    """Weight-stationary persistent pointwise kernel: against torch on the bf16-rounded operands AND bit-for-bit against the X-tile /
+    persistent kernels it replaces (same MFMA k order, same epilogue arithmetic)."""
+    cin, cout, (n, t, h, w), use_res, gate, act = case
+    dtype = torch.bfloat16
+    torch.manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, t, h, w)
+    g = torch.rand(n, cin) + 0.25 if gate else None
+    conv = nn.Conv3d(cin, cout, 1, bias=False)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    xin = _rt(x, dtype)
+    if gate:
+        xin = xin * g[:, :, None, None, None]
+        xin = _rt(xin * torch.sigmoid(xin), dtype)
+    ref = bn(F.conv3d(xin, _rt(conv.weight.data, dtype)))
+    res = torch.randn(n, cout, t, h, w) if use_res else None
+    if res is not None:
+        ref = ref + _rt(res, dtype)
+    ref = {"relu": F.relu, "none": lambda v: v, "sigmoid": torch.sigmoid, "abs": torch.abs}[act](ref).detach()
+    conv, bn = conv.to(DEV), bn.to(DEV)
+
+    from protoasnet_amd.plan import round_up
+
+    def run(ws: bool):
+        monkeypatch.setenv("PASN_WS", "1" if ws else "0")
+        if ws and shrink:  # one block per CU slot and the smallest tiles: blocks walk several tiles, the stage ring wraps
+            monkeypatch.setenv("PASN_WS_BPC", "1")
+            monkeypatch.setenv("PASN_WS_MT", "1")
+            monkeypatch.setenv("PASN_WS_NS", "2")
+        pb = _pb(dtype)
+        xa, xs = _cl_input(pb, x, dtype)
+        ra = rs = gbuf = gt = None
+        if res is not None:
+            ra, rs = _cl_input(pb, res, dtype)
+        if gate:
+            gt = torch.zeros(n, round_up(cin, 8), dtype=torch.float32, device=DEV)
+            gt[:, :cin] = g.to(DEV)
+            gbuf = pb._new_buf(gt.numel() * 4, external=True)
+        y = pb.conv(xa, conv, bn, act, residual=ra, in_gate=gbuf, in_swish=gate)
+        name = pb.meta[-1]["kernel"]
+        plan = pb.finish(xa, y)
+        if ra is not None:
+            plan.ptrs[ra.buf] = rs.data_ptr()
+        if gate:
+            plan.ptrs[gbuf] = gt.data_ptr()
+        out = plan.run(xs)
+        torch.cuda.synchronize()
+        for k in ("PASN_WS", "PASN_WS_BPC", "PASN_WS_MT", "PASN_WS_NS"):
+            monkeypatch.delenv(k, raising=False)
+        return out, name
+
+    out, name = run(True)
+    assert name.startswith("pwconv_ws_kernel"), name
+    old, old_name = run(False)
+    assert not old_name.startswith("pwconv_ws_kernel"), old_name
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, cout), ref, 3e-2 * scale, 2e-2, f"ws conv {case}")
+    if "xtile" in old_name:  # identical arithmetic: the k order of the MFMA chain and the fp32 epilogue are the same
+        assert torch.equal(out, old), f"ws vs {old_name}: max diff {float((out.float() - old.float()).abs().max())}"
+    else:
+        assert_close(_from_cl(out, cout), _from_cl(old, cout), 1.6e-2 * scale, 1e-2, f"ws vs {old_name} {case}")
+    if out.shape[-1] > cout:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
 HALO_CASES = [
     # cin, cout, k, p, (N, T, H, W), act, residual -- stride-1 "same" convs of R(2+1)D-18 / ResNet-18 (igemm_halo.hip)
     (64, 144, (1, 3, 3), (0, 1, 1), (2, 3, 9, 11), "relu", False),    # spatial taps, 160-channel tile, tiles straddle rows / frames / clips

@@ -8,6 +8,9 @@ from protoasnet_amd import synth
 from util import (CFG_PPNET, CFG_PPNET_BOTTLENECK, CFG_VIDEO_R2P1D, CFG_VIDEO_X3D, CFG_XPROTO, synth_model)
 
 pytestmark = pytest.mark.gpu
+# bf16 (activations / weights, fp32 accumulation) against the fp32 oracle, whole model: max |similarity| error, max |logit| error, mean relative
+# occurrence-map error.  Observed 1.2e-4 .. 2.9e-4 / 1.3e-4 .. 4e-4 / <= 9e-3 (round 2); fp32 stays the <= 1e-3 parity path.
+BF16_SIM, BF16_LOGITS, BF16_OCC_REL = 2e-3, 2e-2, 2e-2
 DEV = "cuda"
 
 
@@ -87,10 +90,12 @@ def test_bf16_compute_tolerance(cfg, shape):
     with torch.no_grad():
         logits, sim, occ = m(x.to(DEV))
     assert logits.dtype == torch.float32 and sim.dtype == torch.float32
-    assert_close(sim, ref["similarity"], 2e-2, 0, "bf16 similarity")
-    assert_close(logits, ref["logits"], 0.25, 0.05, "bf16 logits")
+    # gates ~5-10x the observed error (similarity 1.4e-4 .. 2.9e-4, logits 2.4e-4 .. 4e-4: profiles/r02_parity_observed_errors.tsv), so that a
+    # kernel regression worth 1e-2 in a similarity fails
+    assert_close(sim, ref["similarity"], BF16_SIM, 0, "bf16 similarity")
+    assert_close(logits, ref["logits"], BF16_LOGITS, 0, "bf16 logits")
     rel = (occ.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()
-    assert float(rel) < 0.05, f"bf16 occurrence map mean relative error {float(rel):.3g}"
+    assert float(rel) < BF16_OCC_REL, f"bf16 occurrence map mean relative error {float(rel):.3g}"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -108,10 +113,10 @@ def test_x3d_production_routes_vs_oracle(dtype):
         kernels = {meta["kernel"].split("<")[0] for meta in m.cnn_backbone.plan_for(x.to(DEV).to(dtype)).meta}
     if dtype == torch.bfloat16:
         assert {"x3d_stem_mfma_kernel", "dwconv3d_march_kernel", "pwconv_xtile_kernel", "pwconv_persist_kernel"} <= kernels, kernels
-        assert_close(sim, ref["similarity"], 2e-2, 0, "bf16 similarity")
-        assert_close(logits, ref["logits"], 0.25, 0.05, "bf16 logits")
+        assert_close(sim, ref["similarity"], BF16_SIM, 0, "bf16 similarity")
+        assert_close(logits, ref["logits"], BF16_LOGITS, 0, "bf16 logits")
         rel = (occ.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()
-        assert float(rel) < 0.05, f"bf16 occurrence map mean relative error {float(rel):.3g}"
+        assert float(rel) < BF16_OCC_REL, f"bf16 occurrence map mean relative error {float(rel):.3g}"
     else:
         assert_close(occ, ref["occurrence_map"], 1e-3 * max(1.0, float(ref["occurrence_map"].max())), 1e-3, "occurrence_map")
         assert_close(sim, ref["similarity"], 1e-3, 0, "similarity")
@@ -142,9 +147,9 @@ def test_cfg5_x3d_m_312_p60_fp32_vs_bf16_tolerance_table():
     with torch.no_grad():
         logits16, sim16, occ16 = m(x.to(DEV).bfloat16())
     table = {  # quantity: (bf16 vs fp32-oracle error, bound)
-        "similarity max abs": (float((sim16.cpu() - ref["similarity"]).abs().max()), 2e-2),
-        "logits max abs": (float((logits16.cpu() - ref["logits"]).abs().max()), 0.25),
-        "occurrence map mean rel": (float((occ16.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()), 0.05),
+        "similarity max abs": (float((sim16.cpu() - ref["similarity"]).abs().max()), BF16_SIM),
+        "logits max abs": (float((logits16.cpu() - ref["logits"]).abs().max()), BF16_LOGITS),
+        "occurrence map mean rel": (float((occ16.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()), BF16_OCC_REL),
         "fp32 similarity max abs": (float((sim.cpu() - ref["similarity"]).abs().max()), 1e-3),
     }
     print("cfg5 tolerance table:", {k: f"{v[0]:.3g} (<= {v[1]:g})" for k, v in table.items()})
@@ -170,8 +175,10 @@ def test_cfg2_full_shape_vs_oracle(dtype):
         assert_close(logits, ref["logits"], 1e-3, 0, "cfg2 fp32 logits")
         assert_close(occ, ref["occurrence_map"], 1e-3 * max(1.0, float(ref["occurrence_map"].max())), 1e-3, "cfg2 fp32 occurrence_map")
     else:
-        assert_close(sim, ref["similarity"], 2e-2, 0, "cfg2 bf16 similarity")
-        assert_close(logits, ref["logits"], 0.25, 0.05, "cfg2 bf16 logits")
+        assert_close(sim, ref["similarity"], BF16_SIM, 0, "cfg2 bf16 similarity")
+        assert_close(logits, ref["logits"], BF16_LOGITS, 0, "cfg2 bf16 logits")
+        rel = (occ.cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()
+        assert float(rel) < BF16_OCC_REL, f"cfg2 bf16 occurrence map mean relative error {float(rel):.3g}"
 
 
 def test_module_surface_and_errors():
@@ -258,6 +265,13 @@ def test_grey_input_pipeline_equals_three_channel_path(cfg, shape):
         scale = max(1.0, float(a.abs().max()))
         assert_close(b, a, 2e-6 * scale, 2e-6, f"grey+device-normalised {name}")
         assert_close(c, a, 1e-6 * scale, 1e-6, f"grey pre-normalised {name}")
+    # ... and against the ORACLE run on the reference's expanded, host-normalised 3-channel clip (as_dataloader.py:168-182,217-222): the
+    # grey path is anchored on the reference's op sequence, not on this repo's own 3-channel kernels
+    ref = oracle.nets.xprotonet_forward({k: v.cpu() for k, v in m.state_dict().items()}, x3, arch=cfg["base_architecture"])
+    for name, b, c in zip(("logits", "similarity", "occurrence_map"), got, got_n):
+        scale = max(1.0, float(ref[name].abs().max()))
+        assert_close(b, ref[name], 1e-3 * scale, 1e-3, f"grey+device-normalised {name} vs oracle")
+        assert_close(c, ref[name], 1e-3 * scale, 1e-3, f"grey pre-normalised {name} vs oracle")
     kernels = [meta["kernel"] for meta in m.cnn_backbone.plan_for(pipe_n(bin_to_norm(u))).meta]
     assert "grey" in kernels[0], kernels[0]
     # uint8 clips (what a cine is on disk): quantise, compare with the float path fed the same quantised values
@@ -267,6 +281,10 @@ def test_grey_input_pipeline_equals_three_channel_path(cfg, shape):
         got8 = m(DeviceClipPipeline(m, normalize=True)(u8))
     for name, a, b in zip(("logits", "similarity"), want8, got8):
         assert_close(b, a, 5e-6 * max(1.0, float(a.abs().max())), 5e-6, f"uint8 {name}")
+    ref8 = oracle.nets.xprotonet_forward({k: v.cpu() for k, v in m.state_dict().items()},
+                                         torch.stack([gray_to_gray3(bin_to_norm(c.float() / 255)) for c in u8]).float(), arch=cfg["base_architecture"])
+    for name, b in zip(("logits", "similarity"), got8):
+        assert_close(b, ref8[name], 1e-3 * max(1.0, float(ref8[name].abs().max())), 1e-3, f"uint8 {name} vs oracle")
     # the 3-channel path is untouched by the trunk's input normalisation setting
     with torch.no_grad():
         again = m(x3.to(DEV))

@@ -888,6 +888,49 @@ def test_video_x3d_train_unmodified_model_vs_oracle():
     assert cos > 0.98 and median < 5e-2, f"gradient direction cosine {cos:.4f}, median per-tensor error {median:.2e}; worst {rows[:3]}"
 
 
+@pytest.mark.timeout(900)
+def test_video_x3d_train_unmodified_model_strict_where_the_oracle_itself_is_stable():
+    """Strict gradient parity on the model AS BUILT (no bias shift).  A ReLU pre-activation within rounding distance of zero flips its mask
+    between two fp32 implementations, and one flipped element moves whole gradient tensors -- so the kink-affected tensors are identified by
+    the ORACLE'S OWN sensitivity: the same oracle pass in fp64 against fp32.  A tensor on which those two agree (<= 2e-4 of its scale) carries
+    no flipped mask on the oracle side and must match the HIP gradient to <= 1e-3; a tensor on which they disagree is reported and skipped.
+    The clips are 8 x 128 x 128 (24 576 stem positions per clip instead of 4 096) so that single flips are diluted and the stable set is
+    the large majority."""
+    m = _train_model(kink_free=False)
+    shape, spatial = (3, 3, 8, 128, 128), (8, 4, 4)
+    x = synth.echo_clips(shape)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    wl, ws, wo = _loss_weights(3, 30, 3, spatial)
+    logits, sim, occ = m(x.to(DEV))
+    ((logits * wl.to(DEV)).sum() + (sim * ws.to(DEV)).sum() + (occ * wo.to(DEV)).sum()).backward()
+    ref, sd32, _ = _oracle_step(sd0, x, wl, ws, wo)
+    sd0_64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd0.items()}
+    _, sd64, _ = _oracle_step(sd0_64, x.double(), wl.double(), ws.double(), wo.double())
+    _rel(logits, ref["logits"], 1e-3, "logits")
+    _rel(sim, ref["similarity"], 1e-3, "similarity")
+    _rel(occ, ref["occurrence_map"], 1e-3, "occurrence_map")
+    stable, unstable, failures = [], [], []
+    for name, p in m.named_parameters():
+        if name == "ones":
+            continue
+        g32, g64 = sd32[name].grad, sd64[name].grad.float()
+        scale = float(g64.abs().max()) + 1e-12
+        sib = sd64.get(name[:-4] + "weight") if name.endswith(".bias") else None
+        if sib is not None and sib.grad is not None and sib.shape == g64.shape:
+            scale = max(scale, float(sib.grad.abs().max()))  # dbeta lives on the scale of its sibling dgamma (see _grad_errors)
+        if float((g32 - g64).abs().max()) / scale > 2e-4:
+            unstable.append(name)
+            continue
+        stable.append(name)
+        err = float((p.grad.cpu() - g64).abs().max()) / scale
+        if err > 1e-3:
+            failures.append((err, name))
+    print(f"strict gradient test: {len(stable)} stable tensors, {len(unstable)} kink-affected in the oracle itself: {unstable[:6]}")
+    assert len(stable) >= 0.8 * (len(stable) + len(unstable)), f"only {len(stable)} of {len(stable) + len(unstable)} tensors are stable in the oracle"
+    failures.sort(reverse=True)
+    assert not failures, "HIP gradients differ on tensors the oracle is stable on: " + ", ".join(f"{n} {e:.2e}" for e, n in failures[:8])
+
+
 @pytest.mark.parametrize("cfg,shape,spatial,env", [(CFG_VIDEO_X3D, SHAPE, SPATIAL, ""), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_DW_DGRAD_REDUCE"),
                                                    (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_DW_STATS"), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_SE_ANALYTIC"),
                                                    (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_NO_PACK"),
