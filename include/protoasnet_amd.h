@@ -147,6 +147,33 @@ int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* scale1, con
                          const float* gate, void* y1, const pasn_conv_desc* d1, const void* w2, const float* scale2,
                          const float* bias2, void* y2, const pasn_conv_desc* d2, int dtype, void* stream);
 
+/*
+ * pasn_conv3d_fwd with the squeeze-excite gate of its input transform computed IN THE SAME LAUNCH (bf16, fragment-major weights): every
+ * block derives the gate rows of the (at most two) clips its rows touch from the stencil's pool partial rows -- mean over positions,
+ * fc1 + ReLU, fc2 + sigmoid, as pasn_se_gate_fwd -- while its first tiles are in flight, then x' = swish(x * gate) as usual.  Replaces the
+ * stand-alone pasn_se_gate_fwd launch between the stencil and the project conv of an X3D SE block (and the gate tensor).
+ *   pool_partial : fp32 [N][pool_blocks][Cin_p] (pasn_dwconv3d_fwd's partial sums), positions = T*H*W of the pooled tensor
+ *   fc1_w : fp32 [Cse][Cin], fc1_b : [Cse], fc2_w : [Cin][Cse], fc2_b : [Cin];  d->in_swish says whether Swish follows the gate
+ * _supported() = 0: call pasn_se_gate_fwd + pasn_conv3d_fwd.
+ */
+int pasn_conv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse, int has_residual);
+int pasn_conv3d_se_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
+                       const float* pool_partial, int pool_blocks, int positions, const float* fc1_w, const float* fc1_b,
+                       const float* fc2_w, const float* fc2_b, int Cse, void* y, const pasn_conv_desc* d, int dtype, void* stream);
+
+/*
+ * A 1x1x1 stride-1 conv + norm with the block's STRIDED 1x1x1 shortcut conv + norm accumulated in the same launch (bf16; the first
+ * project conv of an X3D stage, whose residual is the strided shortcut of the block input):
+ *     y = act(scale * (w . x') + scale2 * (w2 . x2[strided position]) + bias),   x' = swish(x * gate) as in pasn_conv3d_fwd,
+ * bias = the two norms' shifts, summed by the caller.  d = the stride-1 conv, d2 = the shortcut conv (same N, To, Ho, Wo, Cout_p;
+ * kt = kh = kw = 1, st = 1, any sh / sw; row-major weights).  Replaces the pair of launches pasn_conv3d_fwd(shortcut) ->
+ * pasn_conv3d_fwd(project, residual = shortcut) and the shortcut tensor between them.  _supported() = 0: use that pair.
+ */
+int pasn_conv3d_short_supported(const pasn_conv_desc* d, const pasn_conv_desc* d2, int dtype);
+int pasn_conv3d_short_fwd(const void* x, const void* w, const float* scale, const float* bias, const float* gate, const void* x2,
+                          const void* w2, const float* scale2, void* y, const pasn_conv_desc* d, const pasn_conv_desc* d2, int dtype,
+                          void* stream);
+
 /* Which kernel instance pasn_conv3d_fwd picks for this geometry: 1000 + KS*10 + NT = pwconv_persist_kernel<dtype, KS, NT>
  * (1x1x1 stride-1 convs whose weights fit 64 VGPRs per lane); 2500 + 2*KS (+1 with in_swish) = pwconv_xtile_kernel<dtype, KS, ..>
  * (1x1x1 stride-1 convs with Cin_p >= 64: whole-K position tiles in LDS); 2000 / 2001 = gemm_conv_kernel<dtype, pointwise /
@@ -180,29 +207,6 @@ int pasn_dwconv3d_se_fwd(const void* x, const float* w, const float* scale, cons
                          const float* fc2_b, int Cse, float* gate, int32_t* counter, void* stream);
 int pasn_dwconv3d_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y,
                       float* pool_partial, const pasn_conv_desc* d, int dtype, void* stream);
-
-/*
- * Fused front half of an X3D bottleneck: 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 (stride (1,s,s), pad 1)
- * + BN (+ Swish) (+ squeeze-excite partial sums) in ONE launch; the 2.25x-wide expanded activation lives only in an
- * LDS ring while a block marches along T.  Same arithmetic as pasn_conv3d_fwd followed by pasn_dwconv3d_fwd (the
- * expanded activation is rounded to `dtype` in between, exactly as the unfused pair does).
- *   d      : geometry of the DEPTHWISE conv (kt=kh=kw=3, st=1, sh=sw in {1,2}, pads 1) with Cin/Cin_p = channels of x
- *            (the block input), Cout/Cout_p = inner (expanded) channels, act = PASN_ACT_NONE | PASN_ACT_SWISH,
- *            w_kc / w_rows = packing of the expand weight (as for pasn_conv3d_fwd, one tap)
- *   x      : dtype [N][T][Hi][Wi][Cin_p];  wa : dtype [w_rows][w_kc];  sa, ba : fp32 [w_rows]  (BN after the expand conv)
- *   wb     : fp32 [27][Cout_p];  sb, bb : fp32 [Cout_p]                                         (depthwise conv + its BN)
- *   y      : dtype [N][T][Ho][Wo][Cout_p]
- *   pool_partial : fp32 [N][pool_blocks][Cout_p] or NULL, pool_blocks = pasn_x3d_expand_dw_pool_blocks(d, dtype);
- *            that query returns 0 when the geometry is not supported (caller then uses the two unfused calls).
- */
-int pasn_x3d_expand_dw_pool_blocks(const pasn_conv_desc* d, int dtype);
-/* Which fused kernel the call will use: 0 none (use the unfused calls -- the default: neither fused kernel beats them yet),
- * 1 x3d_front_kernel (7x7 planes, bf16: expand conv into an fp32 LDS plane tile, T-marching stencil from it; PASN_FRONT=1),
- * 2 x3d_expand_dw_kernel (LDS ring; PASN_FUSED=1). */
-int pasn_x3d_expand_dw_variant(const pasn_conv_desc* d, int dtype);
-int pasn_x3d_expand_dw_fwd(const void* x, const void* wa, const float* sa, const float* ba, const float* wb,
-                           const float* sb, const float* bb, void* y, float* pool_partial, const pasn_conv_desc* d,
-                           int dtype, void* stream);
 
 /*
  * Squeeze-excite gate: mean over positions (from the partial sums above, fixed summation order),

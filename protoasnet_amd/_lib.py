@@ -48,15 +48,16 @@ SIGNATURES = {
     "pasn_conv3d_pair_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc),
                                      c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_variant": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "pasn_conv3d_se_supported": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),
+    "pasn_conv3d_se_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_conv3d_short_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int]),
+    "pasn_conv3d_short_fwd": (c_int, [c_void_p] * 9 + [POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_dwconv3d_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_se_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_variant": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_se_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "pasn_dwconv3d_se_fwd": (c_int, [c_void_p] * 6 + [POINTER(ConvDesc), c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
     "pasn_dwconv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
-    "pasn_x3d_expand_dw_variant": (c_int, [POINTER(ConvDesc), c_int]),
-    "pasn_x3d_expand_dw_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
-    "pasn_x3d_expand_dw_fwd": (c_int, [c_void_p] * 9 + [POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_se_gate_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pasn_maxpool3d_fwd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_l2_head_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -283,27 +283,38 @@ class X3DFeatures(_plan.HipTrunk):
             pre = None  # this block's expand-conv output when the previous block's chained launch already made it
             for i, blk in enumerate(blocks):
                 sc = x
-                if blk.shortcut is not None:
+                fuse_short = blk.shortcut is not None and pb.short_fusable(x, blk)  # the strided shortcut conv rides in the project conv's launch
+                if blk.shortcut is not None and not fuse_short:
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
                 act_b = "none" if blk.se is not None else "swish"  # no gate between BN and Swish: the stencil applies Swish
-                fused_front = os.environ.get("PASN_FUSED") == "1" or os.environ.get("PASN_FRONT") == "1"  # opt-in expand+stencil kernels
                 gate = None
-                if blk.se is not None and not fused_front:
-                    e = pre if pre is not None else pb.conv(x, blk.conv_a, blk.bn_a, act="relu")
-                    y, gate = pb.dwconv_se(e, blk.conv_b, blk.bn_b, blk.se.fc1, blk.se.fc2)  # stencil + gate in one launch
+                e = pre if pre is not None else pb.conv(x, blk.conv_a, blk.bn_a, act="relu")
+                if blk.se is not None:
+                    # stencil + gate in one launch where that pays; where the project conv can compute the gate in its own prologue, only
+                    # the pool partial rows are produced here (gate = ("pooled", ...))
+                    y, gate = pb.dwconv_se(e, blk.conv_b, blk.bn_b, blk.se.fc1, blk.se.fc2, consumer=(blk.conv_c, True))
                 else:
-                    if pre is not None:
-                        r = pb.dwconv(pre, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
-                    else:  # (an opt-in fused launch keeps the 2.25x-wide tensor between the two convs out of HBM)
-                        r = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act=act_b, pool=blk.se is not None)
-                    if blk.se is not None:
-                        y, pooled = r
-                        gate = pb.se_gate(pooled, blk.se.fc1, blk.se.fc2)
-                    else:
-                        y = r
+                    y = pb.dwconv(e, blk.conv_b, blk.bn_b, act=act_b)
                 # project conv; where the geometry allows, chained in ONE launch with the next block's expand conv
                 nxt = blocks[i + 1] if i + 1 < len(blocks) else None
                 pair = None
+                if isinstance(gate, tuple):  # squeeze-excite gate in the project conv's prologue
+                    if fuse_short:  # (not combined with the fused shortcut: different kernels)
+                        sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
+                        fuse_short = False
+                    yc = pb.conv_se(y, blk.conv_c, blk.bn_c, "relu", sc, gate[1], blk.se.fc1, blk.se.fc2)
+                    if yc is not None:
+                        x, pre = yc, None
+                        continue
+                    gate = pb.se_gate(gate[1], blk.se.fc1, blk.se.fc2)
+                if fuse_short:
+                    fused = pb.conv_short(y, blk.conv_c, blk.bn_c, "relu", x, blk.shortcut.conv, blk.shortcut.bn, in_gate=gate,
+                                          in_swish=blk.se is not None)
+                    if fused is None:  # (short_fusable said yes on the same descriptors; kept for safety)
+                        sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
+                    else:
+                        x, pre = fused, None
+                        continue
                 if nxt is not None and nxt.shortcut is None:
                     pair = pb.conv_pair(y, blk.conv_c, blk.bn_c, "relu", sc, nxt.conv_a, nxt.bn_a, "relu",
                                         in_gate=gate, in_swish=blk.se is not None)

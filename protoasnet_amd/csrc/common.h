@@ -51,9 +51,18 @@ struct PwGeom {
     int TM, xrow, co_chunk, lds;
 };
 PwGeom pw_geom(const pasn_conv_desc& d, int dtype);
+// pwconv.hip: the fused strided shortcut conv's operands and geometry: output row (n, to, ho, wo) reads x2 row ((n To + to) Hi + ho sh) Wi + wo sw
+struct PwShort {
+    const void* x2;
+    const void* w2;        // [rows][w_kc2], k-contiguous like w
+    const float* scale2;   // [rows] or NULL (= 1)
+    int Cin2_p, w_kc2, Ho, Wo, Hi, Wi, sh, sw;
+};
+
+int pw_short_ks2(const pasn_conv_desc& d, const pasn_conv_desc& d2, int dtype);  // template k-steps of the fused shortcut, 0 = not covered
 template <typename T>
 int launch_pwconv(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
-                  void* y, const pasn_conv_desc& d, const PwGeom& g, hipStream_t s);
+                  void* y, const pasn_conv_desc& d, const PwGeom& g, hipStream_t s, const PwShort* sc = nullptr);
 
 // X-stationary pointwise conv for wide layers (pwconv_xtile.hip)
 bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype);
@@ -67,17 +76,19 @@ struct WsGeom {
     int rpb, nslots, abl;                  // rows (positions) per block, blocks per channel group, timing ablations (PASN_WS_ABL)
     int xreg, greg, rreg, stage_bytes, lds_bytes;  // stage regions (X tile, gate rows, residual tile), whole KiB each
 };
-WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res);
+// squeeze-excite operands of the gate computed in the kernel's prologue (pool == NULL: off): partial rows [N][pool_blocks][Cin_p] of the stencil,
+// 1 / positions, fc1 [cse][C] + bias, fc2 [C][cse] + bias
+struct WsSe {
+    const float* pool;
+    int pool_blocks;
+    float inv_positions;
+    const float *w1, *b1, *w2, *b2;
+    int C, cse;
+};
+WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res, bool se_prologue = false);
 int pw_ws_variant(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res);  // 7000 + KS * 10 + MT, or 0
 int launch_pw_ws(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate, void* y,
-                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s);
-// x3d_front.hip: fused expand conv + depthwise stencil for small spatial planes (bf16).  ok = 0: not covered.
-struct XfrontGeom {
-    int ok, ks, nT, ctiles, lds;
-};
-XfrontGeom x3d_front_geom(const pasn_conv_desc& d, int dtype);
-int launch_x3d_front(const void* x, const void* wa, const float* sa, const float* ba, const float* wb, const float* sb,
-                     const float* bb, void* y, float* pool, const pasn_conv_desc& d, const XfrontGeom& g, hipStream_t s);
+                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s, const WsSe* se = nullptr);
 // pwconv_xpair.hip: project conv of block i chained with the expand conv of block i+1 (bf16); 0 = not covered
 int pw_xpair_ks(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, int* ks2_out);
 int launch_pw_xpair(const void* x, const void* w1, const float* s1, const float* b1, const void* res, const float* gate, void* y1,
@@ -112,7 +123,7 @@ struct DwRedArgs {
 };
 // dwmfma.hip: the stride-1 depthwise 3x3x3 stencil on the matrix cores (block-diagonal bf16 weight operands, LDS-DMA frame ring, T-marching); ok = 0: not covered
 struct DwMfmaGeom {
-    int ok, SS, CT, CQ;        // stride in H and W (1 / 2), channel tiles of 16, quads of 4 tiles (one block owns a quad)
+    int ok, CT, CQ;            // channel tiles of 16, quads of 4 tiles (one block owns a quad)
     int BH, BW, RPT, RTH, RTW;  // outputs per region, output rows per 16-lane position tile, regions per frame
     int RP, NI;                // staged positions per frame, 1-KiB DMA instructions per frame
     int Tc, nT, upb, chunks, bpc;  // T chunk (+count), units (T chunk x region) per block, SE partial rows per clip, blocks per clip
@@ -141,13 +152,6 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
                       const pasn_conv_desc& d, int mode, int nt, int mt, hipStream_t s);
 int launch_igemm(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,
                  const pasn_conv_desc& d, int nt, hipStream_t s);
-// dwmarch2.hip: second-generation T-marching stencil (weight double buffer, buffer-load padding, 4 or 8 channels per thread)
-struct Dw2Geom {
-    int CH, WT, OCC, CG, R, strips, Tc, bpc;
-};
-Dw2Geom dw_march2_geom(const pasn_conv_desc& d, int dtype);
-int launch_dw_march2(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
-                     const pasn_conv_desc& d, const Dw2Geom& g, hipStream_t s);
 template <typename T>
 int launch_gemm_pw(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                    void* y, const pasn_conv_desc& d, hipStream_t s);

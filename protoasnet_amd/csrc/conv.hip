@@ -833,6 +833,42 @@ extern "C" int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* 
     return launch_pw_xpair(x, w1, scale1, bias1, residual, gate, y1, *d1, w2, scale2, bias2, y2, *d2, (hipStream_t)stream);
 }
 
+extern "C" int pasn_conv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse, int has_residual) {
+    if (!conv_desc_ok(d) || Cse <= 0 || Cse > 32 || Cse % 4 != 0 || d->Cin > 512) return 0;
+    if (const char* e = getenv("PASN_NO_SE_PROLOGUE"))
+        if (e[0] == '1') return 0;
+    pasn_conv_desc df = *d;
+    df.w_frag = 1;
+    return pw_ws_geom(df, dtype, true, has_residual != 0, true).ok;
+}
+
+extern "C" int pasn_conv3d_se_fwd(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
+                                  const float* pool_partial, int pool_blocks, int positions, const float* fc1_w, const float* fc1_b,
+                                  const float* fc2_w, const float* fc2_b, int Cse, void* y, const pasn_conv_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(x && w && y && pool_partial && fc1_w && fc1_b && fc2_w && fc2_b, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(d) && pool_blocks > 0 && positions > 0, "bad geometry");
+    PASN_REQUIRE(d->w_frag == 1 && pasn_conv3d_se_supported(d, dtype, Cse, residual != nullptr), "layer not covered (pasn_conv3d_se_supported returns 0)");
+    const WsGeom wg = pw_ws_geom(*d, dtype, true, residual != nullptr, true);
+    const WsSe se = {pool_partial, pool_blocks, 1.0f / (float)positions, fc1_w, fc1_b, fc2_w, fc2_b, d->Cin, Cse};
+    return launch_pw_ws(x, w, scale, bias, residual, nullptr, y, *d, wg, (hipStream_t)stream, &se);
+}
+
+extern "C" int pasn_conv3d_short_supported(const pasn_conv_desc* d, const pasn_conv_desc* d2, int dtype) {
+    if (!conv_desc_ok(d) || !conv_desc_ok(d2)) return 0;
+    return pw_short_ks2(*d, *d2, dtype) != 0;
+}
+
+extern "C" int pasn_conv3d_short_fwd(const void* x, const void* w, const float* scale, const float* bias, const float* gate, const void* x2,
+                                     const void* w2, const float* scale2, void* y, const pasn_conv_desc* d, const pasn_conv_desc* d2,
+                                     int dtype, void* stream) {
+    PASN_REQUIRE(x && w && x2 && w2 && y, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(d) && conv_desc_ok(d2), "bad geometry");
+    PASN_REQUIRE(pw_short_ks2(*d, *d2, dtype) != 0, "layer pair not covered (pasn_conv3d_short_supported returns 0)");
+    PASN_REQUIRE(d->w_frag == 0, "row-major weights");
+    const PwShort sc = {x2, w2, scale2, d2->Cin_p, d2->w_kc, d2->Ho, d2->Wo, d2->Hi, d2->Wi, d2->sh, d2->sw};
+    return launch_pwconv<__bf16>(x, w, scale, bias, nullptr, gate, y, *d, pw_geom(*d, dtype), (hipStream_t)stream, &sc);
+}
+
 extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags) {
     if (!conv_desc_ok(d)) return 0;
     const int has_gate = flags & 1, has_res = (flags >> 1) & 1;  // bit 0: an SE gate tensor is passed, bit 1: a residual is passed
@@ -855,9 +891,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags
 
 extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
-    const Dw2Geom m2 = dw_march2_geom(*d, dtype);
-    if (m2.WT) return 40000 + m2.CH * 1000 + m2.WT * 10 + d->sw;  // dwconv3d_march2_kernel<SW, WT, CH>
-    if (const DwMfmaGeom mf = dw_mfma_geom(*d, dtype); mf.ok) return 50000 + mf.SS;  // dwconv3d_mfma_kernel<.., SS>
+    if (const DwMfmaGeom mf = dw_mfma_geom(*d, dtype); mf.ok) return 50001;  // dwconv3d_mfma_kernel (stride 1)
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return 3000 + m.WT * 10 + d->sw;  // dwconv3d_march_kernel<SW, WT>
     const DwGeom g = dw_geom(*d);
@@ -866,8 +900,6 @@ extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
 
 extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
-    const Dw2Geom m2 = dw_march2_geom(*d, dtype);
-    if (m2.WT) return m2.bpc;
     const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
     if (mf.ok) return mf.chunks;
     const DwMarchGeom m = dw_march_geom(*d, dtype);
@@ -887,8 +919,6 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     PASN_REQUIRE(conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
     PASN_REQUIRE(d->Cin == d->Cout && d->Cin_p == d->Cout_p, "depthwise conv keeps the channel count");
     hipStream_t s = (hipStream_t)stream;
-    const Dw2Geom m2 = dw_march2_geom(*d, dtype);
-    if (m2.WT) return launch_dw_march2(x, w, scale, bias, y, pool_partial, *d, m2, s);
     const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
     if (mf.ok) return launch_dw_mfma(x, w, scale, bias, y, pool_partial, *d, mf, s);
     const DwMarchGeom m = dw_march_geom(*d, dtype);
@@ -905,7 +935,6 @@ extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, in
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0 || Cse <= 0) return 0;
     if (const char* e = getenv("PASN_NO_SE_FUSE"))
         if (e[0] == '1') return 0;
-    if (dw_march2_geom(*d, dtype).WT) return 0;  // the opt-in second-generation kernel has no fused gate
     if (dw_mfma_geom(*d, dtype).ok) return 0;    // the matrix-core stencil + the stand-alone gate beat the fused VALU launch (8669 vs 8623 clips/s)
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     // The last block of a clip computes the gate alone, at the END of the launch: atomic + acquire, the partial rows (agent-scope loads:

@@ -1,7 +1,9 @@
 // Depthwise 3x3x3 stencil (stride 1, pad 1, bf16) on the MATRIX CORES -- third generation of the X3D conv_b stencil, the default for
-// every stride-1 layer that does not ride the fused SE-gate launch (dw_mfma_geom; profiles/README entry 45).
+// every stride-1 layer that does not ride the fused SE-gate launch (dw_mfma_geom; profiles/README entry 45).  (A stride-2 instance --
+// staged rows 32 positions wide, 9 slots per position -- was built and measured in round 2: 210 vs 224 us on the first stage, slower on the
+// others, -0.8 % end to end; both kernels sit at the fabric's rate there.  Retired in round 3; the findings are profiles/README entry 53.)
 //
-// Why: both VALU generations (dwmarch.hip, dwmarch2.hip) are bound by vector-instruction issue, not by bytes: per output element 27
+// Why: both VALU generations (dwmarch.hip and round 2's dwmarch2.hip, retired in round 3) are bound by vector-instruction issue, not by bytes: per output element 27
 // fp32 FMAs plus the bf16->fp32 conversions, padding selects and accumulator moves around them (FMAs are ~1/3 of the issued
 // instructions; 0.29 of the HBM rate on the 54-channel 56x56 layer).  The matrix cores take bf16 operands as they lie in memory
 // and issue beside the vector unit, so the whole inner loop moves there with a BLOCK-DIAGONAL weight operand:
@@ -88,13 +90,13 @@ __device__ __forceinline__ void dwf_wait_all_but(int n) {  // n wave-uniform: ev
 // from memory is waited for by count (dwf_wait_all_but) just before.
 __device__ __forceinline__ void dwf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ACT: the epilogue activation compiled in (none / Swish: what X3D uses), -1 = the descriptor's.  SS: the stride in H and W (1 or 2; stride 2:
-// one output row of 14 per tile, 3 tiles, the staged rows 32 positions wide and 9 slots apart -- see dwf_slots)
-template <int RPT, bool ABLB = false, int ACT = -1, int SS = 1>
+// ACT: the epilogue activation compiled in (none / Swish: what X3D uses), -1 = the descriptor's.
+template <int RPT, bool ABLB = false, int ACT = -1>
 __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ scale, const float* __restrict__ bias,
                                                                __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
                                                                DwMfmaGeom g) {
+    constexpr int SS = 1;  // stride in H and W (the stride-2 instance of round 2 was retired: see the file header)
     extern __shared__ __attribute__((aligned(1024))) char ring[];  // [DWF_RING][NI x 1024]: frame images, position stride 160 bytes
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, q = lane >> 4;
@@ -368,18 +370,11 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     if (on && on[0] == '0') return g;
     const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : (1 << 30);
     if (d.Wo > maxw) return g;
-    const int ss = d.sh;
-    const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && (ss == 1 || ss == 2) && d.sw == ss && d.pt == 1 && d.ph == 1 &&
+    const int ss = 1;
+    const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
                        d.pw == 1 && d.To == d.Ti && d.Ho == (d.Hi - 1) / ss + 1 && d.Wo == (d.Wi - 1) / ss + 1 && d.Cin_p == d.Cout_p &&
                        d.Cout_p % 8 == 0;
     if (!shape) return g;
-    // stride 2 (the first stencil of an X3D stage): OPT-IN (PASN_DWMFMA_S2=1), planes more than 8 wide only (one output row per tile).
-    // Measured (N = 32, profiles/README entry 52): 54 channels 112 -> 56: 210 us vs 224 VALU (200 with one unit per block), 108
-    // channels 56 -> 28: 123 vs 113, 216 channels 28 -> 14: 54 vs 52; end to end 8727 / 8735 vs 8796 / 8804 clips/s (the two narrow
-    // layers also lose their fused gate).  Both kernels sit at ~4-4.3 TB/s of algorithmic bytes plus the halo rows they re-read
-    // (7 staged rows per 3 output rows here): these layers are at the fabric's practical rate, not at an issue limit.
-    if (ss == 2 && (d.Wo <= 8 || !(getenv("PASN_DWMFMA_S2") && getenv("PASN_DWMFMA_S2")[0] == '1'))) return g;
-    g.SS = ss;
     if ((long)d.Ti * d.Hi * d.Wi * d.Cin_p * 2 >= (1L << 31)) return g;  // one clip per buffer descriptor, 2^31 marks "outside"
     g.CT = ceil_div(d.Cout_p, 16);
     g.CQ = ceil_div(g.CT, 4);
@@ -427,14 +422,9 @@ int launch_dw_mfma(const void* x, const float* w, const float* scale, const floa
                    const DwMfmaGeom& g, hipStream_t s) {
     const dim3 grid(g.bpc * d.N), block(256);
     const size_t lds = (size_t)DWF_RING * g.NI * 1024;
-#define PASN_DWF(RPT_, ABL_, ACT_) PASN_DWFS(RPT_, ABL_, ACT_, 1)
-#define PASN_DWFS(RPT_, ABL_, ACT_, SS_) \
-    hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_, SS_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
-    if (g.SS == 2) {
-        if (d.act == PASN_ACT_NONE) PASN_DWFS(1, false, PASN_ACT_NONE, 2);
-        else if (d.act == PASN_ACT_SWISH) PASN_DWFS(1, false, PASN_ACT_SWISH, 2);
-        else PASN_DWFS(1, false, -1, 2);
-    } else if (g.abl) PASN_DWF(1, true, -1);
+#define PASN_DWF(RPT_, ABL_, ACT_) \
+    hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
+    if (g.abl) PASN_DWF(1, true, -1);
     else if (g.RPT == 2) {
         if (d.act == PASN_ACT_NONE) PASN_DWF(2, false, PASN_ACT_NONE);
         else if (d.act == PASN_ACT_SWISH) PASN_DWF(2, false, PASN_ACT_SWISH);
@@ -445,7 +435,6 @@ int launch_dw_mfma(const void* x, const float* w, const float* scale, const floa
         else PASN_DWF(1, false, -1);
     }
 #undef PASN_DWF
-#undef PASN_DWFS
     return check_launch("dwconv3d_mfma_kernel");
 }
 

@@ -11,6 +11,11 @@
 //   * epilogue from the accumulator: position on the lane, 4 consecutive channels per register quad -> 8/16-byte stores.
 // An LDS-staged variant (coalesced whole-row loads and stores through LDS) was built first and measured SLOWER
 // (3 barriers per 128-row tile; 260 us of pure per-block latency on the 6.4 M-row layer): profiles/README.md.
+//
+// KS2 > 0: the block's strided 1x1x1 SHORTCUT conv + its norm rides in the same launch (first block of an X3D stage):
+//   Y = act(scale * (W . X') + scale2 * (W2 . X2[rowmap(m)]) + bias),  bias = both norms' shifts summed by the host,
+// a second accumulator set fed from the block INPUT at the strided position of every output row (second weight set in registers,
+// its rows prefetched like X).  The shortcut tensor (written by one launch, read back as the residual by the next) never exists.
 #include "common.h"
 #include <type_traits>
 
@@ -51,27 +56,30 @@ struct RawQuad<float> {
     }
 };
 
-template <typename T, int KS, int NT, bool RES>
+template <typename T, int KS, int NT, bool RES, int KS2 = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 && NT == 4 && !RES) ? 3 : 1))) void pwconv_persist_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              const T* __restrict__ res, const float* __restrict__ gate,
                                                              T* __restrict__ y, long M, int S, int Cin_p, int Cout, int Cout_p,
-                                                             int w_kc, int act, int in_swish, int gate_rows) {
+                                                             int w_kc, int act, int in_swish, int gate_rows, PwShort sc2) {
+    static_assert(KS2 == 0 || !RES, "the fused shortcut replaces the residual operand");
+    constexpr int SB = KS2 ? 3 : 2;  // scale | bias (| scale2) arrays in LDS
     using frag = typename Traits<T>::frag;
     constexpr int CH = Traits<T>::CH;
     constexpr int KSTEP = Traits<T>::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sbl = reinterpret_cast<float*>(smem);                  // [2][NT*32] scale | bias of the channel chunk
-    T* stage = reinterpret_cast<T*>(smem + 2 * NT * 32 * 4);       // [4 waves][32 rows][Cout_p] output images
+    float* sbl = reinterpret_cast<float*>(smem);                  // [SB][NT*32] scale | bias (| shortcut scale) of the channel chunk
+    T* stage = reinterpret_cast<T*>(smem + SB * NT * 32 * 4);      // [4 waves][32 rows][Cout_p] output images
     // [gate_rows][Cin_p] the WHOLE squeeze-excite gate tensor (a few KB), staged once per block: the transform then reads
     // LDS instead of issuing 8 dependent dword loads per k-step (64 L2 round trips per tile in the first version)
-    float* gl = reinterpret_cast<float*>(smem + 2 * NT * 32 * 4 + (size_t)4 * 32 * Cout_p * sizeof(T));
+    float* gl = reinterpret_cast<float*>(smem + SB * NT * 32 * 4 + (size_t)4 * 32 * Cout_p * sizeof(T));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int co_base = blockIdx.y * (NT * 32);
     for (int i = threadIdx.x; i < NT * 32; i += 256) {
         sbl[i] = scale ? scale[co_base + i] : 1.0f;
         sbl[NT * 32 + i] = bias ? bias[co_base + i] : 0.0f;
+        if (KS2) sbl[2 * NT * 32 + i] = sc2.scale2 ? sc2.scale2[co_base + i] : 1.0f;
     }
     if (gate_rows)
         for (int i = threadIdx.x; i < gate_rows * Cin_p; i += 256) gl[i] = gate[i];
@@ -84,6 +92,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             A[nt][ks] = ks < ks_real ? load_frag<T>(w + (long)(co_base + nt * 32 + c) * w_kc + ks * KSTEP + h * CH) : zero_frag<T>();
+
+    // shortcut weights: a second stationary set (KS2 fragments per channel tile)
+    frag A2[KS2 ? NT : 1][KS2 ? KS2 : 1];
+    const T* x2 = reinterpret_cast<const T*>(sc2.x2);
+    if (KS2) {
+        const T* w2 = reinterpret_cast<const T*>(sc2.w2);
+        const int ks2_real = sc2.w_kc2 / KSTEP;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+                A2[nt][ks] = ks < ks2_real ? load_frag<T>(w2 + (long)(co_base + nt * 32 + c) * sc2.w_kc2 + ks * KSTEP + h * CH) : zero_frag<T>();
+    }
 
     const long ntiles = (M + 31) / 32;
     const long stride = (long)gridDim.x * 4;
@@ -113,12 +134,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
             B[ks] = load_frag<T>(xp + (k < Cin_p ? k : 0));
         }
     };
-    if (tile < ntiles) load_rows(tile, Bc);
+    // shortcut rows: this lane's output position as (wo, ho, frame index n To + to), advanced by the tile stride with carries (one
+    // division chain here instead of three per tile)
+    frag B2c[KS2 ? KS2 : 1], B2n[KS2 ? KS2 : 1];
+    int pwo = 0, pho = 0;
+    long ptn = 0;
+    int dwo = 0, dho = 0;
+    long dtn = 0;
+    if (KS2) {
+        const long m_first = tile * 32 + c;
+        pwo = (int)(m_first % sc2.Wo);
+        const long r = m_first / sc2.Wo;
+        pho = (int)(r % sc2.Ho);
+        ptn = r / sc2.Ho;
+        const long rs = stride * 32;
+        dwo = (int)(rs % sc2.Wo);
+        const long r2 = rs / sc2.Wo;
+        dho = (int)(r2 % sc2.Ho);
+        dtn = r2 / sc2.Ho;
+    }
+    const long rows_in = KS2 ? (M / ((long)sc2.Ho * sc2.Wo)) * sc2.Hi * sc2.Wi : 0;  // M = frames x Ho x Wo
+    auto load_rows2 = [&](frag (&B)[KS2 ? KS2 : 1]) {  // rows of the position held in (pwo, pho, ptn); clamped like load_rows
+        long row = (ptn * sc2.Hi + (long)pho * sc2.sh) * sc2.Wi + (long)pwo * sc2.sw;
+        row = row < rows_in ? row : rows_in - 1;
+        const T* xp = x2 + row * sc2.Cin2_p;
+#pragma unroll
+        for (int ks = 0; ks < (KS2 ? KS2 : 1); ++ks) {
+            const int k = ks * KSTEP + h * CH;
+            B[ks] = load_frag<T>(xp + (k < sc2.Cin2_p ? k : 0));
+        }
+    };
+    auto advance2 = [&]() {
+        pwo += dwo;
+        const int c1 = pwo >= sc2.Wo ? 1 : 0;
+        pwo -= c1 ? sc2.Wo : 0;
+        pho += dho + c1;
+        const int c2 = pho >= sc2.Ho ? 1 : 0;
+        pho -= c2 ? sc2.Ho : 0;
+        ptn += dtn + c2;
+    };
+    if (tile < ntiles) {
+        load_rows(tile, Bc);
+        if (KS2) {
+            load_rows2(B2c);
+            advance2();  // (pwo, pho, ptn) now names the NEXT tile's position
+        }
+    }
 
     for (; tile < ntiles; tile += stride) {
         const long m = tile * 32 + c;
         const bool mv = m < M;
-        if (tile + stride < ntiles) load_rows(tile + stride, Bn);  // next tile's rows: in flight during everything below
+        if (tile + stride < ntiles) {
+            load_rows(tile + stride, Bn);  // next tile's rows: in flight during everything below
+            if (KS2) {
+                load_rows2(B2n);
+                advance2();
+            }
+        }
         // this tile's residual rows, requested before the MFMAs that hide them
         // raw (unconverted), unconditional, clamped: see load_rows.  Compile-time RES: expand convs pay no registers.
         // bf16: the tile's 32 residual rows are ONE contiguous range, like the output: whole 16-byte pieces, lane-contiguous (the quad
@@ -151,6 +223,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)  // zero what load_rows clamped
             if (!(mv && ks * KSTEP + h * CH < Cin_p)) Bc[ks] = zero_frag<T>();
+        if (KS2) {
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+                if (!(mv && ks * KSTEP + h * CH < sc2.Cin2_p)) B2c[ks] = zero_frag<T>();
+        }
         if (xform) {  // x' = swish(x * gate[n][ci]), rounded back to the MFMA input type
             const long n = mv ? cn : 0;
             const float* gp = gate ? (gate_rows ? gl : gate) + n * Cin_p + h * CH : nullptr;
@@ -184,6 +261,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) mma32(acc[nt], A[nt][ks], Bc[ks]);
+        f32x16 acc2[KS2 ? NT : 1];
+        if (KS2) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[nt][i] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma32(acc2[nt], A2[nt][ks], B2c[ks]);
+        }
         // Epilogue.  The accumulator layout (position on the lane, 4 consecutive channels per quad) would give 8-byte
         // stores scattered at the row stride -- measured at ~1.7 TB/s of writes.  The 32 rows of a tile are ONE contiguous
         // global range, so bounce the finished tile through a WAVE-PRIVATE LDS image of exactly that range (no block
@@ -204,6 +292,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
                 load4(sbl + NT * 32 + col, bs);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = acc[nt][4 * g + j] * sc[j] + bs[j];
+                if (KS2) {
+                    float s2[4];
+                    load4(sbl + 2 * NT * 32 + col, s2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(acc2[nt][4 * g + j], s2[j], o[j]);
+                }
                 if (RES && !RCOPY) {
                     float r4[4];
                     RawQuad<T>::to_f4(rq[nt][g], r4);
@@ -262,6 +356,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
         __builtin_amdgcn_wave_barrier();  // the image is reused by this wave's next tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) Bc[ks] = Bn[ks];
+        if (KS2) {
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) B2c[ks] = B2n[ks];
+        }
         if (gate) {  // advance the clip index to the next tile's row
             crem += row_step;
             while (crem >= S) {
@@ -293,9 +391,28 @@ PwGeom pw_geom(const pasn_conv_desc& d, int dtype) {
     return g;
 }
 
+// Shortcut-fused instances (bf16): the first project convs of X3D stages 2 and 3 -- (KS, NT, KS2) = (4, 1, 2): 54 -> 24 + 24 -> 24 stride 2;
+// (8, 2, 4): 108 -> 48 + 48 -> 48 stride 2.  0 = not covered.
+int pw_short_ks2(const pasn_conv_desc& d, const pasn_conv_desc& d2, int dtype) {
+    if (dtype != PASN_BF16) return 0;
+    if (const char* e = getenv("PASN_NO_SHORTFUSE"))
+        if (e[0] == '1') return 0;
+    const PwGeom g = pw_geom(d, dtype);
+    if (!g.TM) return 0;
+    const bool geo = d2.kt == 1 && d2.kh == 1 && d2.kw == 1 && d2.pt == 0 && d2.ph == 0 && d2.pw == 0 && d2.st == 1 && d2.Ti == d2.To &&
+                     d2.N == d.N && d2.To == d.To && d2.Ho == d.Ho && d2.Wo == d.Wo && d2.Cout_p == d.Cout_p && d2.Cout == d.Cout &&
+                     d2.w_frag == 0 && d2.w_kc % 16 == 0 && d2.w_kc >= d2.Cin_p && d2.w_rows >= d.w_rows && d2.in_swish == 0 &&
+                     (d2.Hi - 1) / d2.sh + 1 == d2.Ho && (d2.Wi - 1) / d2.sw + 1 == d2.Wo;
+    if (!geo) return 0;
+    const int ks2 = d2.w_kc / 16;
+    if (g.TM == 4 && g.xrow == 1 && ks2 <= 2) return 2;
+    if (g.TM == 8 && g.xrow == 2 && ks2 <= 4) return ks2 <= 2 ? 2 : 4;
+    return 0;
+}
+
 template <typename T>
 int launch_pwconv(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
-                  void* y, const pasn_conv_desc& d, const PwGeom& g, hipStream_t s) {
+                  void* y, const pasn_conv_desc& d, const PwGeom& g, hipStream_t s, const PwShort* sc) {
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const int S = d.To * d.Ho * d.Wo;
     const long ntiles = (M + 31) / 32;
@@ -307,23 +424,24 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const dim3 block(256);
-#define PASN_PW2(KS_, NT_, RES_)                                                                                                   \
+#define PASN_PW2(KS_, NT_, RES_) PASN_PW3(KS_, NT_, RES_, 0, PwShort{})
+#define PASN_PW3(KS_, NT_, RES_, KS2_, SC_)                                                                                        \
     do {                                                                                                                      \
-        if (lds > 64 * 1024) PASN_MAX_LDS(80 * 1024, pwconv_persist_kernel<T, KS_, NT_, RES_>); /* BEFORE the occupancy query */ \
+        if (lds > 64 * 1024) PASN_MAX_LDS(80 * 1024, pwconv_persist_kernel<T, KS_, NT_, RES_, KS2_>); /* BEFORE the occupancy query */ \
         static std::atomic<long> cached_{-1}; /* (device << 40 | lds << 8 | per_cu) of the last query of this instance */          \
         const long key_ = ((long)dev << 40) | ((long)lds << 8);                                                               \
         long c_ = cached_.load(std::memory_order_relaxed);                                                                    \
         int per_cu = (c_ >= 0 && (c_ & ~0xffL) == key_) ? (int)(c_ & 0xff) : 0;                                               \
         if (per_cu == 0) {                                                                                                    \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pwconv_persist_kernel<T, KS_, NT_, RES_>, 256, lds) !=  \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pwconv_persist_kernel<T, KS_, NT_, RES_, KS2_>, 256, lds) !=  \
                     hipSuccess || per_cu < 1)                                                                                 \
                 per_cu = 2;                                                                                                   \
             cached_.store(key_ | (per_cu & 0xff), std::memory_order_relaxed);                                                 \
         }                                                                                                                     \
         long blocks = want_blocks < (long)n_cu * per_cu ? want_blocks : (long)n_cu * per_cu;                                  \
         const dim3 grid((unsigned)blocks, 1);                                                                                 \
-        hipLaunchKernelGGL((pwconv_persist_kernel<T, KS_, NT_, RES_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,   \
-                           (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gate_rows); \
+        hipLaunchKernelGGL((pwconv_persist_kernel<T, KS_, NT_, RES_, KS2_>), grid, block, lds, s, (const T*)x, (const T*)w, scale, bias,   \
+                           (const T*)res, gate, (T*)y, M, S, d.Cin_p, d.Cout, d.Cout_p, d.w_kc, d.act, d.in_swish, gate_rows, SC_); \
     } while (0)
 #define PASN_PW(KS_, NT_)                 \
     do {                                  \
@@ -331,13 +449,23 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
         else PASN_PW2(KS_, NT_, false);    \
     } while (0)
     const int KS = g.TM, NT = g.xrow;
-    size_t lds = (size_t)2 * NT * 32 * 4 + (size_t)4 * 32 * d.Cout_p * sizeof(T);  // <= 64.5 KB (fp32, 128 channels)
+    size_t lds = (size_t)(sc ? 3 : 2) * NT * 32 * 4 + (size_t)4 * 32 * d.Cout_p * sizeof(T);  // <= 64.5 KB (fp32, 128 channels)
     int gate_rows = 0;  // the whole gate tensor rides in LDS when it is small (it is: N x Cin_p floats)
     if (gate && (size_t)d.N * d.Cin_p * 4 <= 32 * 1024 && lds + (size_t)d.N * d.Cin_p * 4 <= 80 * 1024) {
         gate_rows = d.N;
         lds += (size_t)d.N * d.Cin_p * 4;
     }
-    if (KS == 2) {
+    if (sc) {  // shortcut-fused instances (bf16 only: pw_short_ks2)
+        if constexpr (sizeof(T) == 2) {
+            PASN_REQUIRE(res == nullptr, "the fused shortcut replaces the residual");
+            if (KS == 4 && NT == 1) PASN_PW3(4, 1, false, 2, *sc);
+            else if (KS == 8 && NT == 2 && sc->w_kc2 <= 32) PASN_PW3(8, 2, false, 2, *sc);
+            else if (KS == 8 && NT == 2) PASN_PW3(8, 2, false, 4, *sc);
+            else PASN_REQUIRE(false, "no shortcut-fused instance for this layer");
+        } else {
+            PASN_REQUIRE(false, "the shortcut-fused pointwise conv is bf16 only");
+        }
+    } else if (KS == 2) {
         if (NT == 1) PASN_PW(2, 1); else if (NT == 2) PASN_PW(2, 2); else PASN_PW(2, 4);
     } else if (KS == 4) {
         if (NT == 1) PASN_PW(4, 1); else if (NT == 2) PASN_PW(4, 2); else PASN_PW(4, 4);
@@ -346,12 +474,13 @@ int launch_pwconv(const void* x, const void* w, const float* scale, const float*
     }
 #undef PASN_PW
 #undef PASN_PW2
+#undef PASN_PW3
     return check_launch("pwconv_persist_kernel");
 }
 
 template int launch_pwconv<float>(const void*, const void*, const float*, const float*, const void*, const float*, void*,
-                                  const pasn_conv_desc&, const PwGeom&, hipStream_t);
+                                  const pasn_conv_desc&, const PwGeom&, hipStream_t, const PwShort*);
 template int launch_pwconv<__bf16>(const void*, const void*, const float*, const float*, const void*, const float*, void*,
-                                   const pasn_conv_desc&, const PwGeom&, hipStream_t);
+                                   const pasn_conv_desc&, const PwGeom&, hipStream_t, const PwShort*);
 
 }  // namespace pasn

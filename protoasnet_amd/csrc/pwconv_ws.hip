@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         const __bf16* __restrict__ res, const float* __restrict__ gate,
                                                         __bf16* __restrict__ y, int M, int S, int N, int Cin_p, int Cout, int Cout_p,
-                                                        int nks, int act, int in_swish, WsGeom g) {
+                                                        int nks, int act, int in_swish, WsGeom g, WsSe se) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NS] stages: X tile | gate rows | residual tile, each a whole number of KiB
     constexpr int PPRL = 2 * KS + 1;  // 16-byte slots per staged X row: exactly KS k-steps (zero beyond Cin_p) + one pad slot (odd stride)
     constexpr int GPR = KS * 4;       // 16-byte slots per staged gate row (KS * 16 floats)
@@ -77,6 +77,10 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, row1 * yrow, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(RES ? res : x), 0, RES ? row1 * yrow : 0u, 0x00020000);
     const bool has_gate = XF && gate != nullptr;
+    // squeeze-excite gate computed HERE (se.pool != NULL) from the stencil's pool partial rows: the stand-alone gate launch between the
+    // stencil and this conv, and its two kernel boundaries, are gone.  A block's rows touch at most two clips (host: rpb <= S)
+    const bool se_on = XF && se.pool != nullptr;
+    const unsigned n_first = row0 / (unsigned)S;
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_gate ? gate : scale), 0, has_gate ? (unsigned)N * (unsigned)Cin_p * 4u : 0u, 0x00020000);
 
     // ---- stationary weights: fragment-major (tile ct, step ks) = 64 lanes x 16 bytes; steps beyond w_kc are zeroed below ---------
@@ -145,9 +149,10 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
     auto transform = [&](int i, int stg) {
         if (abl & 32) return;
         char* sb = smem + stg * g.stage_bytes;
-        const float* gl = reinterpret_cast<const float*>(sb + g.xreg);
         const unsigned m0 = row0 + (unsigned)i * (unsigned)BM;
         const unsigned n0 = m0 / (unsigned)S;
+        // gate rows of the tile's clip and the next one: staged with the tile, or (se_on) the block's own two rows kept in stage 0's gate region
+        const float* gl = se_on ? reinterpret_cast<const float*>(smem + g.xreg) + (n0 > n_first ? GPR * 4 : 0) : reinterpret_cast<const float*>(sb + g.xreg);
         const int r0 = (int)(m0 - n0 * (unsigned)S);
         const int nsl = BM * PPRL;
         for (int idx = threadIdx.x; idx < nsl; idx += NW * 64) {
@@ -177,6 +182,80 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
         if (ks >= nks) A[ks] = zero_frag<__bf16>();  // wave-uniform; only the template steps beyond w_kc
+    if (se_on) {
+        // both FC weight sets are requested first (they do not depend on the clip), then per clip: mean over positions from the partial rows
+        // (fixed order) -> fc1 + ReLU (a wave per hidden unit, lanes over channels) -> fc2 + sigmoid (a thread per channel).  Scratch: the X
+        // region of stage 2 (its first DMA group is issued in iteration 0, after this)
+        float* G = reinterpret_cast<float*>(smem + g.xreg);
+        float* mean = reinterpret_cast<float*>(smem + 2 * g.stage_bytes);  // [2][Cin_p]
+        float* hid = mean + 2 * Cin_p;                                      // [2][cse]
+        const int C = se.C, cse = se.cse, tid = threadIdx.x;
+        const unsigned n_last = (row1 - 1) / (unsigned)S;
+        const int ncl = (int)(n_last - n_first) + 1;  // 1 or 2
+        float w1r[4][8];  // fc1 rows of this wave's hidden units j = wave + 8 u (cse <= 32), columns lane + 64 k (C <= 512)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = wave + 8 * u, ch = lane + 64 * k;
+                w1r[u][k] = se.w1[(j < cse && ch < C) ? j * C + ch : 0];
+            }
+        f32x4 w2r[8];  // fc2 row of this thread's channel (tid < 512 covers C), cse <= 32 floats
+        const float b2r = se.b2[tid < C ? tid : 0];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w2r[u] = *reinterpret_cast<const f32x4*>(se.w2 + ((tid < C && 4 * u < cse) ? tid * cse + 4 * u : 0));
+        float b1r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b1r[u] = se.b1[wave + 8 * u < cse ? wave + 8 * u : 0];
+        for (int q = 0; q < ncl; ++q) {
+            const float* pp = se.pool + (long)(n_first + q) * se.pool_blocks * Cin_p + (tid < Cin_p ? tid : 0);
+            float sum = 0.0f;
+            int b = 0;
+            for (; b + 8 <= se.pool_blocks; b += 8) {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = pp[(long)(b + e) * Cin_p];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += t[e];
+            }
+            for (; b < se.pool_blocks; ++b) sum += pp[(long)b * Cin_p];
+            if (tid < Cin_p) mean[q * Cin_p + tid] = sum * se.inv_positions;
+        }
+        ws_barrier();
+        for (int q = 0; q < ncl; ++q) {
+            float sacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ch = lane + 64 * k;
+                const float mv = ch < C ? mean[q * Cin_p + ch] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sacc[u] = fmaf((ch < C && wave + 8 * u < cse) ? w1r[u][k] : 0.0f, mv, sacc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float t = sacc[u];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+                const int j = wave + 8 * u;
+                if (lane == 0 && j < cse) hid[q * cse + j] = fmaxf(t + b1r[u], 0.0f);
+            }
+        }
+        ws_barrier();
+        for (int q = 0; q < ncl; ++q) {
+            float gv = 0.0f;
+            if (tid < C) {
+                float sacc = b2r;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (4 * u < cse) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sacc = fmaf(w2r[u][e], hid[q * cse + 4 * u + e], sacc);
+                    }
+                gv = sigmoidf_(sacc);
+            }
+            if (tid < GPR * 4) G[q * GPR * 4 + tid] = gv;  // zeros beyond C: the padded k columns
+        }
+    }
     if (XF && nt > 0) {  // tile 0 is transformed here; tile i + 1 during iteration i, beside the MFMAs and the epilogue of tile i (host: NS = 3)
         ws_wait_all_but(min(LA - 1, nt - 1) * kgrp);
         ws_barrier();
@@ -257,6 +336,8 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
     }
 }
 
+static int GPR_fits(int ks, int cin_p) { return ks * 16 >= cin_p && 2 * cin_p * 4 + 2 * 32 * 4 <= 32 * (2 * ks + 1) * 16 ? 1 : 0; }  // gate row holds Cin_p floats; scratch fits one X tile
+
 static int ws_ks(int nks) {
     const int opts[] = {4, 6, 8, 12, 14, 16, 28};
     for (int o : opts)
@@ -265,13 +346,13 @@ static int ws_ks(int nks) {
 }
 
 // Geometry of the launch; ok = 0: the layer stays on the other pointwise kernels.
-WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res) {
+WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res, bool se_prologue) {
     WsGeom g{};
     if (const char* e = getenv("PASN_WS"))
         if (e[0] == '0') return g;
     if (dtype != PASN_BF16 || d.w_frag != 1) return g;
     if (d.kt != 1 || d.kh != 1 || d.kw != 1 || d.pt || d.ph || d.pw || d.st != 1 || d.sh != 1 || d.sw != 1) return g;
-    const int mink = getenv("PASN_WS_MINK") ? atoi(getenv("PASN_WS_MINK")) : 48;
+    const int mink = getenv("PASN_WS_MINK") ? atoi(getenv("PASN_WS_MINK")) : 64;  // stage-2 layers (Cin_p 24 / 56): the register-resident kernel is faster
     if (d.Cin_p < mink || d.w_kc % 16 != 0 || d.w_kc < d.Cin_p) return g;
     const int nks = d.w_kc / 16, ks = ws_ks(nks);
     if (!ks) return g;
@@ -282,6 +363,19 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     if (d.w_rows < ctiles * 32) return g;
     const bool xf = has_gate || d.in_swish;
     if (xf && getenv("PASN_WS_GATED") && getenv("PASN_WS_GATED")[0] == '0') return g;
+    // Routing by measurement (X3D-S at 32 x 16 x 224^2, in the pipeline, us per launch old -> new; profiles/README round-3 entry 59):
+    //   project + residual, plain:  108->48 37.5 -> 32, 432->192 22.7 -> 18.8            (216->96 rides the chained pair launch)
+    //   project + residual, gated:  432->192 33 -> 27;   108->48 45 -> 54, 216->96 31 -> 34: the in-place transform pass costs more there
+    //   expand:                     96->432 38 -> 30.5, 48->216 48 -> 45;   48->108 28 -> 29.5, 192->432 20 -> 21.5, head convs 10.6 -> 12.8
+    // PASN_WS=2 takes every layer the kernel covers (the parity tests do).
+    const char* mode = getenv("PASN_WS");
+    if (!(mode && mode[0] == '2')) {
+        bool take;
+        if (xf) take = ks == 28;
+        else if (has_res) take = ks != 14;
+        else take = ctiles >= 7 && ks <= 6;
+        if (!take) return g;
+    }
     g.KS = ks;
     g.gy = (ctiles + 7) / 8;
     g.CT = (ctiles + g.gy - 1) / g.gy;
@@ -316,6 +410,7 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     if (rpb >= 16L * BM) rpb = (rpb + BM - 1) / BM * BM;     // ... whole tiles where the ragged last tile would not matter anyway
     g.rpb = (int)rpb;
     g.nslots = (int)((M + rpb - 1) / rpb);
+    if (se_prologue && (rpb > S || 3 * g.stage_bytes > 160 * 1024 || d.Cin_p > 512 || GPR_fits(ks, d.Cin_p) == 0)) return WsGeom{};  // a block touches <= 2 clips; scratch in stage 2
     g.abl = getenv("PASN_WS_ABL") ? atoi(getenv("PASN_WS_ABL")) : 0;
     g.NW = g.CT * g.PT;
     if (xf && !(getenv("PASN_WS_HELP") && getenv("PASN_WS_HELP")[0] == '0')) g.NW = 8;  // helper waves: the input transform spread evenly over the four SIMDs
@@ -324,23 +419,25 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
 }
 
 int pw_ws_variant(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res) {
-    const WsGeom g = pw_ws_geom(d, dtype, has_gate, has_res);
+    const WsGeom g = pw_ws_geom(d, dtype, has_gate, has_res, false);
     return g.ok ? 7000 + g.KS * 10 + g.MT : 0;
 }
 
 int launch_pw_ws(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate, void* y,
-                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s) {
+                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s, const WsSe* sep) {
+    const WsSe se = sep ? *sep : WsSe{nullptr, 0, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, 0};
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const int S = d.To * d.Ho * d.Wo;
     PASN_REQUIRE(g.ok && g.lds_bytes <= 160 * 1024 && (g.rreg != 0) == (res != nullptr), "pwconv_ws: geometry does not match the call");
-    const bool xf = gate != nullptr || d.in_swish != 0;
+    const bool xf = gate != nullptr || d.in_swish != 0 || sep != nullptr;
+    PASN_REQUIRE(!(sep && gate), "pwconv_ws: either a gate tensor or the squeeze-excite operands");
     const dim3 grid((unsigned)(g.nslots * g.gy)), block((unsigned)(64 * g.NW));
 #define PASN_WS3(KS_, MT_, XF_, RES_)                                                                                              \
     do {                                                                                                                          \
         PASN_MAX_LDS(160 * 1024, pwconv_ws_kernel<KS_, MT_, XF_, RES_>);                                                         \
         hipLaunchKernelGGL((pwconv_ws_kernel<KS_, MT_, XF_, RES_>), grid, block, (size_t)g.lds_bytes, s, (const __bf16*)x,        \
                            (const __bf16*)w, scale, bias, (const __bf16*)res, gate, (__bf16*)y, (int)M, S, d.N, d.Cin_p, d.Cout,   \
-                           d.Cout_p, d.w_kc / 16, d.act, d.in_swish, g);                                                          \
+                           d.Cout_p, d.w_kc / 16, d.act, d.in_swish, g, se);                                                      \
     } while (0)
 #define PASN_WS2(KS_, MT_)                                   \
     do {                                                     \

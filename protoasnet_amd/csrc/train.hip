@@ -615,8 +615,7 @@ extern "C" int pasn_dwconv3d_stats_rows(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0 || d->Cout_p > 2048) return 0;
     if (const char* e = getenv("PASN_NO_DW_STATS"))
         if (e[0] == '1') return 0;
-    if (dw_march2_geom(*d, dtype).WT) return 0;  // opt-in stencil: no fused statistics (the matrix-core stencil does not matter here:
-                                                 // pasn_dwconv3d_stats_fwd launches the VALU stencil itself)
+    // (the matrix-core stencil does not matter here: pasn_dwconv3d_stats_fwd launches the VALU stencil itself)
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     return m.WT ? m.bpc : 0;
 }

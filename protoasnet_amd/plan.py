@@ -325,6 +325,104 @@ class PlanBuilder:
         )
         return y
 
+    def conv_se(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, residual: Optional[Act], pooled, fc1: nn.Module,
+                fc2: nn.Module) -> Optional[Act]:
+        """Project conv of an X3D SE block with the squeeze-excite gate computed in its own prologue from the stencil's pool partial rows
+        (``pooled`` = what ``dwconv(..., pool=True)`` returned): no stand-alone gate launch, no gate tensor.  None = not covered."""
+        one = (1, 1, 1)
+        if x.planar or self.dtype != torch.bfloat16 or conv.groups != 1 or _triple(conv.kernel_size, 1) != one or _triple(conv.stride, 1) != one:
+            return None
+        pool_buf, pool_blocks, py = pooled
+        cse = fc1.out_channels
+        y = self._out_act(x, conv.out_channels, one, one, (0, 0, 0))
+        wp, kc, rows = pack_conv_weight(conv.weight, x.Cp, self.dtype)
+        d = self._desc(x, y, one, one, (0, 0, 0), act, True, kc, rows)
+        if (py.N, py.positions, py.Cp) != (x.N, x.positions, x.Cp) or \
+                not int(self.lib.pasn_conv3d_se_supported(ctypes.byref(d), self.code, cse, int(residual is not None))):
+            self.bufs[y.buf].nbytes = ALIGN  # never used
+            return None
+        wf = wp.view(rows // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+        d.w_frag = 1
+        scale, bias = fold_norm(norm, conv.bias, y.C, rows, self.device)
+        c = x.C
+        w1 = fc1.weight.detach().float().reshape(cse, c).contiguous()
+        b1 = fc1.bias.detach().float().contiguous()
+        w2 = fc2.weight.detach().float().reshape(c, cse).contiguous()
+        b2 = fc2.bias.detach().float().contiguous()
+        self.keep += [wf, scale, bias, w1, b1, w2, b2]
+        if residual is not None:
+            assert (residual.N, residual.T, residual.H, residual.W, residual.Cp) == (y.N, y.T, y.H, y.W, y.Cp)
+        fn, code = self.lib.pasn_conv3d_se_fwd, self.code
+        a = tuple(t.data_ptr() for t in (wf, scale, bias, w1, b1, w2, b2))
+        xb, yb, rb, pbuf, dref, pos = x.buf, y.buf, (residual.buf if residual is not None else None), pool_buf, ctypes.byref(d), x.positions
+        self._use(xb, yb, rb, pbuf)
+        out_pos = y.N * y.positions
+        self._note("conv+se", f"pwconv_ws_kernel<{max(4, kc // 16 + kc // 16 % 2) if kc // 16 <= 16 else 28},1,true,{'true' if residual is not None else 'false'}>[se]",
+                   (out_pos * (x.C + y.C * (2 if residual is not None else 1)) + y.C * x.C) * self.es + (x.N * pool_blocks * c + 2 * c * cse) * 4,
+                   2 * out_pos * y.C * x.C + 4 * x.N * c * cse)
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[rb] if rb is not None else 0, ptrs[pbuf], pool_blocks, pos,
+                                                       a[3], a[4], a[5], a[6], cse, ptrs[yb], dref, code, st)))
+        return y
+
+    def short_fusable(self, x: Act, blk) -> bool:
+        """Whether ``conv_short`` will cover this block (asked BEFORE the block's launches are emitted: a fusable shortcut conv is not
+        emitted on its own).  ``x`` = the block input, ``blk`` = a block with ``conv_c`` / ``shortcut.conv`` / ``se``."""
+        if self.dtype != torch.bfloat16 or x.planar:
+            return False
+        sc, pc = blk.shortcut.conv, blk.conv_c
+        if _triple(sc.kernel_size, 1) != (1, 1, 1) or _triple(pc.kernel_size, 1) != (1, 1, 1) or _triple(pc.stride, 1) != (1, 1, 1):
+            return False
+        s2 = _triple(sc.stride, 1)
+        if s2[0] != 1:
+            return False
+        T, H, W = x.T, (x.H - 1) // s2[1] + 1, (x.W - 1) // s2[2] + 1
+        inner, cout = pc.in_channels, pc.out_channels
+        cip, cop = round_up(inner, 8), round_up(cout, 8)
+        rows = round_up(cop, 128)
+        d = ConvDesc(N=x.N, Ti=T, Hi=H, Wi=W, Cin=inner, Cin_p=cip, To=T, Ho=H, Wo=W, Cout=cout, Cout_p=cop, kt=1, kh=1, kw=1, st=1, sh=1, sw=1,
+                     pt=0, ph=0, pw=0, act=_lib.ACT["relu"], in_swish=int(blk.se is not None), w_kc=round_up(cip, 16), w_rows=rows)
+        d2 = ConvDesc(N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=x.C, Cin_p=x.Cp, To=T, Ho=H, Wo=W, Cout=cout, Cout_p=cop, kt=1, kh=1, kw=1, st=1,
+                      sh=s2[1], sw=s2[2], pt=0, ph=0, pw=0, act=_lib.ACT["none"], in_swish=0, w_kc=round_up(x.Cp, 16), w_rows=rows)
+        return bool(self.lib.pasn_conv3d_short_supported(ctypes.byref(d), ctypes.byref(d2), self.code))
+
+    def conv_short(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], act: str, x2: Act, conv2: nn.Module, norm2: Optional[nn.Module],
+                   in_gate: Optional[int] = None, in_swish: bool = False) -> Optional[Act]:
+        """A block's project conv + norm with the block's strided 1x1x1 shortcut conv + norm accumulated in the SAME launch
+        (``y = act(norm(conv(x')) + norm2(conv2(x2)))``): the first block of an X3D stage.  Returns None when the fused kernel does
+        not cover the pair (the caller then emits the shortcut conv and the project conv with a residual)."""
+        one = (1, 1, 1)
+        if x.planar or x2.planar or self.dtype != torch.bfloat16 or conv.groups != 1 or conv2.groups != 1:
+            return None
+        if _triple(conv.kernel_size, 1) != one or _triple(conv.stride, 1) != one or _triple(conv2.kernel_size, 1) != one:
+            return None
+        s2 = _triple(conv2.stride, 1)
+        y = self._out_act(x, conv.out_channels, one, one, (0, 0, 0))
+        wp, kc, rows = pack_conv_weight(conv.weight, x.Cp, self.dtype)
+        d = self._desc(x, y, one, one, (0, 0, 0), act, in_swish, kc, rows)
+        w2, kc2, rows2 = pack_conv_weight(conv2.weight, x2.Cp, self.dtype)
+        y2 = Act(y.N, y.T, y.H, y.W, y.C, y.Cp, -1)
+        d2 = self._desc(x2, y2, one, s2, (0, 0, 0), "none", False, kc2, rows2)
+        if (x2.T, (x2.H - 1) // s2[1] + 1, (x2.W - 1) // s2[2] + 1) != (y.T, y.H, y.W) or conv2.out_channels != conv.out_channels or \
+                not int(self.lib.pasn_conv3d_short_supported(ctypes.byref(d), ctypes.byref(d2), self.code)):
+            self.bufs[y.buf].nbytes = ALIGN  # never used
+            return None
+        scale, bias = fold_norm(norm, conv.bias, y.C, rows, self.device)
+        scale2, bias2 = fold_norm(norm2, conv2.bias, y.C, rows2, self.device)
+        bias = (bias + bias2[: bias.numel()]).contiguous()
+        self.keep += [wp, w2, scale, bias, scale2]
+        fn, code = self.lib.pasn_conv3d_short_fwd, self.code
+        a = tuple(t.data_ptr() for t in (wp, scale, bias, w2, scale2))
+        xb, x2b, gb, yb, r1, r2 = x.buf, x2.buf, in_gate, y.buf, ctypes.byref(d), ctypes.byref(d2)
+        self._use(xb, x2b, gb, yb)
+        pos = y.N * y.positions
+        self._note("conv+shortcut", f"pwconv_persist_kernel<{self.tname},{max(2, 1 << (kc // 16 - 1).bit_length()) if kc // 16 > 2 else 2},{(y.Cp + 31) // 32},false,"
+                                    f"{2 if kc2 // 16 <= 2 else 4}>",
+                   (pos * (x.C + x2.C + y.C) + y.C * (x.C + x2.C)) * self.es + (x.N * x.C * 4 if in_gate is not None else 0),
+                   2 * pos * y.C * (x.C + x2.C))
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[gb] if gb is not None else 0, ptrs[x2b], a[3], a[4],
+                                                       ptrs[yb], r1, r2, code, st)))
+        return y
+
     def conv_pair(self, x: Act, conv1: nn.Module, norm1: Optional[nn.Module], act1: str, residual: Act,
                   conv2: nn.Module, norm2: Optional[nn.Module], act2: str, in_gate: Optional[int] = None,
                   in_swish: bool = False):
@@ -390,11 +488,9 @@ class PlanBuilder:
         self._use(xb, yb, pb)
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
-        if dv >= 50000:  # the instance as the profiler prints it: <rows per position tile, ablation build, compiled-in activation, stride in H and W>
+        if dv >= 50000:  # the instance as the profiler prints it: <rows per position tile, ablation build, compiled-in activation>
             actc = _lib.ACT[act]
-            kname = f"dwconv3d_mfma_kernel<{2 if y.W <= 8 else 1},false,{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1},{dv % 10}>"
-        elif dv >= 40000:
-            kname = f"dwconv3d_march2_kernel<{dv % 10},{dv // 10 % 100},{dv // 1000 % 10}>"
+            kname = f"dwconv3d_mfma_kernel<{2 if y.W <= 8 else 1},false,{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1}>"
         elif dv >= 3000:
             kname = f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>"
         elif dv:
@@ -411,7 +507,7 @@ class PlanBuilder:
             return y, (pool_buf, pool_blocks, y)
         return y
 
-    def dwconv_se(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], fc1: nn.Module, fc2: nn.Module):
+    def dwconv_se(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], fc1: nn.Module, fc2: nn.Module, consumer=None):
         """Depthwise 3x3x3 conv + BN (no activation: the gate comes first) + the block's squeeze-excite gate in ONE launch where the
         T-marching stencil covers the layer (the clip's last-arriving block computes the gate); otherwise the stencil launch followed
         by the stand-alone gate launch.  Returns (y, gate buffer id)."""
@@ -423,6 +519,15 @@ class PlanBuilder:
         cse = fc1.out_channels
         if not int(self.lib.pasn_dwconv3d_se_supported(ctypes.byref(probe), self.code, cse)):
             y, pooled = self.dwconv(x, conv, norm, act="none", pool=True)
+            if consumer is not None:
+                # the project conv may compute the gate in its own prologue (pasn_conv3d_se_fwd): ``consumer`` = (conv_c, has residual)
+                cc, has_res = consumer
+                cop = round_up(cc.out_channels, 8)
+                dc = ConvDesc(N=y.N, Ti=y.T, Hi=y.H, Wi=y.W, Cin=y.C, Cin_p=y.Cp, To=y.T, Ho=y.H, Wo=y.W, Cout=cc.out_channels, Cout_p=cop,
+                              kt=1, kh=1, kw=1, st=1, sh=1, sw=1, pt=0, ph=0, pw=0, act=_lib.ACT["relu"], in_swish=1,
+                              w_kc=round_up(y.Cp, 16), w_rows=round_up(cop, 128))
+                if self.dtype == torch.bfloat16 and int(self.lib.pasn_conv3d_se_supported(ctypes.byref(dc), self.code, cse, int(has_res))):
+                    return y, ("pooled", pooled)
             return y, self.se_gate(pooled, fc1, fc2)
         y = self._out_act(x, x.C, k, s, p)
         taps = k[0] * k[1] * k[2]
@@ -451,58 +556,13 @@ class PlanBuilder:
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
         # the T-marching VALU stencil's instance (the layer's plain launch may be routed elsewhere: then only the stride is known here)
-        kname = f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>" if 3000 <= dv < 40000 else f"dwconv3d_march_kernel<{s[2]},se>"
+        kname = f"dwconv3d_march_kernel<{dv % 10},{dv // 10 % 100}>" if 3000 <= dv < 50000 else f"dwconv3d_march_kernel<{s[2]},se>"
         self._note("dwconv+se", kname,
                    (self._touched(x, y, k, s) + out_pos) * y.C * self.es + (y.N * pool_blocks * y.C * 8 + y.N * c * 4 + 2 * c * cse * 4),
                    2 * out_pos * y.C * taps + 4 * y.N * c * cse)
         self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], ptrs[yb], ptrs[pb_], dref, code, a[3], a[4], a[5], a[6],
                                                        cse, ptrs[gate], a[7], st)))
         return y, gate
-
-    def expand_dw(self, x: Act, conv_a: nn.Module, norm_a: nn.Module, conv_b: nn.Module, norm_b: nn.Module, act: str,
-                  pool: bool = False):
-        """X3D front half (1x1x1 expand + BN + ReLU -> depthwise 3x3x3 + BN [+Swish] [+SE partial sums]) as ONE launch;
-        falls back to the two unfused launches when the fused kernel does not cover the geometry."""
-        k, s, p = _triple(conv_b.kernel_size, 1), _triple(conv_b.stride, 1), _triple(conv_b.padding, 0)
-        ci = conv_a.out_channels
-        assert conv_b.groups == ci == conv_b.in_channels and _triple(conv_a.kernel_size, 1) == (1, 1, 1)
-        mid = Act(x.N, x.T, x.H, x.W, ci, round_up(ci, 8), -1)
-        y = self._out_act(mid, ci, k, s, p)
-        wa, kc, rows = pack_conv_weight(conv_a.weight, x.Cp, self.dtype)
-        d = ConvDesc(
-            N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=x.C, Cin_p=x.Cp, To=y.T, Ho=y.H, Wo=y.W, Cout=ci, Cout_p=y.Cp,
-            kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
-            act=_lib.ACT[act], in_swish=0, w_kc=kc, w_rows=rows,
-        )
-        dref = ctypes.byref(d)
-        pool_blocks = int(self.lib.pasn_x3d_expand_dw_pool_blocks(dref, self.code))
-        if pool_blocks == 0:  # geometry outside the fused kernel: the buffer made for y is simply never used
-            self.bufs[y.buf].nbytes = ALIGN
-            e = self.conv(x, conv_a, norm_a, act="relu")
-            return self.dwconv(e, conv_b, norm_b, act=act, pool=pool)
-        sa, ba = fold_norm(norm_a, conv_a.bias, ci, rows, self.device)
-        taps = k[0] * k[1] * k[2]
-        wb = torch.zeros(taps, y.Cp, dtype=torch.float32, device=self.device)
-        wb[:, :ci] = conv_b.weight.detach().float().reshape(ci, taps).t()
-        sb, bb = fold_norm(norm_b, conv_b.bias, ci, y.Cp, self.device)
-        self.keep += [wa, sa, ba, wb, sb, bb, d]
-        pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4) if pool else None
-        fn, code = self.lib.pasn_x3d_expand_dw_fwd, self.code
-        a = tuple(t.data_ptr() for t in (wa, sa, ba, wb, sb, bb))
-        xb, yb, pb = x.buf, y.buf, pool_buf
-        self._use(xb, yb, pb)
-        out_pos = y.N * y.positions
-        fv = int(self.lib.pasn_x3d_expand_dw_variant(dref, self.code))
-        self._note("expand_dw", f"x3d_front_kernel<{kc // 16},{x.H}>" if fv == 1 else f"x3d_expand_dw_kernel<{self.tname},{s[1]}>",
-                   (x.N * x.positions * x.C + out_pos * ci + ci * x.C) * self.es + (y.N * pool_blocks * ci * 4 if pool else 0),
-                   2 * x.N * x.positions * ci * x.C + 2 * out_pos * ci * taps)
-        self.ops.append(
-            lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], a[4], a[5], ptrs[yb],
-                                           ptrs[pb] if pb is not None else 0, dref, code, st))
-        )
-        if pool:
-            return y, (pool_buf, pool_blocks, y)
-        return y
 
     def se_gate(self, pooled, fc1: nn.Module, fc2: nn.Module) -> int:
         pool_buf, pool_blocks, y = pooled

@@ -142,23 +142,26 @@ def test_plan_shapes_and_arena(cfg, shape):
     # the 11 gates of the stride-1 SE blocks are stand-alone launches; with it off (PASN_DWMFMA=0) the 5 gates of the stages up to 128
     # channels ride in their VALU stencil launches (PASN_SE_FUSE_MAXC moves the boundary, PASN_NO_SE_FUSE=1: all stand-alone).  The 4
     # stride-2 SE blocks (first block of every stage: 54, 108, 216, 432 channels): they stay on the VALU stencil, the narrow ones
-    # with their gate fused (PASN_DWMFMA_S2=1 moves the first three -- output planes 56 / 28 / 14 wide -- to the matrix-core stencil:
-    # measured slower end to end).  Opt-in fused launches:
-    # PASN_FRONT=1 fuses expand + depthwise of the 6 stride-1 blocks of the 7x7 stage, PASN_FUSED=1 of all 26
-    fused = 26 if os.environ.get("PASN_FUSED") == "1" else (6 if os.environ.get("PASN_FRONT") == "1" else 0)
+    # with their gate fused.  (Round 2's opt-in fused expand + depthwise launches and its stride-2 matrix-core stencil were retired in
+    # round 3: none beat the default route; the measurements are in profiles/README.md.)
+    fused = 0
     # project conv of block i + expand conv of block i+1 chained in one launch (bf16): the 10 pairs of stage 4
     # (+ the 4 of stage 3 with PASN_XPAIR_ALL=1)
     paired = 0 if os.environ.get("PASN_NO_XPAIR") == "1" or fused else (14 if os.environ.get("PASN_XPAIR_ALL") == "1" else 10)
     max_c = int(os.environ.get("PASN_SE_FUSE_MAXC", "128"))
     mfma = os.environ.get("PASN_DWMFMA", "1") != "0" and "PASN_DWMFMA_MAXW" not in os.environ
-    mfma_s2 = mfma and os.environ.get("PASN_DWMFMA_S2") == "1"  # opt-in: stride-2 stencils whose output plane is more than 8 wide
+    mfma_s2 = False
     # (channels, stride-2 SE blocks, stride-1 SE blocks) per stage
     se_blocks = ((54, 1, 1), (108, 1, 2), (216, 1, 5), (432, 1, 3))
     if os.environ.get("PASN_NO_SE_FUSE") == "1" or fused:
         gates = 15
     else:
         gates = sum((s2 if (c > max_c or (mfma_s2 and c < 432)) else 0) + (s1 if (c > max_c or mfma) else 0) for c, s2, s1 in se_blocks)
-    assert n_ops == {"x3d_s": 1 + 26 * 3 - fused - paired + 4 + gates, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
+    # round 3: the strided shortcut convs of stages 2 and 3 ride in their blocks' project-conv launches (pasn_conv3d_short_fwd), and the four
+    # gates of the 432-channel stage are computed in the project convs' prologues (pasn_conv3d_se_fwd) -- bf16 only, like the pairs
+    short_fused = 0 if os.environ.get("PASN_NO_SHORTFUSE") == "1" else 2
+    se_prologue = 0 if (os.environ.get("PASN_NO_SE_PROLOGUE") == "1" or os.environ.get("PASN_WS") == "0") else 4
+    assert n_ops == {"x3d_s": 1 + 26 * 3 - fused - paired + 4 + gates - short_fused - se_prologue, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
 
 
 def test_packed_weight_layout():

@@ -336,7 +336,8 @@ def test_pwconv_ws(case, shrink, monkeypatch):
     from protoasnet_amd.plan import round_up
 
     def run(ws: bool):
-        monkeypatch.setenv("PASN_WS", "1" if ws else "0")
+        monkeypatch.setenv("PASN_WS", "2" if ws else "0")  # 2: every layer the kernel covers, not only the ones it is routed to by default
+        monkeypatch.setenv("PASN_WS_MINK", "48")
         if ws and shrink:  # one block per CU slot and the smallest tiles: blocks walk several tiles, the stage ring wraps
             monkeypatch.setenv("PASN_WS_BPC", "1")
             monkeypatch.setenv("PASN_WS_MT", "1")
@@ -359,7 +360,7 @@ def test_pwconv_ws(case, shrink, monkeypatch):
             plan.ptrs[gbuf] = gt.data_ptr()
         out = plan.run(xs)
         torch.cuda.synchronize()
-        for k in ("PASN_WS", "PASN_WS_BPC", "PASN_WS_MT", "PASN_WS_NS"):
+        for k in ("PASN_WS", "PASN_WS_MINK", "PASN_WS_BPC", "PASN_WS_MT", "PASN_WS_NS"):
             monkeypatch.delenv(k, raising=False)
         return out, name
 
@@ -375,6 +376,130 @@ def test_pwconv_ws(case, shrink, monkeypatch):
         assert_close(_from_cl(out, cout), _from_cl(old, cout), 1.6e-2 * scale, 1e-2, f"ws vs {old_name} {case}")
     if out.shape[-1] > cout:
         assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
+@pytest.mark.parametrize("gate", [False, True])
+@pytest.mark.parametrize("inner,cout,cin2,thw", [(54, 24, 24, (3, 11, 13)), (108, 48, 24, (2, 9, 10)), (108, 48, 48, (2, 8, 7))])
+def test_conv_with_fused_strided_shortcut(inner, cout, cin2, thw, gate, monkeypatch):
+    """First block of an X3D stage: project conv (+BN, optional SE gate + Swish on its input) with the block's strided 1x1x1 shortcut conv
+    (+BN) accumulated in the same launch, then ReLU -- against torch on the bf16-rounded operands, and against the two separate launches
+    (shortcut conv -> project conv with residual; the fused form skips the bf16 rounding of the shortcut tensor).  Odd planes (the last
+    strided row / column exists), three clips, M not a multiple of the 32-row tile."""
+    dtype = torch.bfloat16
+    torch.manual_seed(inner + cin2 + gate)
+    n = 3
+    t, hi, wi = thw
+    ho, wo = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
+    z = torch.randn(n, inner, t, ho, wo)
+    x2 = torch.randn(n, cin2, t, hi, wi)
+    g = torch.rand(n, inner) + 0.25 if gate else None
+    conv, conv2 = nn.Conv3d(inner, cout, 1, bias=False), nn.Conv3d(cin2, cout, 1, (1, 2, 2), bias=False)
+    bn, bn2 = nn.BatchNorm3d(cout), nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        for b in (bn, bn2):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+            b.running_mean.normal_(0, 0.3)
+            b.running_var.uniform_(0.5, 1.5)
+    bn.eval(), bn2.eval()
+    zin = _rt(z, dtype)
+    if gate:
+        zin = zin * g[:, :, None, None, None]
+        zin = _rt(zin * torch.sigmoid(zin), dtype)
+    ref = F.relu(bn(F.conv3d(zin, _rt(conv.weight.data, dtype))) + bn2(F.conv3d(_rt(x2, dtype), _rt(conv2.weight.data, dtype), stride=(1, 2, 2)))).detach()
+    conv, conv2, bn, bn2 = conv.to(DEV), conv2.to(DEV), bn.to(DEV), bn2.to(DEV)
+
+    from protoasnet_amd.plan import round_up
+
+    def run(fused: bool):
+        pb = _pb(dtype)
+        za, zs = _cl_input(pb, z, dtype)
+        xa, xs = _cl_input(pb, x2, dtype)
+        gbuf = gt = None
+        if gate:
+            gt = torch.zeros(n, round_up(inner, 8), dtype=torch.float32, device=DEV)
+            gt[:, :inner] = g.to(DEV)
+            gbuf = pb._new_buf(gt.numel() * 4, external=True)
+        if fused:
+            y = pb.conv_short(za, conv, bn, "relu", xa, conv2, bn2, in_gate=gbuf, in_swish=gate)
+            assert y is not None and pb.meta[-1]["kind"] == "conv+shortcut", "the fused kernel must cover this pair"
+        else:
+            sc = pb.conv(xa, conv2, bn2, act="none")
+            y = pb.conv(za, conv, bn, "relu", residual=sc, in_gate=gbuf, in_swish=gate)
+        plan = pb.finish(za, y)
+        plan.ptrs[xa.buf] = xs.data_ptr()
+        if gate:
+            plan.ptrs[gbuf] = gt.data_ptr()
+        out = plan.run(zs)
+        torch.cuda.synchronize()
+        return out, len(plan.ops)
+
+    out, n_fused = run(True)
+    two, n_two = run(False)
+    assert n_fused == 1 and n_two == 2
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, cout), ref, 3e-2 * scale, 2e-2, f"fused shortcut {inner}->{cout} + {cin2}->{cout}")
+    assert_close(_from_cl(out, cout), _from_cl(two, cout), 1.6e-2 * scale, 1e-2, "fused vs the two launches")  # one bf16 ulp of the output
+    if out.shape[-1] > cout:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
+@pytest.mark.parametrize("c,cout,cse,n,thw,stride", [(432, 192, 32, 3, (4, 7, 7), 1), (432, 192, 32, 2, (5, 14, 14), 2), (216, 96, 16, 3, (4, 9, 9), 1)])
+def test_project_conv_with_se_gate_in_its_prologue(c, cout, cse, n, thw, stride, monkeypatch):
+    """X3D SE block back half: depthwise stencil (+BN, pool partial rows) -> project conv whose PROLOGUE computes the squeeze-excite gate from
+    those rows (mean, fc1 + ReLU, fc2 + sigmoid), applies x' = swish(x * gate), adds the residual, ReLU -- one launch after the stencil --
+    against torch, and against the stand-alone gate launch + gated conv.  Clips shorter than a block's row share and blocks that straddle
+    two clips (three clips, ragged M)."""
+    dtype = torch.bfloat16
+    monkeypatch.setenv("PASN_WS", "2")  # the prologue lives in the weight-stationary kernel: take it for every covered layer
+    torch.manual_seed(c + n)
+    x = torch.randn(n, c, *thw)
+    conv_b = nn.Conv3d(c, c, 3, (1, stride, stride), 1, groups=c, bias=False)
+    conv_c = nn.Conv3d(c, cout, 1, bias=False)
+    bn_b, bn_c = nn.BatchNorm3d(c), nn.BatchNorm3d(cout)
+    fc1, fc2 = nn.Conv3d(c, cse, 1), nn.Conv3d(cse, c, 1)
+    with torch.no_grad():
+        for b in (bn_b, bn_c):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+            b.running_mean.normal_(0, 0.3)
+            b.running_var.uniform_(0.5, 1.5)
+    bn_b.eval(), bn_c.eval()
+    conv_br = nn.Conv3d(c, c, 3, (1, stride, stride), 1, groups=c, bias=False)
+    conv_br.weight.data = _rt(conv_b.weight.data, dtype)  # (the matrix-core stencil rounds its weights to bf16, the VALU one does not: loose gate below)
+    yb = bn_b(conv_br(_rt(x, dtype))).detach()
+    gate = torch.sigmoid(fc2(F.relu(fc1(yb.mean(dim=(2, 3, 4), keepdim=True))))).detach()
+    yq = _rt(yb, dtype)
+    zin = yq * gate
+    zin = _rt(zin * torch.sigmoid(zin), dtype)
+    res = torch.randn(n, cout, *yb.shape[2:])
+    ref = F.relu(bn_c(F.conv3d(zin, _rt(conv_c.weight.data, dtype))) + _rt(res, dtype)).detach()
+    mods = [m_.to(DEV) for m_ in (conv_b, bn_b, conv_c, bn_c, fc1, fc2)]
+
+    def run(prologue: bool):
+        monkeypatch.setenv("PASN_NO_SE_PROLOGUE", "0" if prologue else "1")
+        pb = _pb(dtype)
+        xa, xs = _cl_input(pb, x, dtype)
+        ra, rs = _cl_input(pb, res, dtype)
+        y, pooled = pb.dwconv(xa, mods[0], mods[1], act="none", pool=True)
+        if prologue:
+            out = pb.conv_se(y, mods[2], mods[3], "relu", ra, pooled, mods[4], mods[5])
+            assert out is not None and pb.meta[-1]["kind"] == "conv+se", "the prologue kernel must cover this layer"
+        else:
+            g = pb.se_gate(pooled, mods[4], mods[5])
+            out = pb.conv(y, mods[2], mods[3], "relu", residual=ra, in_gate=g, in_swish=True)
+        plan = pb.finish(xa, out)
+        plan.ptrs[ra.buf] = rs.data_ptr()
+        o = plan.run(xs)
+        torch.cuda.synchronize()
+        return o, len(plan.ops)
+
+    out, n1 = run(True)
+    two, n2 = run(False)
+    assert (n1, n2) == (2, 3)
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, cout), ref, 4e-2 * scale, 3e-2, f"project conv with SE prologue {c}->{cout}")
+    assert_close(_from_cl(out, cout), _from_cl(two, cout), 1.6e-2 * scale, 1e-2, "prologue gate vs stand-alone gate launch")  # one bf16 ulp of the output
 
 
 HALO_CASES = [
@@ -468,6 +593,13 @@ def test_conv_kernel_routing():
     assert v(desc(48, 108)) == 2500 + 2 * 4               # untransformed, 4 channel tiles: x-tile preferred
     assert v(desc(108, 48, in_swish=1), 1) == 1000 + 8 * 10 + 2  # gated: persistent kernel
     assert v(desc(216, 96, s=16)) < 2500                  # fewer than 64 positions per clip: not the x-tile kernel
+    # weight-stationary persistent kernel (flags: bit 0 gate, bit 1 residual): the layers it is routed to by measurement
+    assert v(desc(432, 192), 2) == 7000 + 28 * 10 + 1     # project + residual
+    assert v(desc(432, 192, in_swish=1), 3) == 7000 + 28 * 10 + 1  # ... gated
+    assert v(desc(108, 48), 2) == 7000 + 8 * 10 + 1
+    assert v(desc(108, 48, in_swish=1), 3) == 1000 + 8 * 10 + 2    # gated narrow project conv: stays on the persistent kernel
+    assert v(desc(96, 432)) == 7000 + 6 * 10 + 2          # wide expand conv
+    assert v(desc(192, 432)) == 2500 + 2 * 12             # stays on the x-tile kernel
 
 
 FIRST_CASES = [
@@ -603,34 +735,6 @@ def _run_march(x, conv, bn, act, dtype=torch.bfloat16):
     return out, part, pb.meta[-1]["kernel"]
 
 
-@pytest.mark.parametrize("c", [56, 108, 432])
-@pytest.mark.parametrize("inst", ["1:8,3", "1:8,2", "1:4,4", "1:4,6", "1:4,3", "2:8,2", "2:4,3", "2:4,2"])
-@pytest.mark.parametrize("tc", [4, 16])
-def test_dwconv3d_march2_instances(inst, tc, c, monkeypatch):
-    """Second-generation T-marching stencil: every (channels per thread, outputs per strip) instance, with and without T chunks, on
-    ragged shapes (T = 9, W not a multiple of any strip width), 56 / 108 / 432 channels (weight-row strides 64 / 128 / 512, a channel
-    count that is not a multiple of 8 values per group included), Swish epilogue and SE partial sums -- against torch, and
-    BIT-IDENTICAL to round 1's kernel (same fp32 summation order per output element)."""
-    stride, chwt = inst.split(":")
-    stride = int(stride)
-    x, conv, bn, pre = _march_case(stride, c)
-    ref = pre * torch.sigmoid(pre)
-    monkeypatch.setenv("PASN_DWMFMA", "0")  # the VALU generations against each other (planes this narrow take the matrix-core stencil)
-    monkeypatch.setenv("PASN_DWM2", f"{chwt},{tc}")
-    out, part, kernel = _run_march(x, conv, bn, "swish")
-    ch, wt = chwt.split(",")
-    assert kernel == f"dwconv3d_march2_kernel<{stride},{wt},{ch}>", kernel
-    atol, rtol = _tols(torch.bfloat16)
-    assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"march2 {inst} tc{tc} c{c}")
-    want = pre.sum(dim=(2, 3, 4))
-    assert_close(part.sum(dim=1)[:, :c].cpu(), want, 2e-2 * float(want.abs().max()), 0, "SE partial sums")
-    assert float(out[..., c:].abs().max() if out.shape[-1] > c else 0.0) == 0.0, "padded channels must stay zero"
-    monkeypatch.setenv("PASN_DWM2", "0")
-    out1, _, kernel1 = _run_march(x, conv, bn, "swish")
-    assert kernel1.startswith("dwconv3d_march_kernel<")
-    assert torch.equal(out, out1), "march2 must reproduce round 1's stencil bit for bit"
-
-
 @pytest.mark.parametrize("c", [24, 56, 108, 432])
 @pytest.mark.parametrize("geom", ["0,0", "4,1", "4,3", "16,2", "2,1000"])
 @pytest.mark.parametrize("thw", [(9, 11, 13), (9, 14, 22), (5, 7, 7), (4, 30, 8)])
@@ -642,7 +746,6 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     sums, against torch; and against round 1's VALU stencil within the bf16 rounding of the weights (the only arithmetic difference:
     fp32 accumulation in both)."""
     tc, upb = geom.split(",")
-    monkeypatch.delenv("PASN_DWM2", raising=False)
     monkeypatch.setenv("PASN_DWMFMA", "1")  # every stride-1 layer (default: only the planes at most 8 wide)
     if tc != "0":
         monkeypatch.setenv("PASN_DWMFMA_TC", tc)
@@ -663,45 +766,13 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     assert float(d.max()) <= 2.0 ** -6 * max(1.0, float(out1.float().abs().max())), float(d.max())
 
 
-@pytest.mark.parametrize("c", [24, 56, 108, 432])
-@pytest.mark.parametrize("geom", ["0,0", "4,1", "4,3", "2,1000"])
-@pytest.mark.parametrize("thw", [(9, 22, 26), (9, 28, 44), (5, 19, 33), (4, 60, 18)])
-def test_dwconv3d_mfma_stride2(thw, geom, c, monkeypatch):
-    """Matrix-core stencil at stride 2 in H and W (the first stencil of every X3D stage): staged rows 32 positions wide, operand reads
-    two positions apart, 3 output rows per region -- even and odd input planes (the last staged row / column inside or outside the
-    image), ragged regions in both directions, T chunks, partial channel tiles and quads, Swish epilogue and SE partial sums, against
-    torch and against the VALU stencil within the bf16 rounding of the weights."""
-    tc, upb = geom.split(",")
-    monkeypatch.delenv("PASN_DWM2", raising=False)
-    monkeypatch.setenv("PASN_DWMFMA", "1")
-    monkeypatch.setenv("PASN_DWMFMA_S2", "1")  # opt-in: the stride-2 layers sit at the memory system's rate on either kernel
-    if tc != "0":
-        monkeypatch.setenv("PASN_DWMFMA_TC", tc)
-        monkeypatch.setenv("PASN_DWMFMA_UPB", upb)
-    x, conv, bn, pre = _march_case(2, c, thw=thw)
-    ref = pre * torch.sigmoid(pre)
-    out, part, kernel = _run_march(x, conv, bn, "swish")
-    assert kernel.startswith("dwconv3d_mfma_kernel<1,false,") and kernel.endswith(",2>"), kernel
-    atol, rtol = _tols(torch.bfloat16)
-    assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"mfma stencil stride 2 {thw} {geom} c{c}")
-    want = pre.sum(dim=(2, 3, 4))
-    assert_close(part.sum(dim=1)[:, :c].cpu(), want, 2e-2 * float(want.abs().max()), 0, "SE partial sums")
-    assert float(out[..., c:].abs().max() if out.shape[-1] > c else 0.0) == 0.0, "padded channels must stay zero"
-    monkeypatch.setenv("PASN_DWMFMA_S2", "0")
-    out1, part1, kernel1 = _run_march(x, conv, bn, "swish")
-    assert kernel1.startswith("dwconv3d_march_kernel<"), kernel1
-    d = (out.float() - out1.float()).abs()
-    assert float(d.max()) <= 2.0 ** -6 * max(1.0, float(out1.float().abs().max())), float(d.max())
-
-
 @pytest.mark.parametrize("wt", [2, 3])
 @pytest.mark.parametrize("tc", [4, 8, 16])
 @pytest.mark.parametrize("stride", [1, 2])
 def test_dwconv3d_march_variants(stride, tc, wt, monkeypatch):
     """T-marching stencil: every (outputs per strip, T chunk) instance on a shape with T = 9 (chunk halos, a partial last
     chunk), ragged W for both strip widths and SE partial sums; the cost model's own choice is covered by DW_CASES."""
-    monkeypatch.delenv("PASN_DWM2", raising=False)  # round 1's kernel (the second-generation one is opt-in, the matrix-core one takes
-    monkeypatch.setenv("PASN_DWMFMA", "0")           # narrow planes by default)
+    monkeypatch.setenv("PASN_DWMFMA", "0")  # the VALU stencil (stride-1 layers take the matrix-core one by default)
     monkeypatch.setenv("PASN_DWM_WT", str(wt))
     monkeypatch.setenv("PASN_DWM_TC", str(tc))
     dtype = torch.bfloat16
@@ -783,82 +854,6 @@ def test_dwconv3d_and_se(case, dtype):
     gm = pre.mean(dim=(2, 3, 4), keepdim=True)
     gref = torch.sigmoid(se.fc2(F.relu(se.fc1(gm)))).reshape(n, c).detach()
     assert_close(gate[:, :c], gref, 1e-3 if dtype == torch.float32 else 1e-2, 0, "SE gate")
-
-
-FUSED_CASES = [
-    # cin, inner, stride, (T,H,W), act, pool
-    (24, 54, 1, (5, 13, 30), "swish", False),   # stage-2 style, W > tile width (2 W tiles), ragged H
-    (24, 54, 2, (3, 18, 20), "none", True),     # stride 2 + SE partial sums
-    (48, 108, 1, (4, 9, 9), "none", True),      # two 32-channel MFMA tiles + tail
-    (96, 216, 1, (3, 14, 14), "swish", False),  # channel-chunked (216 inner channels)
-    (192, 432, 1, (2, 7, 7), "none", True),     # widest stage, many chunks, T = 2 (prologue-only ring)
-    (96, 432, 2, (1, 14, 14), "swish", False),  # T = 1
-    # x3d_front_kernel (7x7 planes: expand conv into an fp32 LDS plane tile, stencil from it; opt-in, bf16)
-    (192, 432, 1, (16, 7, 7), "none", True),    # benchmark stage-5 shape: two T chunks, partial last channel tile, SE sums
-    (192, 432, 1, (9, 7, 7), "swish", False),   # partial second chunk (1 frame), Swish epilogue
-    (96, 216, 1, (3, 7, 7), "swish", True),     # single short chunk, K = 96
-]
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", FUSED_CASES)
-def test_x3d_expand_dw_fused(case, dtype, monkeypatch):
-    """Fused expand(1x1x1)+BN+ReLU -> depthwise 3x3x3+BN(+Swish)(+SE sums) == the two unfused torch ops."""
-    monkeypatch.setenv("PASN_FUSED", "1")  # the fused launches are opt-in (profiles/README.md); this test always exercises them
-    monkeypatch.setenv("PASN_FRONT", "1")  # 7x7 planes take x3d_front_kernel, everything else x3d_expand_dw_kernel
-    cin, ci, s, thw, act, pool = case
-    torch.manual_seed(13)
-    n = 2
-    x = torch.randn(n, cin, *thw)
-    conv_a = nn.Conv3d(cin, ci, 1, bias=False)
-    conv_b = nn.Conv3d(ci, ci, 3, (1, s, s), 1, groups=ci, bias=False)
-    bn_a, bn_b = nn.BatchNorm3d(ci), nn.BatchNorm3d(ci)
-    with torch.no_grad():
-        for bn in (bn_a, bn_b):
-            bn.weight.uniform_(0.5, 1.5)
-            bn.bias.normal_(0, 0.3)
-            bn.running_mean.normal_(0, 0.3)
-            bn.running_var.uniform_(0.5, 1.5)
-    bn_a.eval(), bn_b.eval()
-    ca = nn.Conv3d(cin, ci, 1, bias=False)
-    ca.weight.data = _rt(conv_a.weight.data, dtype)
-    e = _rt(F.relu(bn_a(ca(_rt(x, dtype)))), dtype)  # the expanded activation is held in the compute dtype
-    pre = bn_b(conv_b(e)).detach()
-    ref = pre * torch.sigmoid(pre) if act == "swish" else pre
-
-    from protoasnet_amd import _lib
-    from protoasnet_amd.backbones import _SE
-
-    pb = _pb(dtype)
-    xa, xs = _cl_input(pb, x, dtype)
-    mods = [m.to(DEV) for m in (conv_a, bn_a, conv_b, bn_b)]
-    atol, rtol = _tols(dtype)
-    if not pool:
-        y = pb.expand_dw(xa, *mods, act=act)
-        assert pb.meta[-1]["kind"] == "expand_dw", "the fused kernel must cover this geometry"
-        out = _run_single(pb, xa, y, xs)
-        assert_close(_from_cl(out, ci), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"fused {case}")
-        if out.shape[-1] > ci:
-            assert float(out[..., ci:].float().abs().max()) == 0.0
-        return
-    se = _SE(ci)
-    with torch.no_grad():
-        for q in se.parameters():
-            q.normal_(0, 0.2)
-    y, pooled = pb.expand_dw(xa, *mods, act=act, pool=True)
-    assert pb.meta[-1]["kind"] == "expand_dw"
-    gate_buf = pb.se_gate(pooled, se.fc1.to(DEV), se.fc2.to(DEV))
-    pb.bufs[gate_buf].external = True
-    plan = pb.finish(xa, y)
-    gate = torch.empty(n, y.Cp, dtype=torch.float32, device=DEV)
-    plan.ptrs[gate_buf] = gate.data_ptr()
-    out = plan.run(xs)
-    torch.cuda.synchronize()
-    assert_close(_from_cl(out, ci), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"fused {case}")
-    se = se.cpu()
-    gm = pre.mean(dim=(2, 3, 4), keepdim=True)
-    gref = torch.sigmoid(se.fc2(F.relu(se.fc1(gm)))).reshape(n, ci).detach()
-    assert_close(gate[:, :ci], gref, 1e-3 if dtype == torch.float32 else 1e-2, 0, "SE gate from fused partial sums")
 
 
 @pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])

