@@ -143,6 +143,17 @@ int pasn_conv3d_fwd(const void* x, const void* w, const float* scale, const floa
  * pasn_conv3d_pair_supported() says whether the geometry is covered; otherwise call pasn_conv3d_fwd twice.
  */
 int pasn_conv3d_pair_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype);
+/* Which kernel the pair takes: 0 none, 1 pwconv_xpair_kernel (a block per 64-position tile), 2 pwconv_ws_kernel in pair mode (persistent
+ * blocks, both weight sets in registers).  flags bit 0: a gate tensor will be passed.  For profilers and benchmarks. */
+int pasn_conv3d_pair_variant(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype, int flags);
+/* The chained pair whose first conv's squeeze-excite gate is computed in the launch's prologue from the stencil's pool partial rows
+ * (arguments as pasn_conv3d_se_fwd + pasn_conv3d_pair_fwd): stencil -> ONE launch -> next stencil for an X3D SE block that is followed by a
+ * block without shortcut.  _supported() = 0: pasn_se_gate_fwd + pasn_conv3d_pair_fwd. */
+int pasn_conv3d_pair_se_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype, int Cse);
+int pasn_conv3d_pair_se_fwd(const void* x, const void* w1, const float* scale1, const float* bias1, const void* residual,
+                            const float* pool_partial, int pool_blocks, int positions, const float* fc1_w, const float* fc1_b,
+                            const float* fc2_w, const float* fc2_b, int Cse, void* y1, const pasn_conv_desc* d1, const void* w2,
+                            const float* scale2, const float* bias2, void* y2, const pasn_conv_desc* d2, int dtype, void* stream);
 int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* scale1, const float* bias1, const void* residual,
                          const float* gate, void* y1, const pasn_conv_desc* d1, const void* w2, const float* scale2,
                          const float* bias2, void* y2, const pasn_conv_desc* d2, int dtype, void* stream);

@@ -45,6 +45,10 @@ SIGNATURES = {
     "pasn_x3d_stem_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
     "pasn_conv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_pair_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int]),
+    "pasn_conv3d_pair_variant": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_int]),
+    "pasn_conv3d_pair_se_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_int]),
+    "pasn_conv3d_pair_se_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, POINTER(ConvDesc)] + [c_void_p] * 4
+                                + [POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_pair_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc),
                                      c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_variant": (c_int, [POINTER(ConvDesc), c_int, c_int]),

@@ -302,6 +302,12 @@ class X3DFeatures(_plan.HipTrunk):
                     if fuse_short:  # (not combined with the fused shortcut: different kernels)
                         sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
                         fuse_short = False
+                    if nxt is not None and nxt.shortcut is None:  # ... chained with the next block's expand conv where that is covered
+                        pair = pb.conv_pair(y, blk.conv_c, blk.bn_c, "relu", sc, nxt.conv_a, nxt.bn_a, "relu", in_swish=True,
+                                            se=(gate[1], blk.se.fc1, blk.se.fc2))
+                        if pair is not None:
+                            x, pre = pair
+                            continue
                     yc = pb.conv_se(y, blk.conv_c, blk.bn_c, "relu", sc, gate[1], blk.se.fc1, blk.se.fc2)
                     if yc is not None:
                         x, pre = yc, None

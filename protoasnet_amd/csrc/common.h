@@ -72,7 +72,7 @@ int launch_pw_xtile(const void* x, const void* w, const float* scale, const floa
                     void* y, const pasn_conv_desc& d, hipStream_t s);
 // pwconv_ws.hip: weight-stationary pointwise conv (bf16, fragment-major weights): persistent blocks, LDS-DMA stage ring; ok = 0: not covered
 struct WsGeom {
-    int ok, KS, MT, CT, PT, NW, gy, NS;    // template k-steps, 32-position sub-tiles per wave, waves along channels / positions, channel groups, stages
+    int ok, KS, KS2, MT, CT, PT, NW, gy, NS;  // (KS2: second conv of a chained pair, 0 = single conv) template k-steps, 32-position sub-tiles per wave, waves along channels / positions, channel groups, stages
     int rpb, nslots, abl;                  // rows (positions) per block, blocks per channel group, timing ablations (PASN_WS_ABL)
     int xreg, greg, rreg, stage_bytes, lds_bytes;  // stage regions (X tile, gate rows, residual tile), whole KiB each
 };
@@ -85,10 +85,17 @@ struct WsSe {
     const float *w1, *b1, *w2, *b2;
     int C, cse;
 };
-WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res, bool se_prologue = false);
+// second conv of a chained pair (w2 == NULL: single conv): fragment-major weights, fp32 scale / bias (NULL = 1 / 0), output, channel counts, k-steps, activation
+struct WsPair {
+    const __bf16* w2;
+    const float *scale2, *bias2;
+    __bf16* y2;
+    int Cout2, Cout2_p, nks2, act2;
+};
+WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res, bool se_prologue = false, const pasn_conv_desc* d2 = nullptr);
 int pw_ws_variant(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res);  // 7000 + KS * 10 + MT, or 0
 int launch_pw_ws(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate, void* y,
-                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s, const WsSe* se = nullptr);
+                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s, const WsSe* se = nullptr, const WsPair* pair = nullptr);
 // pwconv_xpair.hip: project conv of block i chained with the expand conv of block i+1 (bf16); 0 = not covered
 int pw_xpair_ks(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, int* ks2_out);
 int launch_pw_xpair(const void* x, const void* w1, const float* s1, const float* b1, const void* res, const float* gate, void* y1,

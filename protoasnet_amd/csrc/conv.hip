@@ -818,9 +818,42 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     return launch_conv3d<__bf16>(x, w, scale, bias, residual, gate, y, *d, s);
 }
 
-extern "C" int pasn_conv3d_pair_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype) {
+// 0 = not covered, 1 = pwconv_xpair_kernel (one block per 64-position tile), 2 = the weight-stationary persistent kernel in pair mode.
+// flags: bit 0 = a gate tensor (or the squeeze-excite operands) will be passed.
+extern "C" int pasn_conv3d_pair_variant(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype, int flags) {
     if (!conv_desc_ok(d1) || !conv_desc_ok(d2)) return 0;
-    return pw_xpair_ks(*d1, *d2, dtype, nullptr) != 0;
+    pasn_conv_desc f1 = *d1, f2 = *d2;
+    f1.w_frag = f2.w_frag = 1;
+    if (pw_ws_geom(f1, dtype, (flags & 1) != 0, true, false, &f2).ok) return 2;
+    return pw_xpair_ks(*d1, *d2, dtype, nullptr) != 0 ? 1 : 0;
+}
+
+// The chained pair with the first conv's squeeze-excite gate computed in the launch's prologue (pasn_conv3d_se_fwd + pasn_conv3d_pair_fwd in one).
+extern "C" int pasn_conv3d_pair_se_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype, int Cse) {
+    if (!conv_desc_ok(d1) || !conv_desc_ok(d2) || Cse <= 0 || Cse > 32 || Cse % 4 != 0 || d1->Cin > 512) return 0;
+    if (const char* e = getenv("PASN_NO_SE_PROLOGUE"))
+        if (e[0] == '1') return 0;
+    pasn_conv_desc f1 = *d1, f2 = *d2;
+    f1.w_frag = f2.w_frag = 1;
+    return pw_ws_geom(f1, dtype, true, true, true, &f2).ok;
+}
+
+extern "C" int pasn_conv3d_pair_se_fwd(const void* x, const void* w1, const float* scale1, const float* bias1, const void* residual,
+                                       const float* pool_partial, int pool_blocks, int positions, const float* fc1_w, const float* fc1_b,
+                                       const float* fc2_w, const float* fc2_b, int Cse, void* y1, const pasn_conv_desc* d1, const void* w2,
+                                       const float* scale2, const float* bias2, void* y2, const pasn_conv_desc* d2, int dtype, void* stream) {
+    PASN_REQUIRE(x && w1 && w2 && y1 && y2 && residual && pool_partial && fc1_w && fc1_b && fc2_w && fc2_b, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(d1) && conv_desc_ok(d2) && pool_blocks > 0 && positions > 0, "bad geometry");
+    PASN_REQUIRE(dtype == PASN_BF16 && d1->w_frag == 1 && d2->w_frag == 1, "bf16 with fragment-major weights only");
+    PASN_REQUIRE(pasn_conv3d_pair_se_supported(d1, d2, dtype, Cse), "pair not covered (pasn_conv3d_pair_se_supported returns 0)");
+    const WsGeom wg = pw_ws_geom(*d1, dtype, true, true, true, d2);
+    const WsSe se = {pool_partial, pool_blocks, 1.0f / (float)positions, fc1_w, fc1_b, fc2_w, fc2_b, d1->Cin, Cse};
+    const WsPair p2 = {(const __bf16*)w2, scale2, bias2, (__bf16*)y2, d2->Cout, d2->Cout_p, d2->w_kc / 16, d2->act};
+    return launch_pw_ws(x, w1, scale1, bias1, residual, nullptr, y1, *d1, wg, (hipStream_t)stream, &se, &p2);
+}
+
+extern "C" int pasn_conv3d_pair_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype) {
+    return pasn_conv3d_pair_variant(d1, d2, dtype, 0) != 0 || pasn_conv3d_pair_variant(d1, d2, dtype, 1) != 0;
 }
 
 extern "C" int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* scale1, const float* bias1, const void* residual,
@@ -829,6 +862,10 @@ extern "C" int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* 
     PASN_REQUIRE(x && w1 && w2 && y1 && y2 && residual, "null pointer");
     PASN_REQUIRE(conv_desc_ok(d1) && conv_desc_ok(d2), "bad geometry");
     PASN_REQUIRE(dtype == PASN_BF16 && d1->w_frag == 1 && d2->w_frag == 1, "bf16 with fragment-major weights only");
+    if (const WsGeom wg = pw_ws_geom(*d1, dtype, gate != nullptr, true, false, d2); wg.ok) {  // persistent blocks, both weight sets in registers
+        const WsPair p2 = {(const __bf16*)w2, scale2, bias2, (__bf16*)y2, d2->Cout, d2->Cout_p, d2->w_kc / 16, d2->act};
+        return launch_pw_ws(x, w1, scale1, bias1, residual, gate, y1, *d1, wg, (hipStream_t)stream, nullptr, &p2);
+    }
     PASN_REQUIRE(pw_xpair_ks(*d1, *d2, dtype, nullptr) != 0, "pair not covered (pasn_conv3d_pair_supported returns 0)");
     return launch_pw_xpair(x, w1, scale1, bias1, residual, gate, y1, *d1, w2, scale2, bias2, y2, *d2, (hipStream_t)stream);
 }

@@ -44,12 +44,18 @@ __device__ __forceinline__ void ws_wait_all_but(int n) {  // n wave-uniform: all
 // barrier WITHOUT the fence of __syncthreads() (that fence is `s_waitcnt vmcnt(0)`: it would drain the DMA groups in flight)
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KS, int MT, bool XF, bool RES>
+// KS2 > 0: CHAINED PAIR (an X3D block's project conv and the next block's expand conv): after the first conv's epilogue the finished
+// block-output tile goes to HBM AND, as bf16, into an LDS tile; behind one more barrier every wave w < ctiles2 computes channel tile w of the
+// second conv for BOTH 32-position halves of the 64-position tile from it (second weight set in registers too).  Pair mode: PT = 2, MT = 1.
+template <int KS, int MT, bool XF, bool RES, int KS2 = 0>
 __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         const __bf16* __restrict__ res, const float* __restrict__ gate,
                                                         __bf16* __restrict__ y, int M, int S, int N, int Cin_p, int Cout, int Cout_p,
-                                                        int nks, int act, int in_swish, WsGeom g, WsSe se) {
+                                                        int nks, int act, int in_swish, WsGeom g, WsSe se, WsPair pr2) {
+    static_assert(KS2 == 0 || MT == 1, "pair mode: one 32-position sub-tile per wave in the first conv");
+    constexpr int MT2 = 2;             // pair mode: 32-position halves per wave in the second conv (PT = 2)
+    constexpr int Y1PL = 2 * KS2 + 1;  // 16-byte slots per row of the handed-over tile (odd)
     extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NS] stages: X tile | gate rows | residual tile, each a whole number of KiB
     constexpr int PPRL = 2 * KS + 1;  // 16-byte slots per staged X row: exactly KS k-steps (zero beyond Cin_p) + one pad slot (odd stride)
     constexpr int GPR = KS * 4;       // 16-byte slots per staged gate row (KS * 16 floats)
@@ -109,6 +115,38 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
         yoff[pr] = ok ? (unsigned)(pt * MT * 32 + c) * yrow + (unsigned)ch * 2u : WS_OOB;
     }
     const bool tail = live && ct * 32 + 32 > Cout;  // wave-uniform: this tile holds channels beyond the real count (stored as zeros)
+    // ---- pair mode: the second conv's stationary weights and epilogue constants (channel tile = wave) ----------------------------------
+    const int ctiles2 = KS2 ? (pr2.Cout2_p + 31) >> 5 : 0;
+    const bool live2 = KS2 && wave < ctiles2;
+    const unsigned y2row = KS2 ? (unsigned)pr2.Cout2_p * 2u : 0u;
+    const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(KS2 ? pr2.y2 : y, 0, KS2 ? row1 * y2row : 0u, 0x00020000);
+    bf16x8 A2[KS2 ? KS2 : 1];
+    float sc2[KS2 ? 2 : 1][8], bs2[KS2 ? 2 : 1][8];
+    unsigned y2off[2] = {WS_OOB, WS_OOB};
+    char* const y1t = smem + NS * g.stage_bytes;  // [BM][Y1PL] slots: the first conv's output tile as the second conv's operand
+    if (KS2) {
+        const int c2 = live2 ? wave : ctiles2 - 1;
+        const __bf16* ab2 = pr2.w2 + ((long)c2 * pr2.nks2 * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) A2[ks] = load_frag<__bf16>(ab2 + (size_t)(ks < pr2.nks2 ? ks : pr2.nks2 - 1) * 512);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int ch = wave * 32 + 16 * pr + 8 * h;
+            const bool ok = live2 && ch < pr2.Cout2_p;
+            const int chc = ok ? ch : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sc2[pr][j] = 1.0f;
+                bs2[pr][j] = 0.0f;
+            }
+            if (pr2.scale2) load8(pr2.scale2 + chc, sc2[pr]);
+            if (pr2.bias2) load8(pr2.bias2 + chc, bs2[pr]);
+            y2off[pr] = ok ? (unsigned)c * y2row + (unsigned)ch * 2u : WS_OOB;
+        }
+        // the handed-over tile's pad slot and the k columns beyond the first conv's channels stay zero: cleared once, never written
+        for (int i = threadIdx.x; i < BM * Y1PL; i += NW * 64) reinterpret_cast<uint4*>(y1t)[i] = uint4{0u, 0u, 0u, 0u};
+    }
+    const bool tail2 = live2 && wave * 32 + 32 > pr2.Cout2;
 
     // ---- DMA roles.  Instruction j of a region covers its LDS slots 64 j .. 64 j + 63; wave `wave` issues j = wave, wave + NW, ... -------
     const int nix = (abl & 4) ? 0 : (BM * PPRL + 63) >> 6;
@@ -116,7 +154,7 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
     const int nir = RES && !(abl & 16) ? (BM * RPL + 63) >> 6 : 0;
     auto mine = [&](int ni) -> int { return ni > wave ? (ni - wave + NW - 1) / NW : 0; };
     const int kgrp = mine(nix) + mine(nig) + mine(nir);  // DMA instructions of this wave per tile
-    const int kst = live && !(abl & 2) ? 2 * MT : 0;       // stores of this wave per tile
+    const int kst = ((live ? 2 * MT : 0) + (live2 ? 2 * MT2 : 0)) * (abl & 2 ? 0 : 1);  // stores of this wave per tile
     const float rpl_inv = 1.0f / (float)RPL;
     auto issue = [&](int i, int stg) {  // the DMA group of this block's tile i into stage stg
         char* sb = smem + stg * g.stage_bytes;
@@ -182,6 +220,11 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
         if (ks >= nks) A[ks] = zero_frag<__bf16>();  // wave-uniform; only the template steps beyond w_kc
+    if (KS2) {
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+            if (ks >= pr2.nks2) A2[ks] = zero_frag<__bf16>();
+    }
     if (se_on) {
         // both FC weight sets are requested first (they do not depend on the clip), then per clip: mean over positions from the partial rows
         // (fixed order) -> fc1 + ReLU (a wave per hidden unit, lanes over channels) -> fc2 + sigmoid (a thread per channel).  Scratch: the X
@@ -328,6 +371,49 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
                     if (!(abl & 2))
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), yrsrc, (int)(yoff[pr] + (m0 + (unsigned)(mt * 32)) * yrow), 0, 0);
+                    if (KS2 && yoff[pr] != WS_OOB)  // the same 8 channels of this position, as the second conv's operand
+                        *reinterpret_cast<bf16x8*>(y1t + ((pt * 32 + c) * Y1PL + ct * 4 + 2 * pr + h) * 16) = o;
+                }
+            }
+        }
+        if (KS2) {
+            ws_barrier();  // the block-output tile is complete (and every wave is past its reads of the X tile)
+            if (live2) {
+                f32x16 acc2[MT2];
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc2[mt][e] = 0.0f;
+                const char* yb = y1t + (c * Y1PL + h) * 16;
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) {
+#pragma unroll
+                    for (int mt = 0; mt < MT2; ++mt) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(yb + (mt * 32 * Y1PL + 2 * ks) * 16);
+                        acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[ks], b, acc2[mt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) {
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc2[mt][8 * pr + q]), __float_as_uint(acc2[mt][8 * pr + 4 + q]), false, false);
+                            v[q] = __uint_as_float(sw[0]);
+                            v[4 + q] = __uint_as_float(sw[1]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc2[pr][e] + bs2[pr][e];
+                        act_vec(v, pr2.act2);
+                        if (tail2) mask_tail(v, pr2.Cout2 - (wave * 32 + 16 * pr + 8 * h));
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                        if (!(abl & 2))
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), y2rsrc, (int)(y2off[pr] + (m0 + (unsigned)(mt * 32)) * y2row), 0, 0);
+                    }
                 }
             }
         }
@@ -346,8 +432,17 @@ static int ws_ks(int nks) {
 }
 
 // Geometry of the launch; ok = 0: the layer stays on the other pointwise kernels.
-WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res, bool se_prologue) {
+WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res, bool se_prologue, const pasn_conv_desc* d2) {
     WsGeom g{};
+    if (d2) {  // chained pair: the second conv must be a plain stride-1 pointwise conv on the first one's output
+        if (const char* e = getenv("PASN_WSPAIR"))
+            if (e[0] == '0') return g;
+        const bool ok2 = d2->kt == 1 && d2->kh == 1 && d2->kw == 1 && !d2->pt && !d2->ph && !d2->pw && d2->st == 1 && d2->sh == 1 && d2->sw == 1 &&
+                         d2->N == d.N && d2->To == d.To && d2->Ho == d.Ho && d2->Wo == d.Wo && d2->Cin == d.Cout && d2->Cin_p == d.Cout_p &&
+                         d2->w_frag == 1 && d2->w_kc % 16 == 0 && d2->w_kc >= d2->Cin_p && !d2->in_swish && has_res &&
+                         d2->w_rows >= ((d2->Cout_p + 31) / 32) * 32 && (long)d.N * d.To * d.Ho * d.Wo * d2->Cout_p * 2 < (1L << 30);
+        if (!ok2) return g;
+    }
     if (const char* e = getenv("PASN_WS"))
         if (e[0] == '0') return g;
     if (dtype != PASN_BF16 || d.w_frag != 1) return g;
@@ -369,9 +464,9 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     //   expand:                     96->432 38 -> 30.5, 48->216 48 -> 45;   48->108 28 -> 29.5, 192->432 20 -> 21.5, head convs 10.6 -> 12.8
     // PASN_WS=2 takes every layer the kernel covers (the parity tests do).
     const char* mode = getenv("PASN_WS");
-    if (!(mode && mode[0] == '2')) {
+    if (!(mode && mode[0] == '2') && !d2) {
         bool take;
-        if (xf) take = ks == 28;
+        if (xf) take = ks == 28 || (se_prologue && ks == 14);  // (with the gate in the prologue the stand-alone gate launch is saved as well)
         else if (has_res) take = ks != 14;
         else take = ctiles >= 7 && ks <= 6;
         if (!take) return g;
@@ -383,6 +478,19 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     if (const char* e = getenv("PASN_WS_PT")) g.PT = max(1, min(8 / g.CT, atoi(e)));
     g.MT = (ks <= 16 && g.PT < 4) ? 2 : 1;
     if (const char* e = getenv("PASN_WS_MT")) g.MT = ks <= 16 ? max(1, min(2, atoi(e))) : 1;
+    int ks2 = 0, y1bytes = 0;
+    if (d2) {  // pair mode: 64-position tiles, (channel tile, position half) per wave in the first conv, channel tile = wave in the second
+        const int nks2 = d2->w_kc / 16, ct2 = (d2->Cout_p + 31) / 32;
+        ks2 = nks2 <= 4 ? 4 : nks2 <= 6 ? 6 : 0;
+        if (!ks2 || !((ks == 14 && ks2 == 6) || (ks == 8 && ks2 == 4)) || g.gy != 1 || g.CT * 2 > 8 || ct2 > 8) return WsGeom{};
+        // measured in the pipeline (profiles/README entry 61): 216 -> 96 -> 216 plain 34.6 us vs 36.4 (pwconv_xpair), gated 46 vs 43 -- but 39 vs 53 once
+        // the gate is computed in the prologue and its launch is gone; 108 -> 48 -> 108: 70 / 92 us against 61 / 73 for the two separate launches
+        const char* pm = getenv("PASN_WSPAIR");
+        const bool all = pm && pm[0] == '2';
+        if (!all && (ks != 14 || (xf && !se_prologue))) return WsGeom{};
+        g.PT = 2;
+        g.MT = 1;
+    }
     auto kib = [](int b) { return (b + 1023) / 1024 * 1024; };
     const int rpl = (d.Cout_p / 8) | 1;
     for (;;) {  // the largest tile whose two stages fit the LDS: halve the sub-tiles per wave, then the waves along the positions
@@ -391,17 +499,20 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
         g.greg = xf ? kib(2 * ks * 64) : 0;
         g.rreg = has_res ? kib(BM * rpl * 16) : 0;
         g.stage_bytes = g.xreg + g.greg + g.rreg;
-        if ((xf ? 3 : 2) * g.stage_bytes <= 160 * 1024) break;  // the input transform works one tile ahead of the MFMAs: three stages
+        y1bytes = d2 ? kib(BM * (2 * ks2 + 1) * 16) : 0;
+        if ((xf ? 3 : 2) * g.stage_bytes + y1bytes <= 160 * 1024) break;  // the input transform works one tile ahead of the MFMAs: three stages
+        if (d2) return WsGeom{};
         if (g.MT == 2) g.MT = 1;
         else if (g.PT > 1) g.PT /= 2;
         else return g;
     }
     const int BM = 32 * g.PT * g.MT;
     if (S < BM) return g;  // a tile may touch at most two clips (two staged gate rows)
-    g.NS = (xf || 3 * g.stage_bytes <= 150 * 1024) ? 3 : 2;
+    g.NS = (xf || 3 * g.stage_bytes + y1bytes <= 150 * 1024) ? 3 : 2;
     if (const char* e = getenv("PASN_WS_NS")) g.NS = xf ? 3 : max(2, min(4, atoi(e)));
-    while (g.NS > 2 && g.NS * g.stage_bytes > 160 * 1024) --g.NS;
-    g.lds_bytes = g.NS * g.stage_bytes;
+    while (g.NS > 2 && g.NS * g.stage_bytes + y1bytes > 160 * 1024) --g.NS;
+    g.lds_bytes = g.NS * g.stage_bytes + y1bytes;
+    g.KS2 = ks2;
     int bpc = g.lds_bytes <= 78 * 1024 ? 2 : 1;
     if (const char* e = getenv("PASN_WS_BPC")) bpc = max(1, atoi(e));
     const long max_slots = max(1, 256 * bpc / g.gy);
@@ -413,7 +524,8 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     if (se_prologue && (rpb > S || 3 * g.stage_bytes > 160 * 1024 || d.Cin_p > 512 || GPR_fits(ks, d.Cin_p) == 0)) return WsGeom{};  // a block touches <= 2 clips; scratch in stage 2
     g.abl = getenv("PASN_WS_ABL") ? atoi(getenv("PASN_WS_ABL")) : 0;
     g.NW = g.CT * g.PT;
-    if (xf && !(getenv("PASN_WS_HELP") && getenv("PASN_WS_HELP")[0] == '0')) g.NW = 8;  // helper waves: the input transform spread evenly over the four SIMDs
+    if (xf && !(getenv("PASN_WS_HELP") && getenv("PASN_WS_HELP")[0] == '0')) g.NW = 8;
+    if (d2) g.NW = 8;  // covers the second conv's channel tiles (<= 8) and the first conv's (channel tile, half) grid  // helper waves: the input transform spread evenly over the four SIMDs
     g.ok = 1;
     return g;
 }
@@ -424,20 +536,23 @@ int pw_ws_variant(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
 }
 
 int launch_pw_ws(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate, void* y,
-                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s, const WsSe* sep) {
+                 const pasn_conv_desc& d, const WsGeom& g, hipStream_t s, const WsSe* sep, const WsPair* pairp) {
     const WsSe se = sep ? *sep : WsSe{nullptr, 0, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const WsPair pr2 = pairp ? *pairp : WsPair{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    PASN_REQUIRE((g.KS2 != 0) == (pairp != nullptr), "pwconv_ws: pair geometry does not match the call");
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const int S = d.To * d.Ho * d.Wo;
     PASN_REQUIRE(g.ok && g.lds_bytes <= 160 * 1024 && (g.rreg != 0) == (res != nullptr), "pwconv_ws: geometry does not match the call");
     const bool xf = gate != nullptr || d.in_swish != 0 || sep != nullptr;
     PASN_REQUIRE(!(sep && gate), "pwconv_ws: either a gate tensor or the squeeze-excite operands");
     const dim3 grid((unsigned)(g.nslots * g.gy)), block((unsigned)(64 * g.NW));
-#define PASN_WS3(KS_, MT_, XF_, RES_)                                                                                              \
+#define PASN_WS3(KS_, MT_, XF_, RES_) PASN_WS4(KS_, MT_, XF_, RES_, 0)
+#define PASN_WS4(KS_, MT_, XF_, RES_, KS2_)                                                                                        \
     do {                                                                                                                          \
-        PASN_MAX_LDS(160 * 1024, pwconv_ws_kernel<KS_, MT_, XF_, RES_>);                                                         \
-        hipLaunchKernelGGL((pwconv_ws_kernel<KS_, MT_, XF_, RES_>), grid, block, (size_t)g.lds_bytes, s, (const __bf16*)x,        \
+        PASN_MAX_LDS(160 * 1024, pwconv_ws_kernel<KS_, MT_, XF_, RES_, KS2_>);                                                   \
+        hipLaunchKernelGGL((pwconv_ws_kernel<KS_, MT_, XF_, RES_, KS2_>), grid, block, (size_t)g.lds_bytes, s, (const __bf16*)x,  \
                            (const __bf16*)w, scale, bias, (const __bf16*)res, gate, (__bf16*)y, (int)M, S, d.N, d.Cin_p, d.Cout,   \
-                           d.Cout_p, d.w_kc / 16, d.act, d.in_swish, g, se);                                                      \
+                           d.Cout_p, d.w_kc / 16, d.act, d.in_swish, g, se, pr2);                                                 \
     } while (0)
 #define PASN_WS2(KS_, MT_)                                   \
     do {                                                     \
@@ -452,6 +567,18 @@ int launch_pw_ws(const void* x, const void* w, const float* scale, const float* 
         if (g.MT == 2) PASN_WS2(KS_, 2);      \
         else PASN_WS2(KS_, 1);                \
     } while (0)
+    if (g.KS2) {  // chained pairs: (216 -> 96 -> 216) and (108 -> 48 -> 108), always with the residual
+        if (g.KS == 14 && g.KS2 == 6) {
+            if (xf) PASN_WS4(14, 1, true, true, 6);
+            else PASN_WS4(14, 1, false, true, 6);
+        } else if (g.KS == 8 && g.KS2 == 4) {
+            if (xf) PASN_WS4(8, 1, true, true, 4);
+            else PASN_WS4(8, 1, false, true, 4);
+        } else {
+            PASN_REQUIRE(false, "pwconv_ws: no pair instance");
+        }
+        return check_launch("pwconv_ws_kernel (pair)");
+    }
     switch (g.KS) {
         case 4: PASN_WS1(4); break;
         case 6: PASN_WS1(6); break;
@@ -464,6 +591,7 @@ int launch_pw_ws(const void* x, const void* w, const float* scale, const float* 
 #undef PASN_WS1
 #undef PASN_WS2
 #undef PASN_WS3
+#undef PASN_WS4
     return check_launch("pwconv_ws_kernel");
 }
 

@@ -425,9 +425,11 @@ class PlanBuilder:
 
     def conv_pair(self, x: Act, conv1: nn.Module, norm1: Optional[nn.Module], act1: str, residual: Act,
                   conv2: nn.Module, norm2: Optional[nn.Module], act2: str, in_gate: Optional[int] = None,
-                  in_swish: bool = False):
+                  in_swish: bool = False, se=None):
         """Two chained 1x1x1 convs in ONE launch (X3D: a block's project conv + the next block's expand conv): returns
-        (y1, y2), or None when the chained kernel does not cover the geometry (the caller then emits the two convs)."""
+        (y1, y2), or None when the chained kernel does not cover the geometry (the caller then emits the two convs).
+        ``se = (pooled, fc1, fc2)``: the first conv's squeeze-excite gate is computed in the launch's prologue from the stencil's pool
+        partial rows (no gate launch, no gate tensor); None is returned when THAT form is not covered."""
         if x.planar or self.dtype != torch.bfloat16 or conv1.groups != 1 or conv2.groups != 1:
             return None
         one = (1, 1, 1)
@@ -441,7 +443,12 @@ class PlanBuilder:
         y2 = self._out_act(mid, conv2.out_channels, one, one, (0, 0, 0))
         w2, kc2, rows2 = pack_conv_weight(conv2.weight, y1.Cp, self.dtype)
         d2 = self._desc(mid, y2, one, one, (0, 0, 0), act2, False, kc2, rows2)
-        if not int(self.lib.pasn_conv3d_pair_supported(ctypes.byref(d1), ctypes.byref(d2), self.code)):
+        if se is not None:
+            supported = (se[0][2].N, se[0][2].positions, se[0][2].Cp) == (x.N, x.positions, x.Cp) and \
+                int(self.lib.pasn_conv3d_pair_se_supported(ctypes.byref(d1), ctypes.byref(d2), self.code, se[1].out_channels))
+        else:
+            supported = int(self.lib.pasn_conv3d_pair_supported(ctypes.byref(d1), ctypes.byref(d2), self.code))
+        if not supported:
             self.bufs[y1.buf].nbytes = ALIGN  # never used
             self.bufs[y2.buf].nbytes = ALIGN
             return None
@@ -458,8 +465,25 @@ class PlanBuilder:
         r1, r2 = ctypes.byref(d1), ctypes.byref(d2)
         self._use(xb, rb, gb, y1b, y2b)
         pos = y1.N * y1.positions
-        self._note("conv_pair", f"pwconv_xpair_kernel<{max(8, kc1 // 16 + kc1 // 16 % 2)},{kc2 // 16 + kc2 // 16 % 2},"
-                                f"{'true' if (in_gate is not None or in_swish) else 'false'}>",
+        if se is not None:
+            (pool_buf, pool_blocks, py), fc1, fc2 = se
+            c, cse = x.C, fc1.out_channels
+            sw = [fc1.weight.detach().float().reshape(cse, c).contiguous(), fc1.bias.detach().float().contiguous(),
+                  fc2.weight.detach().float().reshape(c, cse).contiguous(), fc2.bias.detach().float().contiguous()]
+            self.keep += sw
+            sa = tuple(t.data_ptr() for t in sw)
+            self._use(pool_buf)
+            fse, npos = self.lib.pasn_conv3d_pair_se_fwd, x.positions
+            self._note("conv_pair+se", f"pwconv_ws_kernel<{max(8, kc1 // 16 + kc1 // 16 % 2)},1,true,true,{4 if kc2 // 16 <= 4 else 6}>[se]",
+                       (pos * (x.C + 2 * y1.C + y2.C) + y1.C * x.C + y2.C * y1.C) * self.es + (x.N * pool_blocks * c + 2 * c * cse) * 4,
+                       2 * pos * (y1.C * x.C + y2.C * y1.C) + 4 * x.N * c * cse)
+            self.ops.append(lambda ptrs, st: _lib.check(fse(ptrs[xb], a[0], a[1], a[2], ptrs[rb], ptrs[pool_buf], pool_blocks, npos, sa[0], sa[1],
+                                                            sa[2], sa[3], cse, ptrs[y1b], r1, a[3], a[4], a[5], ptrs[y2b], r2, code, st)))
+            return y1, y2
+        pv = int(self.lib.pasn_conv3d_pair_variant(r1, r2, self.code, int(in_gate is not None)))
+        xf_name = 'true' if (in_gate is not None or in_swish) else 'false'
+        self._note("conv_pair", f"pwconv_ws_kernel<{max(8, kc1 // 16 + kc1 // 16 % 2)},1,{xf_name},true,{4 if kc2 // 16 <= 4 else 6}>" if pv == 2 else
+                                f"pwconv_xpair_kernel<{max(8, kc1 // 16 + kc1 // 16 % 2)},{kc2 // 16 + kc2 // 16 % 2},{xf_name}>",
                    (pos * (x.C + 2 * y1.C + y2.C) + y1.C * x.C + y2.C * y1.C) * self.es + (x.N * x.C * 4 if in_gate is not None else 0),
                    2 * pos * (y1.C * x.C + y2.C * y1.C))
         self.ops.append(

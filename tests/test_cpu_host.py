@@ -157,10 +157,10 @@ def test_plan_shapes_and_arena(cfg, shape):
         gates = 15
     else:
         gates = sum((s2 if (c > max_c or (mfma_s2 and c < 432)) else 0) + (s1 if (c > max_c or mfma) else 0) for c, s2, s1 in se_blocks)
-    # round 3: the strided shortcut convs of stages 2 and 3 ride in their blocks' project-conv launches (pasn_conv3d_short_fwd), and the four
-    # gates of the 432-channel stage are computed in the project convs' prologues (pasn_conv3d_se_fwd) -- bf16 only, like the pairs
+    # round 3: the strided shortcut convs of stages 2 and 3 ride in their blocks' project-conv launches (pasn_conv3d_short_fwd), and the ten
+    # gates of the 216- and 432-channel stages are computed in the project convs' prologues (pasn_conv3d_se_fwd / _pair_se_fwd) -- bf16 only
     short_fused = 0 if os.environ.get("PASN_NO_SHORTFUSE") == "1" else 2
-    se_prologue = 0 if (os.environ.get("PASN_NO_SE_PROLOGUE") == "1" or os.environ.get("PASN_WS") == "0") else 4
+    se_prologue = 0 if (os.environ.get("PASN_NO_SE_PROLOGUE") == "1" or os.environ.get("PASN_WS") == "0") else 10
     assert n_ops == {"x3d_s": 1 + 26 * 3 - fused - paired + 4 + gates - short_fused - se_prologue, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
 
 

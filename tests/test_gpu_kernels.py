@@ -222,13 +222,15 @@ def test_pointwise_gate_many_clips():
     assert_close(_from_cl(out, cout), ref, atol * max(1.0, float(ref.abs().max())), rtol, "gate rows from global memory")
 
 
+@pytest.mark.parametrize("kernel", ["ws", "xpair"])
 @pytest.mark.parametrize("gate", [False, True])
 @pytest.mark.parametrize("c0,c1,c2", [(216, 96, 216), (108, 48, 108)])
-def test_conv_pair_chained(c0, c1, c2, gate, monkeypatch):
+def test_conv_pair_chained(c0, c1, c2, gate, kernel, monkeypatch):
     """Project conv (+BN + residual + ReLU, optional SE gate + Swish on its input) chained with the next expand conv
     (+BN + ReLU) in one launch == the two torch convs; three clips of 72 positions (a tile straddles two clips), M not a
     multiple of 64."""
     monkeypatch.setenv("PASN_XPAIR_ALL", "1")  # also the narrow (stage-3) instance, off by default
+    monkeypatch.setenv("PASN_WSPAIR", "2" if kernel == "ws" else "0")  # both implementations (2: every pair the persistent kernel covers, not only its default routes)
     dtype = torch.bfloat16
     torch.manual_seed(c0 + gate)
     n, thw = 3, (2, 6, 6)
@@ -262,7 +264,7 @@ def test_conv_pair_chained(c0, c1, c2, gate, monkeypatch):
         gt[:, :c0] = g.to(DEV)
         gbuf = pb._new_buf(gt.numel() * 4, external=True)
     pair = pb.conv_pair(xa, conv1.to(DEV), bn1.to(DEV), "relu", ra, conv2.to(DEV), bn2.to(DEV), "relu", in_gate=gbuf, in_swish=gate)
-    assert pair is not None and "xpair" in pb.meta[-1]["kernel"]
+    assert pair is not None and ("pwconv_ws_kernel" if kernel == "ws" else "xpair") in pb.meta[-1]["kernel"], pb.meta[-1]["kernel"]
     o1, o2 = pair
     pb.bufs[o1.buf].external = True
     plan = pb.finish(xa, o2)
@@ -500,6 +502,69 @@ def test_project_conv_with_se_gate_in_its_prologue(c, cout, cse, n, thw, stride,
     scale = max(1.0, float(ref.abs().max()))
     assert_close(_from_cl(out, cout), ref, 4e-2 * scale, 3e-2, f"project conv with SE prologue {c}->{cout}")
     assert_close(_from_cl(out, cout), _from_cl(two, cout), 1.6e-2 * scale, 1e-2, "prologue gate vs stand-alone gate launch")  # one bf16 ulp of the output
+
+
+@pytest.mark.parametrize("n,thw", [(3, (4, 9, 9)), (2, (3, 14, 14))])
+def test_chained_pair_with_se_gate_in_its_prologue(n, thw, monkeypatch):
+    """X3D stage-4 SE block followed by a block without shortcut: stencil (+ pool partial rows) -> ONE launch that computes the gate from
+    those rows, runs the gated project conv (+BN + residual + ReLU) and the next block's expand conv (+BN + ReLU) from the block output
+    kept on chip -- against the stand-alone gate launch + the chained pair with a gate tensor (pwconv_xpair), and against torch."""
+    dtype = torch.bfloat16
+    c, c1, c2, cse = 216, 96, 216, 16
+    torch.manual_seed(n + thw[1])
+    x = torch.randn(n, c, *thw)
+    conv_b = nn.Conv3d(c, c, 3, 1, 1, groups=c, bias=False)
+    conv_c, conv_a = nn.Conv3d(c, c1, 1, bias=False), nn.Conv3d(c1, c2, 1, bias=False)
+    bn_b, bn_c, bn_a = nn.BatchNorm3d(c), nn.BatchNorm3d(c1), nn.BatchNorm3d(c2)
+    fc1, fc2 = nn.Conv3d(c, cse, 1), nn.Conv3d(cse, c, 1)
+    with torch.no_grad():
+        for b in (bn_b, bn_c, bn_a):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+            b.running_mean.normal_(0, 0.3)
+            b.running_var.uniform_(0.5, 1.5)
+    for b in (bn_b, bn_c, bn_a):
+        b.eval()
+    conv_br = nn.Conv3d(c, c, 3, 1, 1, groups=c, bias=False)
+    conv_br.weight.data = _rt(conv_b.weight.data, dtype)
+    yb = bn_b(conv_br(_rt(x, dtype))).detach()
+    gate = torch.sigmoid(fc2(F.relu(fc1(yb.mean(dim=(2, 3, 4), keepdim=True))))).detach()
+    zin = _rt(yb, dtype) * gate
+    zin = _rt(zin * torch.sigmoid(zin), dtype)
+    res = torch.randn(n, c1, *thw)
+    y1 = F.relu(bn_c(F.conv3d(zin, _rt(conv_c.weight.data, dtype))) + _rt(res, dtype)).detach()
+    y2 = F.relu(bn_a(F.conv3d(_rt(y1, dtype), _rt(conv_a.weight.data, dtype)))).detach()
+    mods = [m_.to(DEV) for m_ in (conv_b, bn_b, conv_c, bn_c, conv_a, bn_a, fc1, fc2)]
+
+    def run(prologue: bool):
+        pb = _pb(dtype)
+        xa, xs = _cl_input(pb, x, dtype)
+        ra, rs = _cl_input(pb, res, dtype)
+        y, pooled = pb.dwconv(xa, mods[0], mods[1], act="none", pool=True)
+        if prologue:
+            pair = pb.conv_pair(y, mods[2], mods[3], "relu", ra, mods[4], mods[5], "relu", in_swish=True, se=(pooled, mods[6], mods[7]))
+            assert pair is not None and pb.meta[-1]["kind"] == "conv_pair+se", "the prologue pair must cover this geometry"
+        else:
+            g = pb.se_gate(pooled, mods[6], mods[7])
+            pair = pb.conv_pair(y, mods[2], mods[3], "relu", ra, mods[4], mods[5], "relu", in_gate=g, in_swish=True)
+            assert pair is not None and "xpair" in pb.meta[-1]["kernel"], pb.meta[-1]["kernel"]
+        o1, o2 = pair
+        pb.bufs[o1.buf].external = True
+        plan = pb.finish(xa, o2)
+        out1 = torch.empty(n, *thw, o1.Cp, dtype=dtype, device=DEV)
+        plan.ptrs[o1.buf] = out1.data_ptr()
+        plan.ptrs[ra.buf] = rs.data_ptr()
+        out2 = plan.run(xs)
+        torch.cuda.synchronize()
+        return out1, out2, len(plan.ops)
+
+    a1, a2, na = run(True)
+    b1, b2, nb = run(False)
+    assert (na, nb) == (2, 3)
+    for got, other, ref, cc, tag in ((a1, b1, y1, c1, "block output"), (a2, b2, y2, c2, "expand output")):
+        scale = max(1.0, float(ref.abs().max()))
+        assert_close(_from_cl(got, cc), ref, 4e-2 * scale, 3e-2, f"pair with SE prologue: {tag}")
+        assert_close(_from_cl(got, cc), _from_cl(other, cc), 1.6e-2 * scale, 1e-2, f"prologue pair vs gate launch + chained pair: {tag}")
 
 
 HALO_CASES = [

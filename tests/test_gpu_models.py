@@ -302,16 +302,16 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
     reduction order is fixed), and every SE layer really takes the fused launch."""
     monkeypatch.setenv("PASN_DWMFMA", "0")  # the VALU stencil with and without the gate (the 7 x 7 stage otherwise takes the matrix-core one)
     x = synth.echo_clips(shape).to(DEV).bfloat16()
-    # default routing: the gate rides in the stencil launch up to 128 channels (stages 2-3); the 432-channel stage computes it in the
-    # project conv's prologue (round 3; only where a block's row share fits one clip: the 160 x 160 shape), stage 4 keeps the stand-alone launch
+    # default routing: the gate rides in the stencil launch up to 128 channels (stages 2-3); the 216- and 432-channel stages compute it in
+    # the project conv's prologue (round 3; where a block's row share fits one clip: the 160 x 160 shape)
     m0 = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
     with torch.no_grad():
         m0.cnn_backbone(x)
     meta0 = m0.cnn_backbone.plan_for(x).meta
-    n_prologue = len([k for k in meta0 if k["kind"] == "conv+se"])
+    n_prologue = len([k for k in meta0 if k["kind"] in ("conv+se", "conv_pair+se")])
     assert len([k for k in meta0 if k["kind"] == "dwconv+se"]) == 5 and len([k for k in meta0 if k["kernel"].startswith("se_gate")]) + n_prologue == 10
     if shape[2:] == (16, 160, 160):
-        assert n_prologue == 4, n_prologue
+        assert n_prologue == 10, n_prologue  # both wide stages: no stand-alone gate launch left
     monkeypatch.setenv("PASN_SE_FUSE_MAXC", "1024")  # the mechanism itself: every SE layer fused
     m = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
     with torch.no_grad():

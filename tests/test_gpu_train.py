@@ -1075,7 +1075,8 @@ def test_cfg3_full_size_train_step_bf16_tracks_fp32():
     wl, ws, wo = torch.randn(32, 3, generator=g), torch.randn(32, 30, generator=g), torch.randn(32, 30, 1, 16, 7, 7, generator=g) * 0.1
     grads, outs, stats = {}, {}, {}
     for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-        m = _train_model(kink_free=False)
+        m = _train_model(kink_free=True)  # as the small-shape bf16-vs-fp32 test: bf16 rounding flips ReLU masks within 2^-8 of zero, and in a random-weight
+        # network as built (half of all units masked) those flips alone decorrelate the two modes' gradients (cosine 0.33 measured)
         if dt == torch.bfloat16:
             m.set_compute_dtype(dt)
         logits, sim, occ = m(x.to(DEV).to(dt))
@@ -1091,9 +1092,18 @@ def test_cfg3_full_size_train_step_bf16_tracks_fp32():
         torch.cuda.empty_cache()
     assert len(grads["f32"]) == len(grads["bf16"]) >= 300
     assert float((outs["bf16"][1] - outs["f32"][1]).abs().max()) < 2e-2, "similarities of the two modes"
-    a = torch.cat([grads["bf16"][n].flatten() / (float(grads["f32"][n].abs().max()) + 1e-12) for n in grads["f32"]])
+    # each mode's tensors on their OWN scale, as the small-shape test does: a norm bias behind a second norm has a TRUE gradient of ~0 (the next norm
+    # removes the shift again), what is left is rounding residue, 10^4 x larger in bf16 than in fp32 -- on the fp32 scale those few tensors would
+    # dominate the concatenated vector (cosine 0.006 measured that way with every weight tensor at 0.99)
+    a = torch.cat([grads["bf16"][n].flatten() / (float(grads["bf16"][n].abs().max()) + 1e-12) for n in grads["f32"]])
     b = torch.cat([grads["f32"][n].flatten() / (float(grads["f32"][n].abs().max()) + 1e-12) for n in grads["f32"]])
     cos = float(F.cosine_similarity(a, b, dim=0))
-    assert cos > 0.95, f"bf16 vs fp32 gradient direction cosine {cos:.4f}"
+    per = sorted((float(F.cosine_similarity(grads["bf16"][n].flatten(), grads["f32"][n].flatten(), dim=0)), n) for n in grads["f32"])
+    hist = [sum(1 for c_, _ in per if c_ > t) for t in (0.99, 0.9, 0.5, 0.0)]
+    big = sorted(((grads["f32"][n].numel(), n) for n in grads["f32"]), reverse=True)[:8]
+    bigcos = [(n, round(dict((nn, cc) for cc, nn in per)[n], 4), float(grads["f32"][n].abs().max()), float(grads["bf16"][n].abs().max())) for _, n in big]
+    assert hist[1] >= 0.9 * len(per), f"only {hist[1]} of {len(per)} gradient tensors have a bf16-vs-fp32 cosine above 0.9: lowest {per[:6]}"
+    assert cos > 0.95, (f"bf16 vs fp32 gradient direction cosine {cos:.4f}; tensors with cos > 0.99 / 0.9 / 0.5 / 0: {hist} of {len(per)}; largest tensors "
+                        f"(name, cos, max|g| fp32, bf16): {bigcos}; lowest {per[:4]}; sim diff {float((outs['bf16'][1] - outs['f32'][1]).abs().max()):.3g}")
     for k, v in stats["f32"].items():
         assert float((stats["bf16"][k] - v).abs().max()) <= 1e-2 * (float(v.abs().max()) + 1e-6) + 1e-4, k
