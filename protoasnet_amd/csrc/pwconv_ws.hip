@@ -325,6 +325,8 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
         }
         char* sb = smem + stg * g.stage_bytes;
         const unsigned m0 = row0 + (unsigned)i * (unsigned)BM;
+        // (A phase stagger -- waves 4-7 transforming the next tile BEFORE their MFMAs, waves 0-3 after their epilogue, so that the two waves of
+        // a SIMD sit in opposite phases -- was measured at +-0: 9664 vs 9643 clips/s, profiles/README round-3 entry 62.)
         if (live) {
             f32x16 acc[MT];
 #pragma unroll

@@ -106,6 +106,76 @@ def test_two_ranks_times_k_equals_one_rank_times_2k(tmp_path):
     assert t.current_iteration == 8
 
 
+class ToyNorm(Toy):
+    """Toy with a batch-statistics norm in the trunk (running estimates are per-rank state) and a seed-dependent initialisation."""
+
+    def __init__(self, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.cnn_backbone = nn.Sequential(nn.Conv3d(3, 8, 3, padding=1), nn.BatchNorm3d(8), nn.ReLU())
+        with torch.no_grad():
+            for p in self.parameters():
+                p.add_(torch.randn_like(p) * 0.05)
+
+
+def _sync_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from protoasnet_amd.trainer import DPTrainer
+
+    all_b = _batches(11, 8)
+    cfg = {"abstain_class": True, "save_dir": os.path.join(out_dir, "ck"), "train": dict(TRAIN_CFG, num_train_epochs=1)}
+    t = DPTrainer(ToyNorm(seed=100 + rank), cfg, {"train": all_b[rank::world], "val": all_b[:2]}, rank=rank, world_size=world, log=lambda *_: None)
+    after_init = {k: v.clone() for k, v in t.model.state_dict().items()}
+    t.run_epoch(0, "train")
+    before_sync = {k: v.clone() for k, v in t.model.state_dict().items() if "running" in k}
+    t.run_epoch(0, "val")  # averages the norm buffers first
+    t.save_checkpoint()
+    torch.save({"init": after_init, "before": before_sync, "final": t.model.state_dict()}, os.path.join(out_dir, f"sync{rank}.pt"))
+    # a rank with a shorter loader must be refused, not hang: both ranks take part in the length check
+    t.data_loaders["train"] = all_b[: 2 if rank == 0 else 4]
+    try:
+        t.run_epoch(1, "train")
+        raised = False
+    except RuntimeError as e:
+        raised = "same number" in str(e)
+    torch.save(raised, os.path.join(out_dir, f"raised{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_built_from_different_seeds_train_one_model(tmp_path):
+    """ADVICE (round 2): ranks whose models were built from different seeds start from rank 0's parameters and buffers (broadcast at
+    construction), take identical optimizer steps, evaluate / checkpoint with the SAME averaged running statistics, and a shard with
+    fewer micro-batches is refused with an error on every rank instead of hanging the collectives."""
+    world, port = 2, _free_port()
+    mp.spawn(_sync_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"sync{r}.pt")) for r in range(world))
+    ref0 = ToyNorm(seed=100).state_dict()
+    for k, v in a["init"].items():
+        assert torch.equal(v, b["init"][k]), f"{k}: ranks differ after construction"
+        assert torch.equal(v, ref0[k]), f"{k}: not rank 0's value"
+    assert any(not torch.equal(a["before"][k], b["before"][k]) for k in a["before"]), "the ranks saw different micro-batches"
+    for k, v in a["final"].items():
+        assert torch.allclose(v.float(), b["final"][k].float(), atol=1e-6), f"{k}: ranks differ after the epoch"
+        if "running" in k and v.is_floating_point():
+            assert torch.allclose(v, (a["before"][k] + b["before"][k]) / 2, atol=1e-6), f"{k}: not the mean of the ranks' estimates"
+    assert os.path.exists(os.path.join(tmp_path, "ck", "last.pth"))
+    assert all(torch.load(os.path.join(tmp_path, f"raised{r}.pt")) for r in range(world))
+
+
+def test_sharded_push_refuses_a_shuffling_loader():
+    """ADVICE (round 2): every rank re-iterates the batch sampler on its own; with a random sampler the shards would overlap."""
+    from protoasnet_amd import push
+
+    ds = torch.utils.data.TensorDataset(torch.zeros(8, 1))
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=True)
+    with pytest.raises(ValueError, match="SequentialSampler"):
+        next(push._iter_shard(loader, 0, 2))
+    assert next(push._iter_shard(torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False), 1, 2))[0] == 2
+
+
 def test_optimizer_groups_scheduler_and_checkpoint_follow_the_reference(tmp_path):
     from protoasnet_amd.trainer import DPTrainer, confusion_to_metrics
 
