@@ -282,6 +282,22 @@ int pasn_xproto_head_fwd(const void* x, const void* a1, const float* a1b, const 
                          void* ws, const pasn_xproto_desc* d, int dtype, void* stream);
 
 /*
+ * Head B in two launches (csrc/head_chain.hip + the finish kernel): same contract and outputs as pasn_xproto_head_fwd (replaces
+ * Video_XProtoNet.forward, Video_XProtoNet.py:66-98, after the trunk), for bf16 with D = 256, Hd = 128, P <= 64 and a trunk channel
+ * stride <= 192 (the X3D heads of BASELINE configs 2, 3 and 5).  A block keeps a tile of <= 104 positions of one clip in LDS through the
+ * five convs and adds the tile's share of the occurrence-weighted pooling; no intermediate map reaches memory.
+ *   a1 .. o3 : conv weights FRAGMENT-MAJOR, [rows / 32][kc / 16][64][8] bf16 (the w_frag = 1 layout of pasn_conv3d_fwd)
+ *   ws       : pasn_xproto_chain_workspace_bytes() bytes, 256-byte aligned (the pooling slabs [N][tiles][P][D] fp32; mode 1: unused)
+ * pasn_xproto_chain_supported() == 0: use pasn_xproto_head_fwd.
+ */
+int pasn_xproto_chain_supported(const pasn_xproto_desc* d, int dtype);
+size_t pasn_xproto_chain_workspace_bytes(const pasn_xproto_desc* d);
+int pasn_xproto_chain_fwd(const void* x, const void* a1, const float* a1b, const void* a2, const float* a2b,
+                          const void* o1, const float* o1b, const void* o2, const float* o2b, const void* o3,
+                          const float* protos, const float* fc_w, float* occ, float* feat, float* sim, float* logits,
+                          void* ws, const pasn_xproto_desc* d, int dtype, void* stream);
+
+/*
  * Push sweep, XProtoNet / Video rule (push_abs_revision.py:288-307): per prototype j, over the clips of
  * this batch whose label matches class(j) (or all clips when class_mask[j] == 0): batch min of
  * proto_dist[:, j], first index; accepted when min <= best (a later batch wins ties).  State stays on the device.

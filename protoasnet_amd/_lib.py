@@ -69,6 +69,9 @@ SIGNATURES = {
     "pasn_xproto_head_splits": (c_int, [POINTER(XProtoDesc)]),
     "pasn_xproto_head_workspace_bytes": (c_size_t, [POINTER(XProtoDesc), c_int]),
     "pasn_xproto_head_fwd": (c_int, [c_void_p] * 17 + [POINTER(XProtoDesc), c_int, c_void_p]),
+    "pasn_xproto_chain_supported": (c_int, [POINTER(XProtoDesc), c_int]),
+    "pasn_xproto_chain_workspace_bytes": (c_size_t, [POINTER(XProtoDesc)]),
+    "pasn_xproto_chain_fwd": (c_int, [c_void_p] * 17 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_push_xproto_update": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int64, c_void_p]),
     # ---- training path
     "pasn_train_chunks": (c_int, [c_int, c_int, c_int]),

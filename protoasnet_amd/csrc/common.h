@@ -163,6 +163,12 @@ template <typename T>
 int launch_gemm_pw(const void* x, const void* w, const float* scale, const float* bias, const void* res, const float* gate,
                    void* y, const pasn_conv_desc& d, hipStream_t s);
 
+// head_chain.hip: head B with the intermediate maps resident in LDS (bf16, D = 256)
+bool xproto_chain_supported(const pasn_xproto_desc& d, int dtype);
+int xproto_chain_tiles(const pasn_xproto_desc& d);
+int launch_xproto_chain(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
+                        const void* w4, const float* b4, const void* w5, float* occ, float* slabs, const pasn_xproto_desc& d, hipStream_t s);
+
 // ---- dtype traits: one MFMA "k-chunk" is the 16 bytes a lane feeds to the matrix core ---------------
 template <typename T>
 struct Traits;

@@ -428,3 +428,37 @@ extern "C" int pasn_xproto_head_fwd(const void* x, const void* a1, const float* 
     }
     return PASN_OK;
 }
+
+// ---- head B as two launches (head_chain.hip + the finish kernel): bf16, D = 256, trunk channel stride <= 192 ----------------------------
+// Same contract as pasn_xproto_head_fwd except that the five conv weights are FRAGMENT-MAJOR ([rows / 32][kc / 16][64 lanes][8], the layout
+// pasn_conv3d_fwd takes with w_frag = 1) and the workspace holds only the pooling slabs.
+extern "C" int pasn_xproto_chain_supported(const pasn_xproto_desc* d, int dtype) {
+    return xp_desc_ok(d) && (d->mode == 0 || d->mode == 1) && xproto_chain_supported(*d, dtype) ? 1 : 0;
+}
+
+extern "C" size_t pasn_xproto_chain_workspace_bytes(const pasn_xproto_desc* d) {
+    if (!xp_desc_ok(d)) return 0;
+    return align256((size_t)d->N * xproto_chain_tiles(*d) * d->P * d->D * sizeof(float));
+}
+
+extern "C" int pasn_xproto_chain_fwd(const void* x, const void* a1, const float* a1b, const void* a2, const float* a2b, const void* o1,
+                                     const float* o1b, const void* o2, const float* o2b, const void* o3, const float* protos,
+                                     const float* fc_w, float* occ, float* feat, float* sim, float* logits, void* ws,
+                                     const pasn_xproto_desc* d, int dtype, void* stream) {
+    PASN_REQUIRE(pasn_xproto_chain_supported(d, dtype), "shape / dtype outside the chained head (see pasn_xproto_chain_supported)");
+    PASN_REQUIRE(x && o1 && o1b && o2 && o2b && o3 && occ, "null pointer");
+    const bool full = d->mode == 0;
+    if (full) {
+        PASN_REQUIRE(a1 && a1b && a2 && a2b && protos && fc_w && feat && sim && logits && ws, "null pointer (full mode)");
+        PASN_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = launch_xproto_chain(x, a1, a1b, a2, a2b, o1, o1b, o2, o2b, o3, occ, (float*)ws, *d, s))) return rc;
+    if (full) {
+        hipLaunchKernelGGL((xproto_finish_kernel<1, 1024>), dim3(d->N), dim3(1024), (size_t)d->P * sizeof(float), s, (const float*)ws, protos, fc_w,
+                           feat, sim, logits, xproto_chain_tiles(*d), d->P, d->D, d->K);
+        if ((rc = check_launch("xproto_finish_kernel"))) return rc;
+    }
+    return PASN_OK;
+}

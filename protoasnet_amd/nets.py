@@ -52,15 +52,18 @@ class PointwiseChain(nn.Sequential):
     def _sig(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def packed(self, cin_p: int, dtype: torch.dtype):
-        """[(weight [rows][1][kc] in dtype, bias fp32 [rows] or None)] per conv, cached until a parameter changes."""
-        key, sig = ("packed", cin_p, dtype), self._sig()
+    def packed(self, cin_p: int, dtype: torch.dtype, frag: bool = False):
+        """[(weight [rows][1][kc] in dtype, bias fp32 [rows] or None)] per conv, cached until a parameter changes.
+        ``frag``: weights fragment-major, [rows / 32][kc / 16][64 lanes][8] (bf16; what ``pasn_xproto_chain_fwd`` reads)."""
+        key, sig = ("packed", cin_p, dtype, frag), self._sig()
         hit = self._cache.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
         out, cp = [], cin_p
         for conv in self.convs():
             w, kc, rows = pack_conv_weight(conv.weight, cp, dtype)
+            if frag:
+                w = w.view(rows // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
             b = None
             if conv.bias is not None:
                 b = torch.zeros(rows, dtype=torch.float32, device=w.device)
@@ -362,13 +365,16 @@ class _XProtoHeadMixin:
             raise NotImplementedError(
                 "the fused head supports the 2-conv add-on ('regular') and 3-conv occurrence module of the shipped configs"
             )
-        (a1, a1b), (a2, a2b) = self.add_on_layers.packed(cbp, dtype)
-        (o1, o1b), (o2, o2b), (o3, _) = self.occurrence_module.packed(cbp, dtype)
         d = XProtoDesc(N=N, S=S, Cb=Cb, Cbp=cbp, D=D, Dp=round_up(D, 8), Hd=D // 2, Hp=round_up(D // 2, 8), P=P,
                        Pp=round_up(P, 8), K=K, mode=mode)
         lib = _lib.lib()
         code = _lib.dtype_code(dtype)
-        ws_bytes = int(lib.pasn_xproto_head_workspace_bytes(ctypes.byref(d), code))
+        # the chained head (one launch for the five convs and the pooling, intermediates in LDS) where the shape allows: bf16, D = 256,
+        # trunk channel stride <= 192 -- the X3D heads; everything else takes the seven-launch path
+        chain = bool(lib.pasn_xproto_chain_supported(ctypes.byref(d), code))
+        (a1, a1b), (a2, a2b) = self.add_on_layers.packed(cbp, dtype, frag=chain)
+        (o1, o1b), (o2, o2b), (o3, _) = self.occurrence_module.packed(cbp, dtype, frag=chain)
+        ws_bytes = int(lib.pasn_xproto_chain_workspace_bytes(ctypes.byref(d)) if chain else lib.pasn_xproto_head_workspace_bytes(ctypes.byref(d), code))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=rows.device)
         dev = rows.device
         occ = torch.empty((N, P, S), dtype=torch.float32, device=dev)
@@ -380,7 +386,7 @@ class _XProtoHeadMixin:
             logits = torch.empty((N, K), dtype=torch.float32, device=dev)
             protos, fcw = _f32(self.prototype_vectors), _f32(self.last_layer.weight)
         _lib.check(
-            lib.pasn_xproto_head_fwd(
+            (lib.pasn_xproto_chain_fwd if chain else lib.pasn_xproto_head_fwd)(
                 rows.data_ptr(), a1.data_ptr(), a1b.data_ptr(), a2.data_ptr(), a2b.data_ptr(), o1.data_ptr(), o1b.data_ptr(),
                 o2.data_ptr(), o2b.data_ptr(), o3.data_ptr(), _lib.ptr(protos), _lib.ptr(fcw), occ.data_ptr(), _lib.ptr(featx),
                 _lib.ptr(sim), _lib.ptr(logits), ws.data_ptr(), ctypes.byref(d), code, _lib.current_stream(),

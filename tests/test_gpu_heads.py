@@ -102,7 +102,8 @@ def test_l2_head_tie_takes_first_index():
 
 
 # ------------------------------------------------------------------------------------------ head B
-def _xproto_head(x, sd, P, D, K, dtype, mode=0):
+def _xproto_head(x, sd, P, D, K, dtype, mode=0, chain=False):
+    """chain: pasn_xproto_chain_fwd (fragment-major weights, one launch for the convs + pooling) instead of pasn_xproto_head_fwd."""
     from protoasnet_amd import _lib
     from protoasnet_amd.plan import pack_conv_weight, round_up
 
@@ -111,6 +112,8 @@ def _xproto_head(x, sd, P, D, K, dtype, mode=0):
 
     def pack(name, cin_p, bias=True):
         w, kc, r = pack_conv_weight(sd[name + ".weight"].to(DEV), cin_p, dtype)
+        if chain:
+            w = w.view(r // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
         b = None
         if bias:
             b = torch.zeros(r, device=DEV)
@@ -126,14 +129,17 @@ def _xproto_head(x, sd, P, D, K, dtype, mode=0):
     d = _lib.XProtoDesc(N=n, S=s, Cb=cb, Cbp=cbp, D=D, Dp=dp, Hd=D // 2, Hp=hp, P=P, Pp=pp, K=K, mode=mode)
     lib = _lib.lib()
     code = _lib.dtype_code(dtype)
-    ws = torch.empty(int(lib.pasn_xproto_head_workspace_bytes(ctypes.byref(d), code)), dtype=torch.uint8, device=DEV)
+    if chain:
+        assert lib.pasn_xproto_chain_supported(ctypes.byref(d), code) == 1
+    ws = torch.empty(int(lib.pasn_xproto_chain_workspace_bytes(ctypes.byref(d)) if chain else lib.pasn_xproto_head_workspace_bytes(ctypes.byref(d), code)),
+                     dtype=torch.uint8, device=DEV)
     occ = torch.full((n, P, s), float("nan"), device=DEV)
     feat = torch.full((n, P, D), float("nan"), device=DEV)
     sim = torch.full((n, P), float("nan"), device=DEV)
     logits = torch.full((n, K), float("nan"), device=DEV)
     protos = sd["prototype_vectors"].reshape(P, D).contiguous().to(DEV)
     fcw = sd["last_layer.weight"].contiguous().to(DEV)
-    _lib.check(lib.pasn_xproto_head_fwd(rows.data_ptr(), a1.data_ptr(), a1b.data_ptr(), a2.data_ptr(), a2b.data_ptr(), o1.data_ptr(),
+    _lib.check((lib.pasn_xproto_chain_fwd if chain else lib.pasn_xproto_head_fwd)(rows.data_ptr(), a1.data_ptr(), a1b.data_ptr(), a2.data_ptr(), a2b.data_ptr(), o1.data_ptr(),
                                         o1b.data_ptr(), o2.data_ptr(), o2b.data_ptr(), o3.data_ptr(), protos.data_ptr(), fcw.data_ptr(),
                                         occ.data_ptr(), feat.data_ptr(), sim.data_ptr(), logits.data_ptr(), ws.data_ptr(),
                                         ctypes.byref(d), code, 0))
@@ -200,3 +206,46 @@ def test_xproto_head_vs_oracle_shapes(cfg, dtype):
     # the path is reproducible bit for bit (fixed-order slab reduction, no atomics)
     occ2, feat2, sim2, logits2 = _xproto_head(x, sd, P, D, K, dtype)
     assert torch.equal(feat, feat2) and torch.equal(sim, sim2) and torch.equal(logits, logits2)
+
+
+@pytest.mark.parametrize("cfg", [(32, 192, 784, 40, 4), (3, 192, 100, 30, 3), (2, 96, 209, 64, 4), (1, 40, 3, 7, 2), (2, 192, 3200, 40, 4)])
+def test_xproto_chain_head(cfg):
+    """Head B with the intermediate maps resident in LDS (pasn_xproto_chain_fwd, bf16, D = 256) against the oracle and against the
+    seven-launch path on the same inputs: the headline shape (784 positions: 8 tiles of 98), ragged tiles (100 = one tile, 209 = 3 x 70 -
+    1), a single short tile, P = 64 / P < 32 (one prototype tile), a narrow trunk (40 and 96 channels: k-steps beyond the data are zero
+    fragments), 31 tiles per clip; and the occurrence-map-only mode."""
+    n, cb, s, P, K = cfg
+    D = 256
+    sd = head_b_state(cb, D, P, K, video=True)
+    x = video_features((n, cb, 1, 1, s), seed=91)
+    ref = oracle.heads.xproto_head(sd, x)
+    occ, feat, sim, logits = _xproto_head(x, sd, P, D, K, torch.bfloat16, chain=True)
+    tol = 4e-2
+    fscale = float(ref["features_extracted"].abs().max())
+    assert_close(occ.view(ref["occurrence_map"].shape), ref["occurrence_map"], tol * 3, tol, "occurrence_map")
+    assert_close(feat, ref["features_extracted"], tol * fscale, tol, "features_extracted")
+    assert_close(sim, ref["similarity"], tol, 0, "similarity")
+    assert_close(logits, ref["logits"], tol * 10, 0, "logits")
+    # the same rounding points as the separate launches: the occurrence map agrees bit for bit, the pooled features to fp32 summation order
+    occ7, feat7, sim7, logits7 = _xproto_head(x, sd, P, D, K, torch.bfloat16)
+    assert torch.equal(occ, occ7)
+    assert_close(feat, feat7, 1e-5 * fscale, 1e-5, "features_extracted vs the seven-launch path")
+    assert_close(sim, sim7, 1e-5, 0, "similarity vs the seven-launch path")
+    assert_close(logits, logits7, 1e-4, 0, "logits vs the seven-launch path")
+    occ1, feat1, sim1, _ = _xproto_head(x, sd, P, D, K, torch.bfloat16, mode=1, chain=True)
+    assert torch.equal(occ1, occ) and torch.isnan(feat1).all() and torch.isnan(sim1).all()
+    occ2, feat2, sim2, logits2 = _xproto_head(x, sd, P, D, K, torch.bfloat16, chain=True)
+    assert torch.equal(feat, feat2) and torch.equal(sim, sim2) and torch.equal(logits, logits2)
+
+
+def test_xproto_chain_head_routing():
+    from protoasnet_amd import _lib
+
+    lib = _lib.lib()
+    mk = lambda **kw: _lib.XProtoDesc(**{**dict(N=2, S=784, Cb=192, Cbp=192, D=256, Dp=256, Hd=128, Hp=128, P=40, Pp=40, K=4, mode=0), **kw})
+    ok = lambda d, dt: lib.pasn_xproto_chain_supported(ctypes.byref(d), _lib.dtype_code(dt))
+    assert ok(mk(), torch.bfloat16) == 1 and ok(mk(mode=1), torch.bfloat16) == 1
+    assert ok(mk(), torch.float32) == 0                         # fp32 keeps the seven-launch path
+    assert ok(mk(D=512, Dp=512, Hd=256, Hp=256), torch.bfloat16) == 0   # image head (D = 512)
+    assert ok(mk(Cb=512, Cbp=512), torch.bfloat16) == 0        # R(2+1)D / ResNet trunks: 512 channels do not fit the tile
+    assert ok(mk(P=68, Pp=72), torch.bfloat16) == 0
