@@ -46,13 +46,14 @@ struct HcArgs {
 
 __device__ __forceinline__ void hc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KS>
+// fragments K0 .. K1 - 1 of channel tile ct (whole-K fragment-major rows of nks steps); steps beyond nks are zero fragments
+template <int KS, int K0 = 0, int K1 = KS>
 __device__ __forceinline__ void hc_load_w(bf16x8 (&W)[KS], const __bf16* __restrict__ w, int ct, int nks, int lane) {
     const __bf16* b = w + ((long)ct * nks * 64 + lane) * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) W[ks] = load_frag<__bf16>(b + (size_t)(ks < nks ? ks : nks - 1) * 512);
+    for (int ks = K0; ks < K1; ++ks) W[ks] = load_frag<__bf16>(b + (size_t)(ks < nks ? ks : nks - 1) * 512);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = K0; ks < K1; ++ks)
         if (ks >= nks) W[ks] = zero_frag<__bf16>();  // wave-uniform
 }
 
@@ -165,16 +166,21 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
         hc_load_w<HC_KS1>(W1, a.w1, wave, a.nks1, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         hc_barrier();
+        // (half of the next stage's weight fragments are requested BEFORE this stage's MFMAs, the rest behind them: all of them up front
+        // does not fit the registers -- 19 spilled, 28.8 us -- and all of them behind leaves an L2 round trip per stage exposed)
         // ---- c1: x -> f1 = relu(.), rows of B1 ----
-        hc_mma<HC_KS1, 4, false>(acc, W1, XR, HC_XS, rows4, h);
         bf16x8 W2[16];
-        hc_load_w<16>(W2, a.w2, wave, 16, lane);
+        hc_load_w<16, 0, 8>(W2, a.w2, wave, 16, lane);
+        hc_mma<HC_KS1, 4, false>(acc, W1, XR, HC_XS, rows4, h);
+        hc_load_w<16, 8, 16>(W2, a.w2, wave, 16, lane);
         hc_epi_rows<4>(acc, a.b1, wave, 0, B1, HC_B1S, c, h);
         hc_barrier();
         // ---- c2: f1 -> f^T (no activation), B2 ----
+        hc_load_w<HC_KS1, 0, 6>(W3, a.w3, wave, a.nks1, lane);
+        const float bias2 = a.b2[wave * 32 + c];
         hc_mma<16, 4, true>(acc, W2, B1, HC_B1S, rows4, h);
-        hc_load_w<HC_KS1>(W3, a.w3, wave, a.nks1, lane);
-        hc_epi_cols<4, false>(acc, a.b2[wave * 32 + c], wave, 0, B2, HC_ROWS, c, h);
+        hc_load_w<HC_KS1, 6, HC_KS1>(W3, a.w3, wave, a.nks1, lane);
+        hc_epi_cols<4, false>(acc, bias2, wave, 0, B2, HC_ROWS, c, h);
         hc_barrier();  // everyone is past its reads of f1
     } else {
         hc_load_w<HC_KS1>(W3, a.w3, wave, a.nks1, lane);
@@ -182,20 +188,21 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
         hc_barrier();
     }
     // ---- c3: x -> o1 = relu(.), rows of B1 ----
-    hc_mma<HC_KS1, 4, false>(acc, W3, XR, HC_XS, rows4, h);
     const int ct4 = wave & 3, sp4 = wave >> 2;
     bf16x8 W4[16];
-    hc_load_w<16>(W4, a.w4, ct4, 16, lane);
+    hc_load_w<16, 0, 8>(W4, a.w4, ct4, 16, lane);
+    hc_mma<HC_KS1, 4, false>(acc, W3, XR, HC_XS, rows4, h);
+    hc_load_w<16, 8, 16>(W4, a.w4, ct4, 16, lane);
     hc_epi_rows<4>(acc, a.b3, wave, 0, B1, HC_B1S, c, h);
     hc_barrier();  // o1 complete; everyone is past its reads of the x tile
     // ---- c4: o1 -> o2 = relu(.), rows of XR: wave = (channel tile, half of the positions) ----
     {
         f32x16 acc2[2];
         const int rows2[2] = {min(64 * sp4 + c, HC_ROWS - 1), min(64 * sp4 + 32 + c, HC_ROWS - 1)};
-        hc_mma<16, 2, false>(acc2, W4, B1, HC_B1S, rows2, h);
         const int pt5 = wave & 1, st5 = wave >> 1;
         bf16x8 W5[8];
         hc_load_w<8>(W5, a.w5, pt5, 8, lane);
+        hc_mma<16, 2, false>(acc2, W4, B1, HC_B1S, rows2, h);
         hc_epi_rows<2>(acc2, a.b4, ct4, 2 * sp4, XR, HC_O2S, c, h);
         hc_barrier();  // o2 complete; everyone is past its reads of o1
         // ---- c5: o2 -> occ^T = |.|, rows of B1: wave = (prototype tile, 32-position sub-tile) ----

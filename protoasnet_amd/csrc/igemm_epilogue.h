@@ -121,6 +121,93 @@ __device__ __forceinline__ void igemm_epilogue_body(const f32x16 (&acc)[NT][MT],
     }
 }
 
+// ---- epilogue WITHOUT the LDS image ------------------------------------------------------------------------------------------------
+// The 32x32 accumulator has the position on the lane and 4 consecutive channels per register quad; one v_permlane32_swap per register
+// pair gives every lane 8 consecutive channels of its position (the pwconv_ws.hip epilogue): scale / bias (LDS, read once per channel
+// piece and reused for the MT position tiles), residual (16-byte loads, all of a channel tile's requested before any is used),
+// activation, one 16-byte store per piece.  Per tile a buffer descriptor over exactly its valid rows: rows beyond them fall out of
+// range (loads return zero, stores are dropped), channel pieces beyond the block's width carry an out-of-range offset.
+typedef __attribute__((ext_vector_type(4))) unsigned ige_u32x4;
+
+template <int NT, int MT, bool HAS_RES, int ACT, typename Rows>
+__device__ __forceinline__ void igemm_epilogue_direct_body(const f32x16 (&acc)[NT][MT], const float* scb, const __bf16* __restrict__ res,
+                                                           __bf16* __restrict__ y, int n0, int cgs, const pasn_conv_desc& d, int lane, Rows rows) {
+    constexpr int BN = NT * 32;
+    const int c = lane & 31, h = lane >> 5;
+    const int Cout_p = d.Cout_p, width = cgs * 8;
+    const bool ragged = n0 + BN > d.Cout;  // wave-uniform: this block holds the padded channels (stored as zeros)
+    __amdgpu_buffer_rsrc_t yr[MT], rr[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        long mbase;
+        int nvalid;
+        rows(j, mbase, nvalid);
+        const unsigned bytes = nvalid > 0 ? (unsigned)(((nvalid - 1) * Cout_p + width) * 2) : 0u;
+        yr[j] = __builtin_amdgcn_make_buffer_rsrc(y + mbase * Cout_p + n0, 0, bytes, 0x00020000);
+        rr[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(HAS_RES ? res + mbase * Cout_p + n0 : y), 0, HAS_RES ? bytes : 0u, 0x00020000);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        unsigned off[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int col = i * 32 + 16 * pr + 8 * h;
+            off[pr] = col < width ? (unsigned)((c * Cout_p + col) * 2) : 0x80000000u;
+        }
+        bf16x8 rv[2][MT];
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) rv[pr][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rr[j], (int)off[pr], 0, 0));
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int col = i * 32 + 16 * pr + 8 * h;
+            float sc[8], bs[8];
+            load8(scb + col, sc);
+            load8(scb + BN + col, bs);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * pr + q]), __float_as_uint(acc[i][j][8 * pr + 4 + q]), false, false);
+                    v[q] = __uint_as_float(sw[0]);
+                    v[4 + q] = __uint_as_float(sw[1]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bs[e];
+                if constexpr (HAS_RES) {
+                    // the image path rounds norm(conv) to bf16 before adding the identity: keep that rounding point
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)(__bf16)v[e] + (float)rv[pr][j][e];
+                }
+                igemm_act<ACT>(v, d.act);
+                if (ragged) mask_tail(v, d.Cout - (n0 + col));
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ige_u32x4, o), yr[j], (int)off[pr], 0, 0);
+            }
+        }
+    }
+}
+
+template <int NT, int MT, typename Rows>
+__device__ __forceinline__ void igemm_epilogue_direct(const f32x16 (&acc)[NT][MT], const float* scb, const __bf16* __restrict__ res,
+                                                      __bf16* __restrict__ y, int n0, int cgs, const pasn_conv_desc& d, int lane, Rows rows) {
+    if (res) {
+        if (d.act == PASN_ACT_RELU) igemm_epilogue_direct_body<NT, MT, true, PASN_ACT_RELU>(acc, scb, res, y, n0, cgs, d, lane, rows);
+        else if (d.act == PASN_ACT_NONE) igemm_epilogue_direct_body<NT, MT, true, PASN_ACT_NONE>(acc, scb, res, y, n0, cgs, d, lane, rows);
+        else igemm_epilogue_direct_body<NT, MT, true, -1>(acc, scb, res, y, n0, cgs, d, lane, rows);
+    } else {
+        if (d.act == PASN_ACT_RELU) igemm_epilogue_direct_body<NT, MT, false, PASN_ACT_RELU>(acc, scb, res, y, n0, cgs, d, lane, rows);
+        else if (d.act == PASN_ACT_NONE) igemm_epilogue_direct_body<NT, MT, false, PASN_ACT_NONE>(acc, scb, res, y, n0, cgs, d, lane, rows);
+        else igemm_epilogue_direct_body<NT, MT, false, -1>(acc, scb, res, y, n0, cgs, d, lane, rows);
+    }
+}
+
 template <int NT, int MT, typename Rows>
 __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[NT][MT], __bf16* img, const float* scb, const __bf16* __restrict__ res,
                                                __bf16* __restrict__ y, int n0, int cgs, const pasn_conv_desc& d, int lane, Rows rows) {

@@ -33,7 +33,7 @@ template <int NT, int MT, int MODE, int ABL = 0>  // ABL: timing-only ablation b
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
                                                             const __bf16* __restrict__ res, __bf16* __restrict__ y, pasn_conv_desc d,
-                                                            int rows16, int scb_off) {
+                                                            int rows16, int scb_off, int direct) {
     constexpr int BN = NT * 32, BM = 128 * MT, BT = 4 * MT;
     constexpr bool PIPE = PASN_HALO_PIPE;
     constexpr int WBYTES = BN * 64, WGROUPS = BN / 16;
@@ -283,14 +283,15 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
     auto tile_rows = [&](int j, long& mbase, int& nvalid) {  // rows of tile j that are output positions
         if (MODE == 0) {
             mbase = m0 + wave * MT * 32 + j * 32;
-            nvalid = (int)min((long)32, M - mbase);
+            nvalid = (int)max(0L, min((long)32, M - mbase));
         } else {
             const int t = t0 + wave * MT + j;
             mbase = ((long)bn * T + t) * FR + p0;
             nvalid = t < T ? min(32, FR - p0) : 0;
         }
     };
-    igemm_epilogue<NT, MT>(acc, img, scb, res, y, n0, cgs, d, lane, tile_rows);
+    if (direct) igemm_epilogue_direct<NT, MT>(acc, scb, res, y, n0, cgs, d, lane, tile_rows);  // block-uniform
+    else igemm_epilogue<NT, MT>(acc, img, scb, res, y, n0, cgs, d, lane, tile_rows);
 }
 
 // Geometry of the halo tile for this layer: tile rows (padded to 16) or 0 when the layer is not a stride-1 "same" (1,k,k) / (3,1,1) conv
@@ -330,7 +331,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
     if (nt == NT_ && mt == MT_ && mode == MODE_ + 1) {                                                                            \
         if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_halo_kernel<NT_, MT_, MODE_>);                                         \
         hipLaunchKernelGGL((igemm_halo_kernel<NT_, MT_, MODE_>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale,  \
-                           bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                                               \
+                           bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off, igemm_direct_epilogue());                                               \
         return check_launch("igemm_halo_kernel");                                                                                 \
     }
     if (const char* e = getenv("PASN_HALO_ABL")) {  // timing-only builds of the 160-channel spatial instance
@@ -339,7 +340,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
         if (abl == A_ && nt == 5 && mt == 2 && mode == 1) {                                                                       \
             PASN_MAX_LDS(96 * 1024, igemm_halo_kernel<5, 2, 0, A_>);                                                              \
             hipLaunchKernelGGL((igemm_halo_kernel<5, 2, 0, A_>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale,  \
-                               bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                                           \
+                               bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off, igemm_direct_epilogue());                                           \
             return check_launch("igemm_halo_kernel");                                                                             \
         }
         PASN_IHA(1) PASN_IHA(2) PASN_IHA(4) PASN_IHA(8) PASN_IHA(3) PASN_IHA(15) PASN_IHA(16)
