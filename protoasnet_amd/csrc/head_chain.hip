@@ -7,7 +7,8 @@
 // head_xproto.hip runs this as 5 pointwise-conv launches + pooling + finish: at the headline shape (32 x 784 positions, 192 trunk
 // channels) that is 7 launches of 5-27 us (~100 us) for 10 GFLOP and ~30 MB -- every launch at its fixed cost (ramp, weight fetch,
 // drain), and f / f1 / o1 / o2 / occ each written to and read back from memory.  Here a block owns R <= 104 consecutive positions of
-// ONE clip (S = 784: 8 tiles of 98 -> 256 blocks, one per CU) and walks the chain with the tile resident:
+// ONE clip (S = 784: 8 tiles of 98 -> 256 blocks, one per CU; trunks with up to 256 channels -- R(2+1)D-18[:-3] -- take 96-row
+// tiles, see HcGeom) and walks the chain with the tile resident:
 //   x tile  --c1--> f1 --c2--> f^T            (add-on;   ^T = stored [channel][position] for the pooling's K = position)
 //   x tile  --c3--> o1 --c4--> o2 --c5--> occ^T (occurrence module, |.| fused)
 //   slab[p][d] = occ^T[p][:] . f^T[d][:]       (one more MFMA pass; the slabs of a clip's tiles are summed in fixed order by the finish kernel)
@@ -24,17 +25,24 @@ namespace pasn {
 
 typedef __attribute__((address_space(3))) void* hc_lds_ptr_t;
 
-constexpr int HC_ROWS = 104;              // staged positions per tile: 13 pieces of 8
-constexpr int HC_PIECES = HC_ROWS / 8;    // 13
-constexpr int HC_KS1 = 12;                // k-steps of the trunk channels (Cbp <= 192)
-constexpr int HC_XS = 2 * HC_KS1 + 1;     // 16-byte slots per x row (odd)
-constexpr int HC_B1S = 33;                // f1 / o1 rows: 256 channels + pad slot
-constexpr int HC_O2S = 17;                // o2 rows: 128 channels + pad slot
-constexpr int HC_TS = 15;                 // transposed rows: 13 pieces + 2 (odd)
-constexpr int HC_XR_BYTES = HC_ROWS * HC_XS * 16;   // 41600  x tile; later o2
-constexpr int HC_B1_BYTES = HC_ROWS * HC_B1S * 16;  // 54912  f1, then o1, then occ^T
-constexpr int HC_B2_BYTES = 256 * HC_TS * 16;       // 61440  f^T
-constexpr int HC_LDS = HC_XR_BYTES + HC_B1_BYTES + HC_B2_BYTES;
+// Tile geometry per instance: KS1 = k-steps of the trunk channels, ROWS = staged positions per tile (a whole number of 8-position pieces).
+//   <12, 104>: trunk stride <= 192 (X3D): x 41.6 KB | f1 / o1 / occ^T 54.9 KB | f^T 61.4 KB = 158 KB; 104 rows = 3.25 sub-tiles of 32 (S = 784 -> 8
+//              tiles of 98 per clip = one block per CU at 32 clips)
+//   <16, 96>:  trunk stride <= 256 (R(2+1)D-18[:-3]): x 50.7 | 50.7 | 53.2 = 155 KB; 96 rows = exactly 3 sub-tiles
+template <int KS1, int ROWS>
+struct HcGeom {
+    static constexpr int PIECES = ROWS / 8;
+    static constexpr int NST = (ROWS + 31) / 32;          // 32-position sub-tiles that hold any staged row
+    static constexpr int XS = 2 * KS1 + 1;                // 16-byte slots per x row (odd)
+    static constexpr int B1S = 33;                        // f1 / o1 rows: 256 channels + pad slot
+    static constexpr int O2S = 17;                        // o2 rows: 128 channels + pad slot
+    static constexpr int TS = PIECES + 1 + (PIECES & 1);  // transposed rows: the pieces + pad, odd
+    static constexpr int XR_BYTES = ROWS * XS * 16;       // x tile; later o2
+    static constexpr int B1_BYTES = ROWS * B1S * 16;      // f1, then o1, then occ^T
+    static constexpr int B2_BYTES = 256 * TS * 16;        // f^T
+    static constexpr int LDS = XR_BYTES + B1_BYTES + B2_BYTES;
+    static_assert(ROWS % 8 == 0 && XR_BYTES >= ROWS * O2S * 16 && B1_BYTES >= 64 * TS * 16 && LDS <= 160 * 1024, "regions must fit");
+};
 constexpr unsigned HC_OOB = 0x80000000u;
 
 struct HcArgs {
@@ -88,7 +96,7 @@ __device__ __forceinline__ void hc_swap8(const f32x16& a, int pr, float (&v)[8])
 }
 
 // row-major epilogue (A = weights): out[position][channel], bias + ReLU, rounded to bf16
-template <int NST>
+template <int NST, int ROWS>
 __device__ __forceinline__ void hc_epi_rows(const f32x16 (&acc)[NST], const float* __restrict__ bias, int ct, int st0, char* out, int stride,
                                             int c, int h) {
     float bs[2][8];
@@ -104,13 +112,13 @@ __device__ __forceinline__ void hc_epi_rows(const f32x16 (&acc)[NST], const floa
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] + bs[pr][e], 0.0f);
-            if (row < HC_ROWS) *reinterpret_cast<bf16x8*>(out + (row * stride + 4 * ct + 2 * pr + h) * 16) = o;
+            if (row < ROWS) *reinterpret_cast<bf16x8*>(out + (row * stride + 4 * ct + 2 * pr + h) * 16) = o;
         }
     }
 }
 
 // transposed epilogue (A = activations): out[channel][position]; ABS: |.| and zeros at positions >= valid (the occurrence map)
-template <int NST, bool ABS>
+template <int NST, bool ABS, int PIECES, int TS>
 __device__ __forceinline__ void hc_epi_cols(const f32x16 (&acc)[NST], float bias, int ct, int st0, char* out, int valid, int c, int h) {
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
@@ -126,16 +134,19 @@ __device__ __forceinline__ void hc_epi_cols(const f32x16 (&acc)[NST], float bias
                 if (ABS) f = piece * 8 + e < valid ? fabsf(f) : 0.0f;
                 o[e] = (__bf16)f;
             }
-            if (piece < HC_PIECES) *reinterpret_cast<bf16x8*>(out + ((ct * 32 + c) * HC_TS + piece) * 16) = o;
+            if (piece < PIECES) *reinterpret_cast<bf16x8*>(out + ((ct * 32 + c) * TS + piece) * 16) = o;
         }
     }
 }
 
+template <int KS1, int ROWS>
 __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
+    using G = HcGeom<KS1, ROWS>;
+    constexpr int HC_ROWS = ROWS, HC_PIECES = G::PIECES, HC_KS1 = KS1, HC_XS = G::XS, HC_B1S = G::B1S, HC_O2S = G::O2S, HC_TS = G::TS, NST = G::NST;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const XR = smem;
-    char* const B1 = smem + HC_XR_BYTES;
-    char* const B2 = B1 + HC_B1_BYTES;
+    char* const B1 = smem + G::XR_BYTES;
+    char* const B2 = B1 + G::B1_BYTES;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.x / a.G, g = blockIdx.x - n * a.G;
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
     {  // x tile by LDS-DMA: slot s of the image = (row s / XS, piece s % XS); pieces beyond the channels / rows beyond the tile arrive as zeros
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, (unsigned)a.N * (unsigned)a.S * (unsigned)a.Cbp * 2u, 0x00020000);
         const int ppr = a.Cbp >> 3;
-        constexpr int nix = (HC_ROWS * HC_XS + 63) / 64;  // the last instruction spills 24 zero slots into B1 (written later)
+        constexpr int nix = (HC_ROWS * HC_XS + 63) / 64;  // the last instruction may spill zero slots into B1 (written later)
         for (int j = wave; j < nix; j += 8) {
             const int s = j * 64 + lane;
             const int r = s / HC_XS, p = s - r * HC_XS;
@@ -155,11 +166,11 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (hc_lds_ptr_t)(XR + j * 1024), 16, (int)off, 0, 0, 0);
         }
     }
-    int rows4[4];
+    int rows4[NST];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) rows4[st] = min(32 * st + c, HC_ROWS - 1);
+    for (int st = 0; st < NST; ++st) rows4[st] = min(32 * st + c, HC_ROWS - 1);
 
-    f32x16 acc[4];
+    f32x16 acc[NST];
     bf16x8 W3[HC_KS1];
     if (full) {  // kernel-uniform
         bf16x8 W1[HC_KS1];
@@ -171,16 +182,16 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
         // ---- c1: x -> f1 = relu(.), rows of B1 ----
         bf16x8 W2[16];
         hc_load_w<16, 0, 8>(W2, a.w2, wave, 16, lane);
-        hc_mma<HC_KS1, 4, false>(acc, W1, XR, HC_XS, rows4, h);
+        hc_mma<HC_KS1, NST, false>(acc, W1, XR, HC_XS, rows4, h);
         hc_load_w<16, 8, 16>(W2, a.w2, wave, 16, lane);
-        hc_epi_rows<4>(acc, a.b1, wave, 0, B1, HC_B1S, c, h);
+        hc_epi_rows<NST, HC_ROWS>(acc, a.b1, wave, 0, B1, HC_B1S, c, h);
         hc_barrier();
         // ---- c2: f1 -> f^T (no activation), B2 ----
         hc_load_w<HC_KS1, 0, 6>(W3, a.w3, wave, a.nks1, lane);
         const float bias2 = a.b2[wave * 32 + c];
-        hc_mma<16, 4, true>(acc, W2, B1, HC_B1S, rows4, h);
+        hc_mma<16, NST, true>(acc, W2, B1, HC_B1S, rows4, h);
         hc_load_w<HC_KS1, 6, HC_KS1>(W3, a.w3, wave, a.nks1, lane);
-        hc_epi_cols<4, false>(acc, bias2, wave, 0, B2, HC_ROWS, c, h);
+        hc_epi_cols<NST, false, HC_PIECES, HC_TS>(acc, bias2, wave, 0, B2, HC_ROWS, c, h);
         hc_barrier();  // everyone is past its reads of f1
     } else {
         hc_load_w<HC_KS1>(W3, a.w3, wave, a.nks1, lane);
@@ -191,9 +202,9 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
     const int ct4 = wave & 3, sp4 = wave >> 2;
     bf16x8 W4[16];
     hc_load_w<16, 0, 8>(W4, a.w4, ct4, 16, lane);
-    hc_mma<HC_KS1, 4, false>(acc, W3, XR, HC_XS, rows4, h);
+    hc_mma<HC_KS1, NST, false>(acc, W3, XR, HC_XS, rows4, h);
     hc_load_w<16, 8, 16>(W4, a.w4, ct4, 16, lane);
-    hc_epi_rows<4>(acc, a.b3, wave, 0, B1, HC_B1S, c, h);
+    hc_epi_rows<NST, HC_ROWS>(acc, a.b3, wave, 0, B1, HC_B1S, c, h);
     hc_barrier();  // o1 complete; everyone is past its reads of the x tile
     // ---- c4: o1 -> o2 = relu(.), rows of XR: wave = (channel tile, half of the positions) ----
     {
@@ -203,13 +214,13 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
         bf16x8 W5[8];
         hc_load_w<8>(W5, a.w5, pt5, 8, lane);
         hc_mma<16, 2, false>(acc2, W4, B1, HC_B1S, rows2, h);
-        hc_epi_rows<2>(acc2, a.b4, ct4, 2 * sp4, XR, HC_O2S, c, h);
+        hc_epi_rows<2, HC_ROWS>(acc2, a.b4, ct4, 2 * sp4, XR, HC_O2S, c, h);
         hc_barrier();  // o2 complete; everyone is past its reads of o1
         // ---- c5: o2 -> occ^T = |.|, rows of B1: wave = (prototype tile, 32-position sub-tile) ----
         f32x16 acc1[1];
         const int rows1[1] = {min(32 * st5 + c, HC_ROWS - 1)};
         hc_mma<8, 1, true>(acc1, W5, XR, HC_O2S, rows1, h);
-        hc_epi_cols<1, true>(acc1, 0.0f, pt5, st5, B1, valid, c, h);
+        hc_epi_cols<1, true, HC_PIECES, HC_TS>(acc1, 0.0f, pt5, st5, B1, valid, c, h);
     }
     hc_barrier();
     // ---- occurrence map rows of this tile: occ[n][p][s0 + s] (fp32 of the bf16 map, as the separate launches store it) ----
@@ -225,14 +236,15 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) accp[pt][e] = 0.0f;
     const bool two = a.P > 32;
+    constexpr int PKS = (HC_PIECES + 1) / 2;  // k-steps of 16 positions
 #pragma unroll
-    for (int ks = 0; ks < 7; ++ks) {
-        const bool dead = ks == 6 && h == 1;  // piece 13 does not exist (104 = 6.5 k-steps): both operands zero there
+    for (int ks = 0; ks < PKS; ++ks) {
+        const bool dead = 2 * ks + h >= HC_PIECES;  // 104 rows = 6.5 k-steps: the last half piece does not exist, both operands are zero there
         const int slot = dead ? 0 : 2 * ks + h;
         bf16x8 fb = *reinterpret_cast<const bf16x8*>(B2 + ((wave * 32 + c) * HC_TS + slot) * 16);
         bf16x8 o0 = *reinterpret_cast<const bf16x8*>(B1 + (c * HC_TS + slot) * 16);
         bf16x8 o1 = *reinterpret_cast<const bf16x8*>(B1 + ((32 + c) * HC_TS + slot) * 16);
-        if (ks == 6) {
+        if (2 * ks + 1 >= HC_PIECES) {
             typedef unsigned hc_u32x4 __attribute__((ext_vector_type(4)));
             hc_u32x4 z = {0u, 0u, 0u, 0u};
             fb = dead ? __builtin_bit_cast(bf16x8, z) : fb;
@@ -253,17 +265,19 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------------------
+static int hc_rows(const pasn_xproto_desc& d) { return d.Cbp <= 192 ? 104 : 96; }
+
 bool xproto_chain_supported(const pasn_xproto_desc& d, int dtype) {
     if (const char* e = getenv("PASN_HEAD_CHAIN"))
         if (e[0] == '0') return false;
     if (dtype != PASN_BF16) return false;
     if (d.D != 256 || d.Dp != 256 || d.Hd != 128 || d.Hp != 128) return false;
     if (d.P < 1 || d.P > 64) return false;
-    if (d.Cbp % 8 != 0 || d.Cbp > 16 * HC_KS1 || d.Cbp < 8) return false;
+    if (d.Cbp % 8 != 0 || d.Cbp > 256 || d.Cbp < 8) return false;
     if ((long)d.N * d.S * d.Cbp * 2 >= (1L << 31)) return false;
     return d.N > 0 && d.S > 0;
 }
-int xproto_chain_tiles(const pasn_xproto_desc& d) { return ceil_div(d.S, HC_ROWS); }
+int xproto_chain_tiles(const pasn_xproto_desc& d) { return ceil_div(d.S, hc_rows(d)); }
 
 int launch_xproto_chain(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
                         const void* w4, const float* b4, const void* w5, float* occ, float* slabs, const pasn_xproto_desc& d, hipStream_t s) {
@@ -279,8 +293,16 @@ int launch_xproto_chain(const void* x, const void* w1, const float* b1, const vo
     a.G = xproto_chain_tiles(d);
     a.R = ceil_div(d.S, a.G);
     a.full = d.mode == 0 ? 1 : 0;
-    PASN_MAX_LDS(160 * 1024, xproto_chain_kernel);
-    hipLaunchKernelGGL(xproto_chain_kernel, dim3((unsigned)(d.N * a.G)), dim3(512), (size_t)HC_LDS, s, a);
+    const dim3 grid((unsigned)(d.N * a.G)), block(512);
+    if (d.Cbp <= 192) {
+        constexpr size_t lds = HcGeom<12, 104>::LDS;
+        PASN_MAX_LDS(160 * 1024, xproto_chain_kernel<12, 104>);
+        hipLaunchKernelGGL((xproto_chain_kernel<12, 104>), grid, block, lds, s, a);
+    } else {
+        constexpr size_t lds = HcGeom<16, 96>::LDS;
+        PASN_MAX_LDS(160 * 1024, xproto_chain_kernel<16, 96>);
+        hipLaunchKernelGGL((xproto_chain_kernel<16, 96>), grid, block, lds, s, a);
+    }
     return check_launch("xproto_chain_kernel");
 }
 

@@ -208,12 +208,14 @@ def test_xproto_head_vs_oracle_shapes(cfg, dtype):
     assert torch.equal(feat, feat2) and torch.equal(sim, sim2) and torch.equal(logits, logits2)
 
 
-@pytest.mark.parametrize("cfg", [(32, 192, 784, 40, 4), (3, 192, 100, 30, 3), (2, 96, 209, 64, 4), (1, 40, 3, 7, 2), (2, 192, 3200, 40, 4)])
+@pytest.mark.parametrize("cfg", [(32, 192, 784, 40, 4), (3, 192, 100, 30, 3), (2, 96, 209, 64, 4), (1, 40, 3, 7, 2), (2, 192, 3200, 40, 4),
+                                 (5, 256, 1568, 40, 4), (2, 256, 97, 30, 3), (3, 200, 193, 64, 4)])
 def test_xproto_chain_head(cfg):
     """Head B with the intermediate maps resident in LDS (pasn_xproto_chain_fwd, bf16, D = 256) against the oracle and against the
     seven-launch path on the same inputs: the headline shape (784 positions: 8 tiles of 98), ragged tiles (100 = one tile, 209 = 3 x 70 -
     1), a single short tile, P = 64 / P < 32 (one prototype tile), a narrow trunk (40 and 96 channels: k-steps beyond the data are zero
-    fragments), 31 tiles per clip; and the occurrence-map-only mode."""
+    fragments), 31 tiles per clip; the 256-channel instance (96-row tiles: the reference's own video shape 5 x 256 x 8 x 14 x 14, a tile
+    of 97 = 96 + 1 positions, 200 channels); and the occurrence-map-only mode."""
     n, cb, s, P, K = cfg
     D = 256
     sd = head_b_state(cb, D, P, K, video=True)
@@ -247,5 +249,6 @@ def test_xproto_chain_head_routing():
     assert ok(mk(), torch.bfloat16) == 1 and ok(mk(mode=1), torch.bfloat16) == 1
     assert ok(mk(), torch.float32) == 0                         # fp32 keeps the seven-launch path
     assert ok(mk(D=512, Dp=512, Hd=256, Hp=256), torch.bfloat16) == 0   # image head (D = 512)
-    assert ok(mk(Cb=512, Cbp=512), torch.bfloat16) == 0        # R(2+1)D / ResNet trunks: 512 channels do not fit the tile
+    assert ok(mk(Cb=256, Cbp=256), torch.bfloat16) == 1        # R(2+1)D-18[:-3]: 256 channels, the 96-row instance
+    assert ok(mk(Cb=512, Cbp=512), torch.bfloat16) == 0        # ResNet-18 trunks: 512 channels do not fit the tile
     assert ok(mk(P=68, Pp=72), torch.bfloat16) == 0
