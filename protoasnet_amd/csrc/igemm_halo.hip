@@ -29,7 +29,11 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int HG_MAX = 8;  // 16-row DMA groups of the halo tile per wave (tile <= 512 rows)
 
-template <int NT, int MT, int MODE, int ABL = 0>  // ABL: timing-only ablation builds (tools), 0 in the product
+// SP (MODE 1 only): SLICE-granular pipeline.  The per-tap schedule below gives a (3,1,1) conv steps of 8 MFMAs between barriers, and because
+// vmcnt retires in order every step's wait for its weight tile is also a wait for the halo groups issued one step earlier: ~1.2 us per step,
+// 15 steps per block, the matrix pipe ~15 % busy.  With SP the whole of slice cs + 1 (halo tile + the three taps' weight tiles, 6 weight
+// stages) is requested at the start of slice cs, the three taps run back to back without a barrier, and ONE wait + barrier ends the slice.
+template <int NT, int MT, int MODE, int ABL = 0, bool SP = false>  // ABL: timing-only ablation builds (tools), 0 in the product
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
                                                             const __bf16* __restrict__ res, __bf16* __restrict__ y, pasn_conv_desc d,
@@ -236,6 +240,23 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
     // taps - 1 steps of slice cs).  At the end of step s everything but the DMAs issued IN step s must have landed.
     float* const scb = reinterpret_cast<float*>(smem + scb_off);  // scale | bias of this block's channels, beyond tiles and epilogue image
     igemm_stage_scale_bias<BN>(scb, scale, bias, n0, d.w_rows, tid);
+    if constexpr (SP && MODE == 1) {
+        for (int i = 0; i < per_wave; ++i) issue_a(0, i);
+        for (int tp = 0; tp < 3; ++tp) issue_w(0, tp, tp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int cs = 0; cs < ncs; ++cs) {
+            const int set = (cs & 1) * 3;
+            if (cs + 1 < ncs) {  // stages of slice cs - 1: everyone left them at the barrier that ended it
+                for (int i = 0; i < per_wave; ++i) issue_a(cs + 1, i);
+                for (int tp = 0; tp < 3; ++tp) issue_w(cs + 1, tp, 3 - set + tp);
+            }
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp) mma_step(cs, tp, tp, 0, set + tp);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else {
     for (int i = 0; i < per_wave; ++i) issue_a(0, i);
     issue_w(0, 0, 0);
     if (taps > 1) issue_w(0, 1, 1);
@@ -274,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
                 stage = stage == 2 ? 0 : stage + 1;
             }
     }
+    }
 
     // ---- epilogue: scale / bias -> wave-private LDS image of 32 positions x BN channels -> residual + activation + whole-row stores ----
     if ((ABL & 8) && acc[0][0][0] != 1.2345f) return;
@@ -310,6 +332,14 @@ static int halo_rows16(const pasn_conv_desc& d, int mode, int mt) {
     return (rows + 15) / 16 * 16;
 }
 
+// (3,1,1) layers: slice-granular pipeline (six weight stages) where it fits two blocks per CU; PASN_HALO_SP=0: the per-tap schedule everywhere
+static bool halo_sp(int mode, int r16, int nt) {
+    if (mode != 2) return false;
+    if (const char* e = getenv("PASN_HALO_SP"))
+        if (e[0] == '0') return false;
+    return (size_t)2 * r16 * 64 + (size_t)6 * nt * 32 * 64 + (size_t)nt * 32 * 8 <= 80 * 1024;
+}
+
 bool igemm_halo_fits(const pasn_conv_desc& d, int mode, int nt, int mt) {
     const int r16 = halo_rows16(d, mode, mt);
     if (r16 > HG_MAX * 4 * 16) return false;
@@ -324,7 +354,8 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const long boxes = mode == 1 ? ceil_div(M, 128L * mt) : (long)d.N * ceil_div(d.Ti, 4 * mt) * ceil_div(d.Hi * d.Wi, 32);
     const dim3 grid((unsigned)boxes, ceil_div(d.Cout_p, nt * 32)), block(256);
-    const size_t tiles = (size_t)2 * r16 * 64 + (size_t)3 * nt * 32 * 64, image = (size_t)4 * 32 * (nt * 32 + 8) * 2;
+    const bool sp = halo_sp(mode, r16, nt);
+    const size_t tiles = (size_t)2 * r16 * 64 + (size_t)(sp ? 6 : 3) * nt * 32 * 64, image = (size_t)4 * 32 * (nt * 32 + 8) * 2;
     const size_t scb_off = tiles > image ? tiles : image;
     const size_t lds = scb_off + (size_t)nt * 32 * 8;
 #define PASN_IH(NT_, MT_, MODE_)                                                                                                  \
@@ -346,6 +377,15 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
         PASN_IHA(1) PASN_IHA(2) PASN_IHA(4) PASN_IHA(8) PASN_IHA(3) PASN_IHA(15) PASN_IHA(16)
 #undef PASN_IHA
     }
+#define PASN_IHS(NT_, MT_)                                                                                                        \
+    if (sp && nt == NT_ && mt == MT_) {                                                                                           \
+        if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_halo_kernel<NT_, MT_, 1, 0, true>);                                    \
+        hipLaunchKernelGGL((igemm_halo_kernel<NT_, MT_, 1, 0, true>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale, \
+                           bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off, igemm_direct_epilogue());                   \
+        return check_launch("igemm_halo_kernel (slice pipeline)");                                                                \
+    }
+    PASN_IHS(2, 2) PASN_IHS(2, 1) PASN_IHS(4, 1)
+#undef PASN_IHS
     PASN_IH(2, 2, 0) PASN_IH(2, 1, 0) PASN_IH(4, 2, 0) PASN_IH(4, 1, 0) PASN_IH(5, 2, 0) PASN_IH(5, 1, 0)
     PASN_IH(2, 2, 1) PASN_IH(2, 1, 1) PASN_IH(4, 2, 1) PASN_IH(4, 1, 1) PASN_IH(5, 2, 1) PASN_IH(5, 1, 1)
 #undef PASN_IH
