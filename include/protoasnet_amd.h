@@ -284,7 +284,7 @@ int pasn_xproto_head_fwd(const void* x, const void* a1, const float* a1b, const 
 /*
  * Head B in two launches (csrc/head_chain.hip + the finish kernel): same contract and outputs as pasn_xproto_head_fwd (replaces
  * Video_XProtoNet.forward, Video_XProtoNet.py:66-98, after the trunk), for bf16 with D = 256, Hd = 128, P <= 64 and a trunk channel
- * stride <= 192 (the X3D heads of BASELINE configs 2, 3 and 5).  A block keeps a tile of <= 104 positions of one clip in LDS through the
+ * stride <= 256 (the X3D heads of BASELINE configs 2, 3 and 5; the reference's own R(2+1)D-18[:-3] video trunk).  A block keeps a tile of <= 104 positions of one clip in LDS through the
  * five convs and adds the tile's share of the occurrence-weighted pooling; no intermediate map reaches memory.
  *   a1 .. o3 : conv weights FRAGMENT-MAJOR, [rows / 32][kc / 16][64][8] bf16 (the w_frag = 1 layout of pasn_conv3d_fwd)
  *   ws       : pasn_xproto_chain_workspace_bytes() bytes, 256-byte aligned (the pooling slabs [N][tiles][P][D] fp32; mode 1: unused)
