@@ -270,7 +270,24 @@ typedef struct pasn_xproto_desc {
     int32_t D, Dp;     /* prototype depth, round_up(D, 8)          */
     int32_t Hd, Hp;    /* D / 2 (hidden width of the occurrence module), round_up(Hd, 8) */
     int32_t P, Pp;     /* prototypes, round_up(P, 8)               */
-    int32_t K;         /* classes                                   */
+    int32_t K;         /*
+ * Front half of an X3D stage's first block in ONE launch (bf16): conv_a (1x1x1) + norm_a + ReLU -> conv_b (depthwise 3x3x3, stride
+ * (1,2,2), pad 1) + norm_b (+ the descriptor's activation, + squeeze-excite pool partial rows), pytorchvideo's BottleneckTransform as
+ * instantiated by the reference's x3d trunks; replaces pasn_conv3d_fwd + pasn_dwconv3d_fwd for that pair -- the expanded activation (2.25x
+ * the block width at the input resolution) stays in LDS.
+ *   x  : block input, channels-last [N][T][H][W][de->Cin_p];   y : [N][T][Ho][Wo][d->Cout_p]
+ *   wa : conv_a weights FRAGMENT-MAJOR (w_frag = 1), scale_a / bias_a: folded norm_a [de->w_rows] (zero beyond the channels)
+ *   w  : conv_b weights fp32 [27][Cp], scale / bias: folded norm_b [Cp]
+ *   pool_partial : NULL or fp32 [N][pasn_x3d_expdw_pool_blocks()][Cp] (sums of the pre-activation output over positions, fixed order)
+ * _supported() == 0: issue the two launches.
+ */
+int pasn_x3d_expdw_supported(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype);
+int pasn_x3d_expdw_pool_blocks(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype);
+int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, const float* bias_a, const float* w, const float* scale,
+                       const float* bias, void* y, float* pool_partial, const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype,
+                       void* stream);
+
+/* classes                                   */
     int32_t mode;
 } pasn_xproto_desc;
 

@@ -288,8 +288,18 @@ class X3DFeatures(_plan.HipTrunk):
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
                 act_b = "none" if blk.se is not None else "swish"  # no gate between BN and Swish: the stencil applies Swish
                 gate = None
-                e = pre if pre is not None else pb.conv(x, blk.conv_a, blk.bn_a, act="relu")
-                if blk.se is not None:
+                # first block of a stage: expand conv + strided stencil in one launch, the expanded activation never leaves LDS
+                front = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act_b, pool=blk.se is not None) if pre is None else None
+                if front is not None:
+                    if blk.se is not None:
+                        y, pooled = front
+                        gate = pb.se_gate_or_prologue(y, pooled, blk.se.fc1, blk.se.fc2, consumer=(blk.conv_c, True))
+                    else:
+                        y = front
+                e = None if front is not None else pre if pre is not None else pb.conv(x, blk.conv_a, blk.bn_a, act="relu")
+                if front is not None:
+                    pass
+                elif blk.se is not None:
                     # stencil + gate in one launch where that pays; where the project conv can compute the gate in its own prologue, only
                     # the pool partial rows are produced here (gate = ("pooled", ...))
                     y, gate = pb.dwconv_se(e, blk.conv_b, blk.bn_b, blk.se.fc1, blk.se.fc2, consumer=(blk.conv_c, True))

@@ -139,6 +139,16 @@ struct DwMfmaGeom {
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
                    const DwMfmaGeom& g, hipStream_t s);
+// x3d_expdw.hip: expand conv (1x1x1 + BN + ReLU) -> depthwise 3x3x3 stride-(1,2,2) stencil (+BN, act, SE partial sums) in one launch, both on
+// the matrix cores, the expanded activation only ever in LDS (the first block of an X3D stage); ok = 0: not covered
+struct XeGeom {
+    int ok, KS, XS, xtb, lds;       // expand k-steps in registers, 16-byte slots per staged x position (odd), bytes per x tile, dynamic LDS
+    int CQ, RTH, RTW;               // 64-channel quads, regions (3 x 14 outputs) per frame
+    int Tc, nT, upb, chunks, bpc;   // T chunk (+count), units per block, SE partial rows per clip, blocks per clip
+};
+XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype);
+int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
+                     void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s);
 // igemm.hip: windowed dense convs (bf16) as an implicit GEMM with direct-to-LDS staging; NT = 0: not covered
 int igemm_nt(const pasn_conv_desc& d, int dtype);
 // first_conv_mfma.hip: the 7x7 stride-2 stems on the matrix cores (bf16 out); slot < 0: not covered

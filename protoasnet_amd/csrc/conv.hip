@@ -966,6 +966,32 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     return PASN_ERR_ARG;
 }
 
+// First block of an X3D stage, front half: expand conv + BN + ReLU -> stride-(1,2,2) depthwise stencil + BN (+ act, + SE pool partial rows)
+// in ONE launch (x3d_expdw.hip).  de = the 1x1x1 conv (fragment-major weights), d = the depthwise conv on its output.
+extern "C" int pasn_x3d_expdw_supported(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype) {
+    if (!conv_desc_ok(de) || !conv_desc_ok(d)) return 0;
+    pasn_conv_desc f = *de;
+    f.w_frag = 1;
+    return xe_geom(f, *d, dtype).ok;
+}
+extern "C" int pasn_x3d_expdw_pool_blocks(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype) {
+    if (!conv_desc_ok(de) || !conv_desc_ok(d)) return 0;
+    pasn_conv_desc f = *de;
+    f.w_frag = 1;
+    const XeGeom g = xe_geom(f, *d, dtype);
+    return g.ok ? g.chunks : 0;
+}
+extern "C" int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, const float* bias_a, const float* w, const float* scale,
+                                  const float* bias, void* y, float* pool_partial, const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype,
+                                  void* stream) {
+    PASN_REQUIRE(x && wa && scale_a && bias_a && w && scale && bias && y, "null pointer");
+    PASN_REQUIRE(conv_desc_ok(de) && conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
+    PASN_REQUIRE(dtype == PASN_BF16 && de->w_frag == 1, "bf16 with fragment-major expand weights only");
+    const XeGeom g = xe_geom(*de, *d, dtype);
+    PASN_REQUIRE(g.ok, "layer pair not covered (pasn_x3d_expdw_supported returns 0)");
+    return launch_x3d_expdw(x, wa, scale_a, bias_a, w, scale, bias, y, pool_partial, *de, *d, g, (hipStream_t)stream);
+}
+
 // Depthwise stencil + squeeze-excite gate in ONE launch (the clip's last-arriving block computes the gate); only where the T-marching
 // stencil covers the layer -- pasn_dwconv3d_se_supported says so, the caller otherwise issues pasn_dwconv3d_fwd + pasn_se_gate_fwd.
 extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse) {

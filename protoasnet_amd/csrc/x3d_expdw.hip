@@ -1,0 +1,415 @@
+// First block of an X3D stage, front half, in ONE launch (bf16): 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 conv, stride (1,2,2),
+// pad 1 + BN (+ Swish, + squeeze-excite partial sums).  The expanded activation -- 2.25x the block width at the INPUT resolution, four
+// times the positions of everything downstream -- never reaches memory.
+//
+// Why: the stride-2 blocks are where the expanded tensor costs most.  At the benchmark shape the first block of stage 2 writes 694 MB
+// (54 channels at 112 x 112) and reads it back once: 1.39 GB of the step's 11 GB, for a K = 24 GEMM; unfused that is two launches at the
+// fabric's rate (182 + 235 us).  Round 1's fused kernel (VALU stencil from an LDS ring) lost to the unfused pair; this one runs BOTH halves
+// on the matrix cores:
+//   * block = 4 waves = one 64-channel quad of the expanded channels of one clip; a unit = (T chunk, region of 3 x 14 outputs); the block
+//     MARCHES ALONG T over the 7 x 29 input positions the region needs;
+//   * per input frame: the x rows of the region arrive by LDS-DMA (out-of-image pieces zero-filled by the hardware); the expand conv is
+//     v_mfma_f32_32x32x16_bf16 with a staged ROW of the region as the 32-position tile (A = this wave's 32 expand channels, whole K, in
+//     registers for the launch); the accumulator goes through the lane swap (8 channels of one position per lane), BN + ReLU, is forced
+//     to ZERO outside the image (the stencil pads the EXPANDED activation), and is written as one 16-byte piece per lane into the frame
+//     image of a 2-frame ring -- [position][9 slots], the layout dwmfma.hip stages by DMA;
+//   * the stencil is dwmfma.hip's: v_mfma_f32_16x16x32_bf16 with block-diagonal weight operands, one 16-byte LDS read per lane and tap
+//     pair, three accumulator sets (outputs t-1, t, t+1) whose role rotation rides in the MFMAs, outputs stored straight from the
+//     accumulators through a per-frame buffer descriptor;
+//   * ONE fence-free barrier per frame: frame t+1 is expanded into the other ring slot before frame t's stencil, the x rows of frame
+//     t+2 are requested in between; what must have landed is waited for by count.
+// Rounding points are those of the two launches (the expanded activation is rounded to bf16 before the stencil; fp32 accumulation), the
+// MFMA k order of the expand conv is pwconv's, the stencil's is dwmfma's.
+#include "common.h"
+
+namespace pasn {
+
+typedef __attribute__((ext_vector_type(4))) unsigned xe_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned xe_u32x2;
+typedef __attribute__((address_space(3))) void* xe_lds_ptr_t;
+
+constexpr int XE_NT = 3;                    // output rows of a region = 16-lane position tiles per wave
+constexpr int XE_BW = 14;                   // output columns of a region
+constexpr int XE_RW = (XE_BW - 1) * 2 + 3;  // 29 staged columns
+constexpr int XE_RH = (XE_NT - 1) * 2 + 3;  // 7 staged rows
+constexpr int XE_POS = XE_RH * XE_RW;       // 203 staged positions per frame
+constexpr int XE_SLOTS = 9;                 // 16-byte slots per staged position (8 used): 2 * 9 = 2 (mod 4), see dwmfma.hip
+constexpr int XE_FRB = (XE_POS * XE_SLOTS * 16 + 1023) / 1024 * 1024;  // bytes per frame image
+constexpr int XE_NE = 6;                    // x DMA instructions per wave and frame, at most (203 positions x <= 7 slots)
+constexpr unsigned XE_OOB = 0x80000000u;
+
+__device__ __forceinline__ unsigned xe_bf16_bits(float f) {
+    const __bf16 b = (__bf16)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ void xe_wait_all_but(int n) {  // n wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;  // n <= XE_NT
+    }
+}
+__device__ __forceinline__ void xe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// KS: k-steps of the expand conv held in registers (K = block width <= 16 KS channels); ACT: the stencil's epilogue activation
+template <int KS, int ACT>
+__global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wa,
+                                                           const float* __restrict__ sa, const float* __restrict__ ba,
+                                                           const float* __restrict__ w, const float* __restrict__ scale,
+                                                           const float* __restrict__ bias, __bf16* __restrict__ y, float* __restrict__ pool,
+                                                           pasn_conv_desc d, int Cin_p, int nks, XeGeom g) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const ring = smem;                                          // [2][XE_FRB] expanded frames
+    char* const xt = smem + 2 * XE_FRB;                               // [2][g.xtb] x rows of the region: [position][XS slots]
+    float* const scb = reinterpret_cast<float*>(xt + 2 * g.xtb);      // [2][64] expand scale | bias of this quad
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, q = lane >> 4;   // stencil roles
+    const int c32 = lane & 31, h32 = lane >> 5;  // expand roles
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = lb / g.bpc, bx = lb - n * g.bpc;
+    const int chunk = bx / g.CQ, cq = bx - chunk * g.CQ;
+    const int Cp = d.Cout_p;
+    const int c0 = (cq * 4 + wave) * 16;
+    const bool wave_live = c0 < Cp;
+    const bool wave_tail = c0 + 16 > d.Cout;
+    const int XS = g.XS, pieces = Cin_p >> 3;
+
+    // ---- stencil: block-diagonal weight operands (dwmfma.hip) ----
+    xe_u32x4 A[3][5];
+    {
+        const int c = c0 + m;
+        const bool mine = ((m >> 3) == (q & 1)) && c < Cp;
+        const int dwsel = (m & 7) >> 1, sh = (m & 1) * 16;
+        float wv[3][5];
+        const int cc = min(c, Cp - 1);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) wv[kt][j] = w[(kt * 9 + min(2 * j + (q >> 1), 8)) * Cp + cc];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const bool live = mine && 2 * j + (q >> 1) < 9;
+                const unsigned bits = live ? (xe_bf16_bits(wv[kt][j]) << sh) : 0u;
+                A[kt][j] = xe_u32x4{dwsel == 0 ? bits : 0u, dwsel == 1 ? bits : 0u, dwsel == 2 ? bits : 0u, dwsel == 3 ? bits : 0u};
+            }
+    }
+    const int ce = c0 + 4 * q;
+    const bool cev = ce < Cp;
+    float sc[4], bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = cev ? scale[ce + i] : 0.0f;
+        bs[i] = cev ? bias[ce + i] : 0.0f;
+    }
+    float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- expand conv: this wave's 32-channel tile (ct = wave & 1 of the quad) for the staged rows rr = (wave >> 1) + 2 i ----
+    const int ect = wave & 1;
+    const int ectiles = (Cp + 31) >> 5;
+    bf16x8 AE[KS];
+    {
+        const int ctg = min(cq * 2 + ect, ectiles - 1);
+        const __bf16* ab = wa + ((long)ctg * nks * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) AE[ks] = load_frag<__bf16>(ab + (size_t)(ks < nks ? ks : nks - 1) * 512);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            if (ks >= nks || cq * 2 + ect >= ectiles) AE[ks] = zero_frag<__bf16>();  // wave-uniform
+    }
+    if (threadIdx.x < 64) {
+        const int ch = cq * 64 + threadIdx.x;
+        scb[threadIdx.x] = ch < Cp ? sa[ch] : 0.0f;
+        scb[64 + threadIdx.x] = ch < Cp ? ba[ch] : 0.0f;
+    }
+    __syncthreads();
+    float esc[2][8], ebs[2][8];  // this lane's 8 channels per register pair, after the lane swap: 32 ect + 16 pr + 8 h32 ..
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        load8(scb + 32 * ect + 16 * pr + 8 * h32, esc[pr]);
+        load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs[pr]);
+    }
+
+    const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
+    const long fx = (long)Hi * Wi * Cin_p;  // elements per x frame
+    const unsigned fx_bytes = (unsigned)(fx * 2);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x + (long)n * Ti * fx), 0, (unsigned)Ti * fx_bytes, 0x00020000);
+    const int nix = (XE_POS * XS + 63) >> 6;   // 1-KiB x DMA instructions per frame
+    int tapoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int tap9 = min(2 * j + (q >> 1), 8);
+        tapoff[j] = ((tap9 / 3) * XE_RW + (tap9 % 3)) * (XE_SLOTS * 16);
+    }
+    const int regions = g.RTH * g.RTW;
+    const int units = g.nT * regions;
+    const int u_end = min(units, (chunk + 1) * g.upb);
+
+#pragma unroll 1
+    for (int u = chunk * g.upb; u < u_end; ++u) {
+        const int tch = u / regions, reg = u - tch * regions;
+        const int rth = reg / g.RTW, rtw = reg - rth * g.RTW;
+        const int t0 = tch * g.Tc, t1 = min(t0 + g.Tc, d.To);
+        const int h0 = rth * XE_NT, w0 = rtw * XE_BW;
+        // ---- x DMA roles: instruction i = wave + 4 e covers slots 64 i .. of the x tile; slot -> (staged position, piece) ----
+        unsigned goff[XE_NE];
+#pragma unroll
+        for (int e = 0; e < XE_NE; ++e) {
+            const int slot = (wave + 4 * e) * 64 + lane;
+            const int rp = slot / XS, p = slot - rp * XS;
+            const int rr = rp / XE_RW, cc = rp - rr * XE_RW;
+            const int hi = h0 * 2 - 1 + rr, wi = w0 * 2 - 1 + cc;
+            const bool ok = wave + 4 * e < nix && rp < XE_POS && p < pieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cin_p + p * 8) * 2) : XE_OOB;
+        }
+        const int kdma = max(0, (nix - wave + 3) >> 2);
+        auto staged = [&](int ti) -> bool { return ti >= 0 && ti < Ti && ti >= t0 - 1 && ti <= t1; };
+        auto slot_of = [&](int ti) -> int { return (ti - (t0 - 1)) & 1; };
+        auto issue_x = [&](int ti) {
+            if (!staged(ti)) return;
+            const unsigned foff = (unsigned)ti * fx_bytes;
+            char* dst = xt + slot_of(ti) * g.xtb;
+#pragma unroll
+            for (int e = 0; e < XE_NE; ++e)
+                if (wave + 4 * e < nix)  // wave-uniform
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (xe_lds_ptr_t)(dst + (wave + 4 * e) * 1024), 16, (int)goff[e], (int)foff, 0, 0);
+        };
+        const bool colin = c32 < XE_RW && (unsigned)(w0 * 2 - 1 + c32) < (unsigned)Wi;
+        // expand frame ti from its x tile into its ring image
+        auto produce = [&](int ti) {
+            if (!staged(ti)) return;
+            const char* xb = xt + slot_of(ti) * g.xtb;
+            char* rb = ring + slot_of(ti) * XE_FRB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = (wave >> 1) + 2 * i;
+                if (rr >= XE_RH) break;  // wave-uniform
+                const bool inside = (unsigned)(h0 * 2 - 1 + rr) < (unsigned)Hi;  // wave-uniform
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                if (inside) {
+                    const char* xp = xb + (rr * XE_RW + min(c32, XE_RW - 1)) * XS * 16;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int piece = 2 * ks + h32;
+                        bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + min(piece, XS - 1) * 16);
+                        if (piece >= pieces) b = zero_frag<__bf16>();
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], b, acc, 0, 0, 0);
+                    }
+                }
+                const bool keep = inside && colin;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float v[8];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * pr + qq]), __float_as_uint(acc[8 * pr + 4 + qq]), false, false);
+                        v[qq] = __uint_as_float(sw[0]);
+                        v[4 + qq] = __uint_as_float(sw[1]);
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(keep ? fmaxf(v[e] * esc[pr][e] + ebs[pr][e], 0.0f) : 0.0f);
+                    if (c32 < XE_RW) *reinterpret_cast<bf16x8*>(rb + ((rr * XE_RW + c32) * XE_SLOTS + 4 * ect + 2 * pr + h32) * 16) = o;
+                }
+            }
+        };
+
+        // ---- stencil roles (dwmfma.hip with SS = 2, one output row per tile) ----
+        const bool lane_ok = m < XE_BW && w0 + m < d.Wo && cev;
+        const int rows_valid = min(XE_NT, d.Ho - h0);
+        const int ntl = rows_valid;
+        const int lbase0 = ((min(m, XE_BW - 1) * 2) * XE_SLOTS + 2 * wave + (q & 1)) * 16;
+        constexpr int lstep = 2 * XE_RW * XE_SLOTS * 16;
+        const int ystep = d.Wo * Cp;
+        __bf16* yclip = y + (long)n * d.To * d.Ho * d.Wo * Cp;
+        const long ofs = (long)d.Ho * d.Wo * Cp;
+        const unsigned yvoff = lane_ok ? (unsigned)(((h0 * d.Wo + w0 + m) * Cp + ce) * 2) : XE_OOB;
+        const unsigned fr_bytes = (unsigned)(ofs * 2);
+        const int kst = wave_live ? ntl : 0;
+        auto stored = [&](int to) -> int { return (to >= t0 && to < t1) ? kst : 0; };
+
+        f32x4 S0[XE_NT], S1[XE_NT], S2[XE_NT];
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int l = 0; l < XE_NT; ++l) S0[l] = S1[l] = S2[l] = zero4;
+
+        auto frame = [&](int ti, f32x4 (&P)[XE_NT], f32x4 (&C)[XE_NT], f32x4 (&N)[XE_NT]) {
+            if (wave_live && ti >= 0 && ti < Ti) {  // wave-uniform
+                int fbo = slot_of(ti) * XE_FRB + lbase0;
+                asm volatile("" : "+v"(fbo));
+                const char* ta[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) ta[j] = ring + fbo + tapoff[j];
+                bf16x8 Bq[2][5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+                for (int l = 0; l < XE_NT; ++l) {
+                    if (l + 1 < XE_NT) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) Bq[(l + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ta[j] + (l + 1) * lstep);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const bf16x8 B = Bq[l & 1][j];
+                        P[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, j == 0 ? C[l] : P[l], 0, 0, 0);
+                        C[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, j == 0 ? N[l] : C[l], 0, 0, 0);
+                        N[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : N[l], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
+                }
+            } else {
+#pragma unroll
+                for (int l = 0; l < XE_NT; ++l) {
+                    P[l] = C[l];
+                    C[l] = N[l];
+                    N[l] = zero4;
+                }
+            }
+            const int to = ti - 1;
+            if (wave_live && to >= t0 && to < t1) {
+                const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yclip + (long)to * ofs, 0, fr_bytes, 0x00020000);
+#pragma unroll
+                for (int l = 0; l < XE_NT; ++l)
+                    if (l < ntl) {  // wave-uniform
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = P[l][i] * sc[i] + bs[i];
+                        if (pool) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) psum[i] += lane_ok ? v[i] : 0.0f;
+                        }
+                        if constexpr (ACT == PASN_ACT_SWISH) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = v[i] * sigmoidf_(v[i]);
+                        } else if constexpr (ACT != PASN_ACT_NONE) {
+                            act_vec(v, d.act);
+                        }
+                        if (wave_tail) mask_tail(v, d.Cout - ce);
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xe_u32x2, o), yrsrc, (int)yvoff, l * ystep * 2, 0);
+                    }
+            }
+        };
+
+        // prologue: frame t0 - 1 expanded, x rows of frame t0 requested
+        issue_x(t0 - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        produce(t0 - 1);
+        issue_x(t0);
+#pragma unroll 1
+        for (int ti = t0 - 1; ti <= t1; ++ti) {
+            // the x rows of frame ti + 1 (requested in step ti - 1, before that step's stores) have landed; behind the barrier everyone's
+            // have, frame ti's image (written in step ti - 1) is complete, and nobody still reads the image / x tile of frame ti - 1
+            xe_wait_all_but(stored(ti - 2));
+            xe_barrier();
+            produce(ti + 1);
+            issue_x(ti + 2);
+            frame(ti, S0, S1, S2);
+        }
+        __syncthreads();
+    }
+
+    if (pool && wave_live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = psum[i];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8);
+            psum[i] = s;
+        }
+        if (m == 0 && cev) {
+            float* pr = pool + ((long)n * g.chunks + chunk) * Cp + ce;
+            *reinterpret_cast<f32x4*>(pr) = f32x4{psum[0], psum[1], psum[2], psum[3]};
+        }
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------------------------------------------------
+// de = the expand conv (1x1x1, stride 1, + BN + ReLU), d = the depthwise conv (3x3x3, stride (1,2,2), pad 1) on its output.
+XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
+    XeGeom g{};
+    if (const char* e = getenv("PASN_EXPDW"))
+        if (e[0] == '0') return g;
+    if (dtype != PASN_BF16) return g;
+    const bool dw = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 2 && d.sw == 2 && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
+                    d.To == d.Ti && d.Ho == (d.Hi - 1) / 2 + 1 && d.Wo == (d.Wi - 1) / 2 + 1 && d.Cin_p == d.Cout_p && d.Cin == d.Cout &&
+                    d.Cout_p % 8 == 0;
+    const bool ex = de.kt == 1 && de.kh == 1 && de.kw == 1 && !de.pt && !de.ph && !de.pw && de.st == 1 && de.sh == 1 && de.sw == 1 &&
+                    !de.in_swish && de.act == PASN_ACT_RELU && de.N == d.N && de.To == d.Ti && de.Ho == d.Hi && de.Wo == d.Wi &&
+                    de.Cout == d.Cin && de.Cout_p == d.Cin_p && de.w_frag == 1 && de.w_kc % 16 == 0 && de.w_kc >= de.Cin_p &&
+                    de.Cin_p % 8 == 0 && de.w_rows >= ((de.Cout_p + 31) / 32) * 32;
+    if (!dw || !ex) return g;
+    const int nks = de.w_kc / 16;
+    if (nks > 3) return g;  // K <= 48: the x tiles of two frames fit beside the ring
+    if ((long)d.Ti * d.Hi * d.Wi * de.Cin_p * 2 >= (1L << 31) || (long)d.To * d.Ho * d.Wo * d.Cout_p * 2 >= (1L << 31)) return g;
+    g.KS = nks <= 2 ? 2 : 3;
+    g.XS = (de.Cin_p / 8) | 1;
+    g.xtb = ((XE_POS + 3) * g.XS * 16 + 1023) / 1024 * 1024;  // + 3 positions: lanes 29 .. 31 of the last staged row read past it
+    g.lds = 2 * XE_FRB + 2 * g.xtb + 512;
+    if (g.lds > 80 * 1024 || (XE_POS * g.XS + 63) / 64 > 4 * XE_NE) return XeGeom{};
+    g.CQ = ceil_div(ceil_div(d.Cout_p, 16), 4);
+    g.RTH = ceil_div(d.Ho, XE_NT);
+    g.RTW = ceil_div(d.Wo, XE_BW);
+    const int regions = g.RTH * g.RTW;
+    const int force_tc = getenv("PASN_EXPDW_TC") ? atoi(getenv("PASN_EXPDW_TC")) : 0;
+    const int force_upb = getenv("PASN_EXPDW_UPB") ? atoi(getenv("PASN_EXPDW_UPB")) : 0;
+    double best = 1e30;
+    for (int tc = d.To;; tc = (tc + 1) / 2) {
+        const int tcu = force_tc ? std::min(force_tc, d.To) : tc;
+        const int nT = ceil_div(d.To, tcu), units = nT * regions;
+        for (int upb = 1; upb <= units; ++upb) {
+            if (force_upb && upb != std::min(force_upb, units)) continue;
+            const int chunks = ceil_div(units, upb);
+            if (chunks > 64 && upb < units && !force_upb) continue;  // the chunk count is the number of SE partial rows per clip
+            const long blocks = (long)d.N * g.CQ * chunks;
+            const double t = (double)ceil_div(blocks, 512L) * (4.0 + upb * (tcu + 3.0));
+            if (t < best) {
+                best = t;
+                g.Tc = tcu;
+                g.nT = nT;
+                g.upb = upb;
+                g.chunks = chunks;
+            }
+        }
+        if (force_tc || tc <= 4) break;
+    }
+    g.bpc = g.CQ * g.chunks;
+    g.ok = 1;
+    return g;
+}
+
+int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
+                     void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s) {
+    const dim3 grid((unsigned)(g.bpc * d.N)), block(256);
+#define PASN_XE(KS_, ACT_)                                                                                                       \
+    do {                                                                                                                         \
+        PASN_MAX_LDS(96 * 1024, x3d_expdw_kernel<KS_, ACT_>);                                                                    \
+        hipLaunchKernelGGL((x3d_expdw_kernel<KS_, ACT_>), grid, block, (size_t)g.lds, s, (const __bf16*)x, (const __bf16*)wa, sa, ba, w,   \
+                           scale, bias, (__bf16*)y, pool, d, de.Cin_p, de.w_kc / 16, g);                                         \
+    } while (0)
+#define PASN_XEK(KS_)                                                  \
+    do {                                                               \
+        if (d.act == PASN_ACT_NONE) PASN_XE(KS_, PASN_ACT_NONE);       \
+        else if (d.act == PASN_ACT_SWISH) PASN_XE(KS_, PASN_ACT_SWISH); \
+        else PASN_XE(KS_, -1);                                         \
+    } while (0)
+    if (g.KS == 2) PASN_XEK(2);
+    else PASN_XEK(3);
+#undef PASN_XEK
+#undef PASN_XE
+    return check_launch("x3d_expdw_kernel");
+}
+
+}  // namespace pasn

@@ -531,6 +531,70 @@ class PlanBuilder:
             return y, (pool_buf, pool_blocks, y)
         return y
 
+    def expand_dw(self, x: Act, conv_a: nn.Module, norm_a: Optional[nn.Module], conv_b: nn.Module, norm_b: Optional[nn.Module], act_b: str,
+                  pool: bool = False):
+        """Front half of an X3D stage's first block in ONE launch (``pasn_x3d_expdw_fwd``): 1x1x1 expand conv + BN + ReLU -> depthwise
+        3x3x3 stride-(1,2,2) conv + BN (+ ``act_b``, + squeeze-excite pool partial rows); the expanded activation stays in LDS.
+        Returns y (or (y, pooled) with ``pool``), or None when the pair is not covered (the caller emits the two launches)."""
+        if x.planar or self.dtype != torch.bfloat16 or conv_a.groups != 1 or conv_b.groups != conv_b.in_channels:
+            return None
+        one, zero = (1, 1, 1), (0, 0, 0)
+        if _triple(conv_a.kernel_size, 1) != one or _triple(conv_a.stride, 1) != one or _triple(conv_a.padding, 0) != zero:
+            return None
+        k, s, p = _triple(conv_b.kernel_size, 1), _triple(conv_b.stride, 1), _triple(conv_b.padding, 0)
+        if k != (3, 3, 3) or s != (1, 2, 2) or p != (1, 1, 1) or conv_b.in_channels != conv_a.out_channels:
+            return None
+        cm = conv_a.out_channels
+        mid = Act(x.N, x.T, x.H, x.W, cm, round_up(cm, 8), -1)  # the expanded activation: never materialised
+        wa, kca, rowsa = pack_conv_weight(conv_a.weight, x.Cp, self.dtype)
+        de = self._desc(x, mid, one, one, zero, "relu", False, kca, rowsa)
+        probe = ConvDesc(N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=cm, Cin_p=mid.Cp, To=x.T, Ho=(x.H - 1) // 2 + 1, Wo=(x.W - 1) // 2 + 1, Cout=cm,
+                         Cout_p=mid.Cp, kt=3, kh=3, kw=3, st=1, sh=2, sw=2, pt=1, ph=1, pw=1, act=_lib.ACT[act_b])
+        if not int(self.lib.pasn_x3d_expdw_supported(ctypes.byref(de), ctypes.byref(probe), self.code)):
+            return None
+        y = self._out_act(mid, cm, k, s, p)
+        d = self._desc(mid, y, k, s, p, act_b)
+        waf = wa.view(rowsa // 32, 32, kca // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+        de.w_frag = 1
+        sa, ba = fold_norm(norm_a, conv_a.bias, cm, rowsa, self.device)
+        wp = torch.zeros(27, y.Cp, dtype=torch.float32, device=self.device)
+        wp[:, : y.C] = conv_b.weight.detach().float().reshape(y.C, 27).t()
+        sb, bb = fold_norm(norm_b, conv_b.bias, y.C, y.Cp, self.device)
+        self.keep += [waf, sa, ba, wp, sb, bb]
+        pool_buf, pool_blocks = None, 0
+        if pool:
+            pool_blocks = int(self.lib.pasn_x3d_expdw_pool_blocks(ctypes.byref(de), ctypes.byref(d), self.code))
+            pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4)
+        fn, code = self.lib.pasn_x3d_expdw_fwd, self.code
+        a = tuple(t.data_ptr() for t in (waf, sa, ba, wp, sb, bb))
+        xb, yb, pb_, re_, rd_ = x.buf, y.buf, pool_buf, ctypes.byref(de), ctypes.byref(d)
+        self._use(xb, yb, pb_)
+        in_pos, out_pos = x.N * x.positions, y.N * y.positions
+        actc = _lib.ACT[act_b]
+        self._note("expand+dwconv", f"x3d_expdw_kernel<{2 if kca // 16 <= 2 else 3},{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1}>",
+                   (in_pos * x.C + out_pos * y.C + cm * x.C) * self.es + (y.N * pool_blocks * y.C * 4 if pool else 0),
+                   2 * in_pos * cm * x.C + 2 * out_pos * y.C * 27)
+        self.meta[-1]["shape"] = f"{x.C}->{cm} k111 + dw k333 s122 in{x.T}x{x.H}x{x.W} out{y.T}x{y.H}x{y.W}"
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], a[4], a[5], ptrs[yb],
+                                                       ptrs[pb_] if pb_ is not None else 0, re_, rd_, code, st)))
+        if pool:
+            return y, (pool_buf, pool_blocks, y)
+        return y
+
+    def se_gate_or_prologue(self, y: Act, pooled, fc1: nn.Module, fc2: nn.Module, consumer=None):
+        """The gate of an SE block whose stencil produced pool partial rows: ("pooled", pooled) where the project conv (``consumer`` =
+        (conv_c, has residual)) computes it in its own prologue, else the stand-alone gate launch's buffer."""
+        cse = fc1.out_channels
+        if consumer is not None:
+            cc, has_res = consumer
+            cop = round_up(cc.out_channels, 8)
+            dc = ConvDesc(N=y.N, Ti=y.T, Hi=y.H, Wi=y.W, Cin=y.C, Cin_p=y.Cp, To=y.T, Ho=y.H, Wo=y.W, Cout=cc.out_channels, Cout_p=cop,
+                          kt=1, kh=1, kw=1, st=1, sh=1, sw=1, pt=0, ph=0, pw=0, act=_lib.ACT["relu"], in_swish=1,
+                          w_kc=round_up(y.Cp, 16), w_rows=round_up(cop, 128))
+            if self.dtype == torch.bfloat16 and int(self.lib.pasn_conv3d_se_supported(ctypes.byref(dc), self.code, cse, int(has_res))):
+                return ("pooled", pooled)
+        return self.se_gate(pooled, fc1, fc2)
+
     def dwconv_se(self, x: Act, conv: nn.Module, norm: Optional[nn.Module], fc1: nn.Module, fc2: nn.Module, consumer=None):
         """Depthwise 3x3x3 conv + BN (no activation: the gate comes first) + the block's squeeze-excite gate in ONE launch where the
         T-marching stencil covers the layer (the clip's last-arriving block computes the gate); otherwise the stencil launch followed

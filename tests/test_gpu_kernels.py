@@ -446,6 +446,72 @@ def test_conv_with_fused_strided_shortcut(inner, cout, cin2, thw, gate, monkeypa
         assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
 
 
+@pytest.mark.parametrize("se", [False, True])
+@pytest.mark.parametrize("cin,cm,n,thw", [(24, 54, 2, (4, 16, 30)), (24, 108, 3, (5, 13, 17)), (24, 54, 2, (18, 12, 56)), (16, 40, 2, (3, 7, 9)),
+                                          (24, 54, 1, (2, 2, 3))])
+def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, se):
+    """Front half of an X3D stage's first block: 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 stride-(1,2,2) conv + BN (+ Swish, or the
+    squeeze-excite pool partial rows) in ONE launch with the expanded activation in LDS (pasn_x3d_expdw_fwd) -- against torch on the
+    bf16-rounded operands and against the two launches.  Even and odd planes (the last strided row / column exists or not), planes
+    smaller than a region, several regions and T chunks, two channel quads (108), channel counts that are not multiples of 16, T = 18
+    (chunked march), clips of 2 frames."""
+    dtype = torch.bfloat16
+    torch.manual_seed(cin + cm + n)
+    t, hi, wi = thw
+    x = torch.randn(n, cin, t, hi, wi)
+    conv_a = nn.Conv3d(cin, cm, 1, bias=False)
+    conv_b = nn.Conv3d(cm, cm, 3, (1, 2, 2), 1, groups=cm, bias=False)
+    bn_a, bn_b = nn.BatchNorm3d(cm), nn.BatchNorm3d(cm)
+    with torch.no_grad():
+        conv_b.weight.mul_(3.0)
+        for b in (bn_a, bn_b):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+            b.running_mean.normal_(0, 0.3)
+            b.running_var.uniform_(0.5, 1.5)
+    bn_a.eval(), bn_b.eval()
+    act_b = "none" if se else "swish"
+    e_ref = _rt(F.relu(bn_a(F.conv3d(_rt(x, dtype), _rt(conv_a.weight.data, dtype)))), dtype)
+    pre = bn_b(F.conv3d(e_ref, _rt(conv_b.weight.data, dtype), stride=(1, 2, 2), padding=1, groups=cm)).detach()
+    ref = pre if se else pre * torch.sigmoid(pre)
+    conv_a, conv_b, bn_a, bn_b = conv_a.to(DEV), conv_b.to(DEV), bn_a.to(DEV), bn_b.to(DEV)
+
+    def run(fused: bool):
+        pb = _pb(dtype)
+        xa, xs = _cl_input(pb, x, dtype)
+        if fused:
+            out = pb.expand_dw(xa, conv_a, bn_a, conv_b, bn_b, act_b, pool=se)
+            assert out is not None and pb.meta[-1]["kind"] == "expand+dwconv", "the fused launch must cover this pair"
+        else:
+            e = pb.conv(xa, conv_a, bn_a, act="relu")
+            out = pb.dwconv(e, conv_b, bn_b, act=act_b, pool=se)
+        y, pooled = out if se else (out, None)
+        if se:
+            pb.bufs[pooled[0]].external = True
+        plan = pb.finish(xa, y)
+        pool_t = None
+        if se:
+            pool_t = torch.full((n, pooled[1], y.Cp), float("nan"), dtype=torch.float32, device=DEV)
+            plan.ptrs[pooled[0]] = pool_t.data_ptr()
+        o = plan.run(xs)
+        torch.cuda.synchronize()
+        return o, pool_t, len(plan.ops)
+
+    out, pool_f, n_f = run(True)
+    two, pool_t, n_t = run(False)
+    assert n_f == 1 and n_t == 2
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, cm), ref, 3e-2 * scale, 2e-2, f"fused expand + stencil {cin}->{cm} {thw}")
+    assert_close(_from_cl(out, cm), _from_cl(two, cm), 1.6e-2 * scale, 1e-2, "fused vs the two launches")  # one bf16 ulp of the output
+    if out.shape[-1] > cm:
+        assert float(out[..., cm:].float().abs().max()) == 0.0, "padded channels must stay zero"
+    if se:  # the pool partial rows sum to the sum of the (pre-activation) output over positions
+        want = pre.double().sum(dim=(2, 3, 4))
+        got = pool_f.double().sum(dim=1)[:, :cm].cpu()
+        assert_close(got, want, 2e-2 * float(pre.abs().max()) * pre[0, 0].numel() ** 0.5 + 1e-3, 1e-2, "pool partial sums")
+        assert not torch.isnan(pool_f).any()
+
+
 @pytest.mark.parametrize("c,cout,cse,n,thw,stride", [(432, 192, 32, 3, (4, 7, 7), 1), (432, 192, 32, 2, (5, 14, 14), 2), (216, 96, 16, 3, (4, 9, 9), 1)])
 def test_project_conv_with_se_gate_in_its_prologue(c, cout, cse, n, thw, stride, monkeypatch):
     """X3D SE block back half: depthwise stencil (+BN, pool partial rows) -> project conv whose PROLOGUE computes the squeeze-excite gate from
