@@ -53,7 +53,7 @@ __device__ __forceinline__ void xe_wait_all_but(int n) {  // n wave-uniform
 __device__ __forceinline__ void xe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // KS: k-steps of the expand conv held in registers (K = block width <= 16 KS channels); ACT: the stencil's epilogue activation
-template <int KS, int ACT>
+template <int KS, int ACT, bool ABLB = false>  // ABLB: timing-only ablation instance (PASN_EXPDW_ABL; results are wrong when set)
 __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wa,
                                                            const float* __restrict__ sa, const float* __restrict__ ba,
                                                            const float* __restrict__ w, const float* __restrict__ scale,
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     const bool wave_live = c0 < Cp;
     const bool wave_tail = c0 + 16 > d.Cout;
     const int XS = g.XS, pieces = Cin_p >> 3;
+    const int abl = ABLB ? g.abl : 0;  // 1: no expand MFMAs, 2: no expand epilogue arithmetic, 4: no x DMA, 8: no stencil MFMAs, 16: no output epilogue / stores
 
     // ---- stencil: block-diagonal weight operands (dwmfma.hip) ----
     xe_u32x4 A[3][5];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
         auto staged = [&](int ti) -> bool { return ti >= 0 && ti < Ti && ti >= t0 - 1 && ti <= t1; };
         auto slot_of = [&](int ti) -> int { return (ti - (t0 - 1)) & 1; };
         auto issue_x = [&](int ti) {
-            if (!staged(ti)) return;
+            if (!staged(ti) || (abl & 4)) return;
             const unsigned foff = (unsigned)ti * fx_bytes;
             char* dst = xt + slot_of(ti) * g.xtb;
 #pragma unroll
@@ -177,7 +178,9 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (xe_lds_ptr_t)(dst + (wave + 4 * e) * 1024), 16, (int)goff[e], (int)foff, 0, 0);
         };
         const bool colin = c32 < XE_RW && (unsigned)(w0 * 2 - 1 + c32) < (unsigned)Wi;
-        // expand frame ti from its x tile into its ring image
+        const bool wedge = w0 == 0 || w0 * 2 - 1 + XE_RW > Wi;  // wave-uniform: the region touches the left / right image border
+        // expand frame ti from its x tile into its ring image.  (K columns beyond the block width carry zero WEIGHTS -- the packed rows
+        // are zero-padded to w_kc -- so the lanes that supply them read a real piece instead of selecting a zero fragment.)
         auto produce = [&](int ti) {
             if (!staged(ti)) return;
             const char* xb = xt + slot_of(ti) * g.xtb;
@@ -187,20 +190,26 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                 const int rr = (wave >> 1) + 2 * i;
                 if (rr >= XE_RH) break;  // wave-uniform
                 const bool inside = (unsigned)(h0 * 2 - 1 + rr) < (unsigned)Hi;  // wave-uniform
+                char* const rp = rb + ((rr * XE_RW + c32) * XE_SLOTS + 4 * ect + h32) * 16;
+                if (!inside) {  // a row of the zero padding
+                    if (c32 < XE_RW) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) *reinterpret_cast<uint4*>(rp + pr * 32) = uint4{0u, 0u, 0u, 0u};
+                    }
+                    continue;
+                }
+                const char* xp = xb + (rr * XE_RW + min(c32, XE_RW - 1)) * XS * 16;
                 f32x16 acc;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-                if (inside) {
-                    const char* xp = xb + (rr * XE_RW + min(c32, XE_RW - 1)) * XS * 16;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        const int piece = 2 * ks + h32;
-                        bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + min(piece, XS - 1) * 16);
-                        if (piece >= pieces) b = zero_frag<__bf16>();
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + min(2 * ks + h32, XS - 1) * 16);
+                    if (ks == 0) {
+                        const f32x16 z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        acc = (abl & 1) ? z : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[0], b, z, 0, 0, 0);
+                    } else if (!(abl & 1)) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], b, acc, 0, 0, 0);
                     }
                 }
-                const bool keep = inside && colin;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     float v[8];
@@ -211,9 +220,21 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                         v[4 + qq] = __uint_as_float(sw[1]);
                     }
                     bf16x8 o;
+                    if (abl & 2) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(keep ? fmaxf(v[e] * esc[pr][e] + ebs[pr][e], 0.0f) : 0.0f);
-                    if (c32 < XE_RW) *reinterpret_cast<bf16x8*>(rb + ((rr * XE_RW + c32) * XE_SLOTS + 4 * ect + 2 * pr + h32) * 16) = o;
+                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e & 1];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[pr][e] + ebs[pr][e], 0.0f);
+                    }
+                    xe_u32x4 ou = __builtin_bit_cast(xe_u32x4, o);
+                    if (wedge) {  // columns outside the image belong to the zero padding of the expanded activation
+                        ou.x = colin ? ou.x : 0u;
+                        ou.y = colin ? ou.y : 0u;
+                        ou.z = colin ? ou.z : 0u;
+                        ou.w = colin ? ou.w : 0u;
+                    }
+                    if (c32 < XE_RW) *reinterpret_cast<xe_u32x4*>(rp + pr * 32) = ou;
                 }
             }
         };
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
         const unsigned yvoff = lane_ok ? (unsigned)(((h0 * d.Wo + w0 + m) * Cp + ce) * 2) : XE_OOB;
         const unsigned fr_bytes = (unsigned)(ofs * 2);
         const int kst = wave_live ? ntl : 0;
-        auto stored = [&](int to) -> int { return (to >= t0 && to < t1) ? kst : 0; };
+        auto stored = [&](int to) -> int { return (to >= t0 && to < t1 && !(abl & 16)) ? kst : 0; };
 
         f32x4 S0[XE_NT], S1[XE_NT], S2[XE_NT];
         const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
         for (int l = 0; l < XE_NT; ++l) S0[l] = S1[l] = S2[l] = zero4;
 
         auto frame = [&](int ti, f32x4 (&P)[XE_NT], f32x4 (&C)[XE_NT], f32x4 (&N)[XE_NT]) {
-            if (wave_live && ti >= 0 && ti < Ti) {  // wave-uniform
+            if (wave_live && ti >= 0 && ti < Ti && !(abl & 8)) {  // wave-uniform
                 int fbo = slot_of(ti) * XE_FRB + lbase0;
                 asm volatile("" : "+v"(fbo));
                 const char* ta[5];
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                 }
             }
             const int to = ti - 1;
-            if (wave_live && to >= t0 && to < t1) {
+            if (wave_live && to >= t0 && to < t1 && !(abl & 16)) {
                 const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yclip + (long)to * ofs, 0, fr_bytes, 0x00020000);
 #pragma unroll
                 for (int l = 0; l < XE_NT; ++l)
@@ -386,6 +407,7 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
         if (force_tc || tc <= 4) break;
     }
     g.bpc = g.CQ * g.chunks;
+    g.abl = getenv("PASN_EXPDW_ABL") ? atoi(getenv("PASN_EXPDW_ABL")) : 0;
     g.ok = 1;
     return g;
 }
@@ -405,7 +427,11 @@ int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float
         else if (d.act == PASN_ACT_SWISH) PASN_XE(KS_, PASN_ACT_SWISH); \
         else PASN_XE(KS_, -1);                                         \
     } while (0)
-    if (g.KS == 2) PASN_XEK(2);
+    if (g.abl) {
+        PASN_MAX_LDS(96 * 1024, x3d_expdw_kernel<2, -1, true>);
+        hipLaunchKernelGGL((x3d_expdw_kernel<2, -1, true>), grid, block, (size_t)g.lds, s, (const __bf16*)x, (const __bf16*)wa, sa, ba, w, scale, bias,
+                           (__bf16*)y, pool, d, de.Cin_p, de.w_kc / 16, g);
+    } else if (g.KS == 2) PASN_XEK(2);
     else PASN_XEK(3);
 #undef PASN_XEK
 #undef PASN_XE
