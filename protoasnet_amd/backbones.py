@@ -288,7 +288,7 @@ class X3DFeatures(_plan.HipTrunk):
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
                 act_b = "none" if blk.se is not None else "swish"  # no gate between BN and Swish: the stencil applies Swish
                 gate = None
-                # first block of a stage: expand conv + strided stencil in one launch, the expanded activation never leaves LDS
+                # expand conv + stencil in one launch where the pair is covered (block width <= 48): the expanded activation never leaves LDS
                 front = pb.expand_dw(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, act_b, pool=blk.se is not None) if pre is None else None
                 if front is not None:
                     if blk.se is not None:

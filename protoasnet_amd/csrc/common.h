@@ -139,10 +139,10 @@ struct DwMfmaGeom {
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
                    const DwMfmaGeom& g, hipStream_t s);
-// x3d_expdw.hip: expand conv (1x1x1 + BN + ReLU) -> depthwise 3x3x3 stride-(1,2,2) stencil (+BN, act, SE partial sums) in one launch, both on
+// x3d_expdw.hip: expand conv (1x1x1 + BN + ReLU) -> depthwise 3x3x3 stride-(1,s,s) stencil, s = 1 or 2, (+BN, act, SE partial sums) in one launch, both on
 // the matrix cores, the expanded activation only ever in LDS (the first block of an X3D stage); ok = 0: not covered
 struct XeGeom {
-    int ok, KS, XS, xtb, lds;       // expand k-steps in registers, 16-byte slots per staged x position (odd), bytes per x tile, dynamic LDS
+    int ok, SS, KS, XS, xtb, lds;   // stride, expand k-steps in registers, 16-byte slots per staged x position (odd), bytes per x tile, dynamic LDS
     int CQ, RTH, RTW;               // 64-channel quads, regions (3 x 14 outputs) per frame
     int Tc, nT, upb, chunks, bpc;   // T chunk (+count), units per block, SE partial rows per clip, blocks per clip
     int abl;                        // timing ablations (PASN_EXPDW_ABL; results are wrong when set)

@@ -28,14 +28,22 @@ typedef __attribute__((ext_vector_type(4))) unsigned xe_u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned xe_u32x2;
 typedef __attribute__((address_space(3))) void* xe_lds_ptr_t;
 
-constexpr int XE_NT = 3;                    // output rows of a region = 16-lane position tiles per wave
-constexpr int XE_BW = 14;                   // output columns of a region
-constexpr int XE_RW = (XE_BW - 1) * 2 + 3;  // 29 staged columns
-constexpr int XE_RH = (XE_NT - 1) * 2 + 3;  // 7 staged rows
-constexpr int XE_POS = XE_RH * XE_RW;       // 203 staged positions per frame
-constexpr int XE_SLOTS = 9;                 // 16-byte slots per staged position (8 used): 2 * 9 = 2 (mod 4), see dwmfma.hip
-constexpr int XE_FRB = (XE_POS * XE_SLOTS * 16 + 1023) / 1024 * 1024;  // bytes per frame image
-constexpr int XE_NE = 6;                    // x DMA instructions per wave and frame, at most (203 positions x <= 7 slots)
+// Region geometry per stride.  Stride 2: 3 x 14 outputs from 7 x 29 staged positions, an expand MFMA tile = one staged row (29 of 32
+// lanes), 9 slots per position.  Stride 1: 6 x 14 outputs from 8 x 16 staged positions = exactly four 32-position MFMA tiles (two staged
+// rows each), 10 slots per position (the slot counts are dwmfma.hip's bank rule: stride x slots = 2 mod 4).
+template <int SS>
+struct XeR {
+    static constexpr int NT = SS == 2 ? 3 : 6;                  // output rows of a region = 16-lane position tiles per wave
+    static constexpr int BW = 14;                               // output columns of a region
+    static constexpr int RW = (BW - 1) * SS + 3;                // staged columns: 29 / 16
+    static constexpr int RH = (NT - 1) * SS + 3;                // staged rows: 7 / 8
+    static constexpr int POS = RH * RW;                         // staged positions per frame: 203 / 128
+    static constexpr int SLOTS = SS == 2 ? 9 : 10;              // 16-byte slots per staged position (8 used)
+    static constexpr int FRB = (POS * SLOTS * 16 + 1023) / 1024 * 1024;  // bytes per frame image
+    static constexpr int TP = SS == 2 ? RW : 32;                // staged positions per expand tile (stride 2: a row; stride 1: two rows)
+    static constexpr int TILES = SS == 2 ? RH : POS / 32;       // expand tiles per frame: 7 / 4
+};
+constexpr int XE_NE = 6;  // x DMA instructions per wave and frame, at most (203 positions x <= 7 slots)
 constexpr unsigned XE_OOB = 0x80000000u;
 
 __device__ __forceinline__ unsigned xe_bf16_bits(float f) {
@@ -47,18 +55,23 @@ __device__ __forceinline__ void xe_wait_all_but(int n) {  // n wave-uniform
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;  // n <= XE_NT
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;  // n <= NT <= 6
     }
 }
 __device__ __forceinline__ void xe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // KS: k-steps of the expand conv held in registers (K = block width <= 16 KS channels); ACT: the stencil's epilogue activation
-template <int KS, int ACT, bool ABLB = false>  // ABLB: timing-only ablation instance (PASN_EXPDW_ABL; results are wrong when set)
+template <int KS, int ACT, int SS, bool ABLB = false>  // ABLB: timing-only ablation instance (PASN_EXPDW_ABL; results are wrong when set)
 __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wa,
                                                            const float* __restrict__ sa, const float* __restrict__ ba,
                                                            const float* __restrict__ w, const float* __restrict__ scale,
                                                            const float* __restrict__ bias, __bf16* __restrict__ y, float* __restrict__ pool,
                                                            pasn_conv_desc d, int Cin_p, int nks, XeGeom g) {
+    using R = XeR<SS>;
+    constexpr int XE_NT = R::NT, XE_BW = R::BW, XE_RW = R::RW, XE_RH = R::RH, XE_POS = R::POS, XE_SLOTS = R::SLOTS, XE_FRB = R::FRB;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const ring = smem;                                          // [2][XE_FRB] expanded frames
     char* const xt = smem + 2 * XE_FRB;                               // [2][g.xtb] x rows of the region: [position][XS slots]
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     }
     float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    // ---- expand conv: this wave's 32-channel tile (ct = wave & 1 of the quad) for the staged rows rr = (wave >> 1) + 2 i ----
+    // ---- expand conv: this wave's 32-channel tile (ct = wave & 1 of the quad) for the expand tiles (wave >> 1) + 2 i of every frame ----
     const int ect = wave & 1;
     const int ectiles = (Cp + 31) >> 5;
     bf16x8 AE[KS];
@@ -126,13 +139,6 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
         scb[64 + threadIdx.x] = ch < Cp ? ba[ch] : 0.0f;
     }
     __syncthreads();
-    float esc[2][8], ebs[2][8];  // this lane's 8 channels per register pair, after the lane swap: 32 ect + 16 pr + 8 h32 ..
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-        load8(scb + 32 * ect + 16 * pr + 8 * h32, esc[pr]);
-        load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs[pr]);
-    }
-
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     const long fx = (long)Hi * Wi * Cin_p;  // elements per x frame
     const unsigned fx_bytes = (unsigned)(fx * 2);
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
             const int slot = (wave + 4 * e) * 64 + lane;
             const int rp = slot / XS, p = slot - rp * XS;
             const int rr = rp / XE_RW, cc = rp - rr * XE_RW;
-            const int hi = h0 * 2 - 1 + rr, wi = w0 * 2 - 1 + cc;
+            const int hi = h0 * SS - 1 + rr, wi = w0 * SS - 1 + cc;
             const bool ok = wave + 4 * e < nix && rp < XE_POS && p < pieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
             goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cin_p + p * 8) * 2) : XE_OOB;
         }
@@ -177,8 +183,22 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                 if (wave + 4 * e < nix)  // wave-uniform
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (xe_lds_ptr_t)(dst + (wave + 4 * e) * 1024), 16, (int)goff[e], (int)foff, 0, 0);
         };
-        const bool colin = c32 < XE_RW && (unsigned)(w0 * 2 - 1 + c32) < (unsigned)Wi;
-        const bool wedge = w0 == 0 || w0 * 2 - 1 + XE_RW > Wi;  // wave-uniform: the region touches the left / right image border
+        // this lane's staged position inside expand tile i of a frame: stride 2: (row tile, column c32 < 29); stride 1: (row 2 tile + c32 / 16,
+        // column c32 % 16).  keepm bit i: the position lies inside the image (the stencil pads the EXPANDED activation with zeros)
+        constexpr int NU = (R::TILES + 1) / 2;  // expand tiles per wave, at most
+        const bool lane_used = c32 < R::TP;
+        unsigned keepm = 0;
+        bool all_in = true, any_in[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int tile = (wave >> 1) + 2 * i;
+            const int rr = SS == 2 ? tile : 2 * tile + (c32 >> 4), cc = SS == 2 ? c32 : (c32 & 15);
+            const bool in = (unsigned)(h0 * SS - 1 + rr) < (unsigned)Hi && (unsigned)(w0 * SS - 1 + cc) < (unsigned)Wi && cc < XE_RW;
+            keepm |= in ? (1u << i) : 0u;
+            const bool lane_counts = lane_used && tile < R::TILES;
+            all_in = all_in && (__ballot(lane_counts && !in) == 0);
+            any_in[i] = __ballot(lane_counts && in) != 0;
+        }
         // expand frame ti from its x tile into its ring image.  (K columns beyond the block width carry zero WEIGHTS -- the packed rows
         // are zero-padded to w_kc -- so the lanes that supply them read a real piece instead of selecting a zero fragment.)
         auto produce = [&](int ti) {
@@ -186,19 +206,19 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
             const char* xb = xt + slot_of(ti) * g.xtb;
             char* rb = ring + slot_of(ti) * XE_FRB;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rr = (wave >> 1) + 2 * i;
-                if (rr >= XE_RH) break;  // wave-uniform
-                const bool inside = (unsigned)(h0 * 2 - 1 + rr) < (unsigned)Hi;  // wave-uniform
-                char* const rp = rb + ((rr * XE_RW + c32) * XE_SLOTS + 4 * ect + h32) * 16;
-                if (!inside) {  // a row of the zero padding
-                    if (c32 < XE_RW) {
+            for (int i = 0; i < NU; ++i) {
+                const int tile = (wave >> 1) + 2 * i;
+                if (tile >= R::TILES) break;  // wave-uniform
+                const int pos = tile * R::TP + min(c32, R::TP - 1);
+                char* const rp = rb + (pos * XE_SLOTS + 4 * ect + h32) * 16;
+                if (!any_in[i]) {  // wave-uniform: a tile of the zero padding
+                    if (lane_used) {
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) *reinterpret_cast<uint4*>(rp + pr * 32) = uint4{0u, 0u, 0u, 0u};
                     }
                     continue;
                 }
-                const char* xp = xb + (rr * XE_RW + min(c32, XE_RW - 1)) * XS * 16;
+                const char* xp = xb + pos * XS * 16;
                 f32x16 acc;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -210,9 +230,12 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], b, acc, 0, 0, 0);
                     }
                 }
+                const bool keep = (keepm >> i) & 1u;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    float v[8];
+                    float v[8], esc[8], ebs[8];
+                    load8(scb + 32 * ect + 16 * pr + 8 * h32, esc);  // this lane's 8 channels after the lane swap: 32 ect + 16 pr + 8 h32 ..
+                    load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs);
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * pr + qq]), __float_as_uint(acc[8 * pr + 4 + qq]), false, false);
@@ -225,26 +248,26 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                         for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e & 1];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[pr][e] + ebs[pr][e], 0.0f);
+                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[e] + ebs[e], 0.0f);
                     }
                     xe_u32x4 ou = __builtin_bit_cast(xe_u32x4, o);
-                    if (wedge) {  // columns outside the image belong to the zero padding of the expanded activation
-                        ou.x = colin ? ou.x : 0u;
-                        ou.y = colin ? ou.y : 0u;
-                        ou.z = colin ? ou.z : 0u;
-                        ou.w = colin ? ou.w : 0u;
+                    if (!all_in) {  // wave-uniform: only regions on the image border select
+                        ou.x = keep ? ou.x : 0u;
+                        ou.y = keep ? ou.y : 0u;
+                        ou.z = keep ? ou.z : 0u;
+                        ou.w = keep ? ou.w : 0u;
                     }
-                    if (c32 < XE_RW) *reinterpret_cast<xe_u32x4*>(rp + pr * 32) = ou;
+                    if (lane_used) *reinterpret_cast<xe_u32x4*>(rp + pr * 32) = ou;
                 }
             }
         };
 
-        // ---- stencil roles (dwmfma.hip with SS = 2, one output row per tile) ----
+        // ---- stencil roles (dwmfma.hip, one output row per tile) ----
         const bool lane_ok = m < XE_BW && w0 + m < d.Wo && cev;
         const int rows_valid = min(XE_NT, d.Ho - h0);
         const int ntl = rows_valid;
-        const int lbase0 = ((min(m, XE_BW - 1) * 2) * XE_SLOTS + 2 * wave + (q & 1)) * 16;
-        constexpr int lstep = 2 * XE_RW * XE_SLOTS * 16;
+        const int lbase0 = ((min(m, XE_BW - 1) * SS) * XE_SLOTS + 2 * wave + (q & 1)) * 16;
+        constexpr int lstep = SS * XE_RW * XE_SLOTS * 16;
         const int ystep = d.Wo * Cp;
         __bf16* yclip = y + (long)n * d.To * d.Ho * d.Wo * Cp;
         const long ofs = (long)d.Ho * d.Wo * Cp;
@@ -358,14 +381,21 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------------------
-// de = the expand conv (1x1x1, stride 1, + BN + ReLU), d = the depthwise conv (3x3x3, stride (1,2,2), pad 1) on its output.
+// de = the expand conv (1x1x1, stride 1, + BN + ReLU), d = the depthwise conv (3x3x3, stride (1,s,s), s = 1 or 2, pad 1) on its output.
 XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     XeGeom g{};
-    if (const char* e = getenv("PASN_EXPDW"))
-        if (e[0] == '0') return g;
+    const char* mode = getenv("PASN_EXPDW");  // 0: off
+    if (mode && mode[0] == '0') return g;
     if (dtype != PASN_BF16) return g;
-    const bool dw = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 2 && d.sw == 2 && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
-                    d.To == d.Ti && d.Ho == (d.Hi - 1) / 2 + 1 && d.Wo == (d.Wi - 1) / 2 + 1 && d.Cin_p == d.Cout_p && d.Cin == d.Cout &&
+    const int ss = d.sh;
+    // Stride 2 only.  The stride-1 instance (XeR<1>: 6 x 14 outputs from 8 x 16 staged positions = four 32-position expand tiles) was built,
+    // passed the same parity test and LOST: 169 / 148 us against 54 + 114 / 55 + 107 for the two launches at 56 x 56, 106 / 94 against
+    // 28 + 60 / 28 + 52 at 28 x 28; 10.34 k vs 10.58 k clips/s end to end (profiles/README.md entry 74).  At stride 1 the expanded tensor is
+    // no larger than the stencil's output, the unfused pair is not bound by its bytes, and the expand epilogue's ~3 vector instructions per
+    // element land on a kernel that is already bound by vector issue.
+    if (ss != 2) return g;
+    const bool dw = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sw == ss && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
+                    d.To == d.Ti && d.Ho == (d.Hi - 1) / ss + 1 && d.Wo == (d.Wi - 1) / ss + 1 && d.Cin_p == d.Cout_p && d.Cin == d.Cout &&
                     d.Cout_p % 8 == 0;
     const bool ex = de.kt == 1 && de.kh == 1 && de.kw == 1 && !de.pt && !de.ph && !de.pw && de.st == 1 && de.sh == 1 && de.sw == 1 &&
                     !de.in_swish && de.act == PASN_ACT_RELU && de.N == d.N && de.To == d.Ti && de.Ho == d.Hi && de.Wo == d.Wi &&
@@ -373,16 +403,20 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
                     de.Cin_p % 8 == 0 && de.w_rows >= ((de.Cout_p + 31) / 32) * 32;
     if (!dw || !ex) return g;
     const int nks = de.w_kc / 16;
-    if (nks > 3) return g;  // K <= 48: the x tiles of two frames fit beside the ring
+    if (nks > 2) return g;  // (the LDS check below admits block widths up to 24 channels: three 16-byte pieces per staged x position)
     if ((long)d.Ti * d.Hi * d.Wi * de.Cin_p * 2 >= (1L << 31) || (long)d.To * d.Ho * d.Wo * d.Cout_p * 2 >= (1L << 31)) return g;
-    g.KS = nks <= 2 ? 2 : 3;
+    const int NT = ss == 2 ? XeR<2>::NT : XeR<1>::NT, POS = ss == 2 ? XeR<2>::POS : XeR<1>::POS, FRB = ss == 2 ? XeR<2>::FRB : XeR<1>::FRB;
+    g.SS = ss;
+    g.KS = 2;
     g.XS = (de.Cin_p / 8) | 1;
-    g.xtb = ((XE_POS + 3) * g.XS * 16 + 1023) / 1024 * 1024;  // + 3 positions: lanes 29 .. 31 of the last staged row read past it
-    g.lds = 2 * XE_FRB + 2 * g.xtb + 512;
-    if (g.lds > 80 * 1024 || (XE_POS * g.XS + 63) / 64 > 4 * XE_NE) return XeGeom{};
+    g.xtb = ((POS + 3) * g.XS * 16 + 1023) / 1024 * 1024;  // + 3 positions: lanes 29 .. 31 of the last staged row read past it (stride 2)
+    g.lds = 2 * FRB + 2 * g.xtb + 512;
+    // two blocks per CU: block width 24 takes 78.5 KB.  (48 channels -- stage 4's first block -- need 107 KB = one block per CU: built,
+    // correct, and slower end to end, 10.37 k vs 10.58 k clips/s: not taken.)
+    if (g.lds > 80 * 1024 || (POS * g.XS + 63) / 64 > 4 * XE_NE) return XeGeom{};
     g.CQ = ceil_div(ceil_div(d.Cout_p, 16), 4);
-    g.RTH = ceil_div(d.Ho, XE_NT);
-    g.RTW = ceil_div(d.Wo, XE_BW);
+    g.RTH = ceil_div(d.Ho, NT);
+    g.RTW = ceil_div(d.Wo, XeR<1>::BW);
     const int regions = g.RTH * g.RTW;
     const int force_tc = getenv("PASN_EXPDW_TC") ? atoi(getenv("PASN_EXPDW_TC")) : 0;
     const int force_upb = getenv("PASN_EXPDW_UPB") ? atoi(getenv("PASN_EXPDW_UPB")) : 0;
@@ -393,7 +427,7 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
         for (int upb = 1; upb <= units; ++upb) {
             if (force_upb && upb != std::min(force_upb, units)) continue;
             const int chunks = ceil_div(units, upb);
-            if (chunks > 64 && upb < units && !force_upb) continue;  // the chunk count is the number of SE partial rows per clip
+            if (chunks > 64 && upb < units && !force_upb) continue;  // the chunk count is the number of SE partial rows per clip (128: 209 vs 195 us per launch)
             const long blocks = (long)d.N * g.CQ * chunks;
             const double t = (double)ceil_div(blocks, 512L) * (4.0 + upb * (tcu + 3.0));
             if (t < best) {
@@ -415,24 +449,21 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
 int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
                      void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s) {
     const dim3 grid((unsigned)(g.bpc * d.N)), block(256);
-#define PASN_XE(KS_, ACT_)                                                                                                       \
+#define PASN_XE(KS_, ACT_, SS_, ABL_)                                                                                             \
     do {                                                                                                                         \
-        PASN_MAX_LDS(96 * 1024, x3d_expdw_kernel<KS_, ACT_>);                                                                    \
-        hipLaunchKernelGGL((x3d_expdw_kernel<KS_, ACT_>), grid, block, (size_t)g.lds, s, (const __bf16*)x, (const __bf16*)wa, sa, ba, w,   \
-                           scale, bias, (__bf16*)y, pool, d, de.Cin_p, de.w_kc / 16, g);                                         \
+        PASN_MAX_LDS(96 * 1024, x3d_expdw_kernel<KS_, ACT_, SS_, ABL_>);                                                         \
+        hipLaunchKernelGGL((x3d_expdw_kernel<KS_, ACT_, SS_, ABL_>), grid, block, (size_t)g.lds, s, (const __bf16*)x, (const __bf16*)wa, sa, \
+                           ba, w, scale, bias, (__bf16*)y, pool, d, de.Cin_p, de.w_kc / 16, g);                                  \
     } while (0)
-#define PASN_XEK(KS_)                                                  \
-    do {                                                               \
-        if (d.act == PASN_ACT_NONE) PASN_XE(KS_, PASN_ACT_NONE);       \
-        else if (d.act == PASN_ACT_SWISH) PASN_XE(KS_, PASN_ACT_SWISH); \
-        else PASN_XE(KS_, -1);                                         \
+#define PASN_XEK(KS_, SS_)                                                          \
+    do {                                                                            \
+        if (d.act == PASN_ACT_NONE) PASN_XE(KS_, PASN_ACT_NONE, SS_, false);        \
+        else if (d.act == PASN_ACT_SWISH) PASN_XE(KS_, PASN_ACT_SWISH, SS_, false); \
+        else PASN_XE(KS_, -1, SS_, false);                                          \
     } while (0)
-    if (g.abl) {
-        PASN_MAX_LDS(96 * 1024, x3d_expdw_kernel<2, -1, true>);
-        hipLaunchKernelGGL((x3d_expdw_kernel<2, -1, true>), grid, block, (size_t)g.lds, s, (const __bf16*)x, (const __bf16*)wa, sa, ba, w, scale, bias,
-                           (__bf16*)y, pool, d, de.Cin_p, de.w_kc / 16, g);
-    } else if (g.KS == 2) PASN_XEK(2);
-    else PASN_XEK(3);
+    PASN_REQUIRE(g.SS == 2, "x3d_expdw: stride-2 instances only");
+    if (g.abl) PASN_XE(2, -1, 2, true);
+    else PASN_XEK(2, 2);
 #undef PASN_XEK
 #undef PASN_XE
     return check_launch("x3d_expdw_kernel");

@@ -533,8 +533,8 @@ class PlanBuilder:
 
     def expand_dw(self, x: Act, conv_a: nn.Module, norm_a: Optional[nn.Module], conv_b: nn.Module, norm_b: Optional[nn.Module], act_b: str,
                   pool: bool = False):
-        """Front half of an X3D stage's first block in ONE launch (``pasn_x3d_expdw_fwd``): 1x1x1 expand conv + BN + ReLU -> depthwise
-        3x3x3 stride-(1,2,2) conv + BN (+ ``act_b``, + squeeze-excite pool partial rows); the expanded activation stays in LDS.
+        """Front half of an X3D block in ONE launch (``pasn_x3d_expdw_fwd``): 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 conv,
+        stride (1,s,s) with s = 1 or 2, + BN (+ ``act_b``, + squeeze-excite pool partial rows); the expanded activation stays in LDS.
         Returns y (or (y, pooled) with ``pool``), or None when the pair is not covered (the caller emits the two launches)."""
         if x.planar or self.dtype != torch.bfloat16 or conv_a.groups != 1 or conv_b.groups != conv_b.in_channels:
             return None
@@ -542,14 +542,14 @@ class PlanBuilder:
         if _triple(conv_a.kernel_size, 1) != one or _triple(conv_a.stride, 1) != one or _triple(conv_a.padding, 0) != zero:
             return None
         k, s, p = _triple(conv_b.kernel_size, 1), _triple(conv_b.stride, 1), _triple(conv_b.padding, 0)
-        if k != (3, 3, 3) or s != (1, 2, 2) or p != (1, 1, 1) or conv_b.in_channels != conv_a.out_channels:
+        if k != (3, 3, 3) or s != (1, 2, 2) or p != (1, 1, 1) or conv_b.in_channels != conv_a.out_channels:  # (stride 1: measured slower)
             return None
         cm = conv_a.out_channels
         mid = Act(x.N, x.T, x.H, x.W, cm, round_up(cm, 8), -1)  # the expanded activation: never materialised
         wa, kca, rowsa = pack_conv_weight(conv_a.weight, x.Cp, self.dtype)
         de = self._desc(x, mid, one, one, zero, "relu", False, kca, rowsa)
-        probe = ConvDesc(N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=cm, Cin_p=mid.Cp, To=x.T, Ho=(x.H - 1) // 2 + 1, Wo=(x.W - 1) // 2 + 1, Cout=cm,
-                         Cout_p=mid.Cp, kt=3, kh=3, kw=3, st=1, sh=2, sw=2, pt=1, ph=1, pw=1, act=_lib.ACT[act_b])
+        probe = ConvDesc(N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=cm, Cin_p=mid.Cp, To=x.T, Ho=(x.H - 1) // s[1] + 1, Wo=(x.W - 1) // s[2] + 1, Cout=cm,
+                         Cout_p=mid.Cp, kt=3, kh=3, kw=3, st=1, sh=s[1], sw=s[2], pt=1, ph=1, pw=1, act=_lib.ACT[act_b])
         if not int(self.lib.pasn_x3d_expdw_supported(ctypes.byref(de), ctypes.byref(probe), self.code)):
             return None
         y = self._out_act(mid, cm, k, s, p)
@@ -571,10 +571,10 @@ class PlanBuilder:
         self._use(xb, yb, pb_)
         in_pos, out_pos = x.N * x.positions, y.N * y.positions
         actc = _lib.ACT[act_b]
-        self._note("expand+dwconv", f"x3d_expdw_kernel<{2 if kca // 16 <= 2 else 3},{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1}>",
+        self._note("expand+dwconv", f"x3d_expdw_kernel<{2 if kca // 16 <= 2 else 3},{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1},{s[1]}>",
                    (in_pos * x.C + out_pos * y.C + cm * x.C) * self.es + (y.N * pool_blocks * y.C * 4 if pool else 0),
                    2 * in_pos * cm * x.C + 2 * out_pos * y.C * 27)
-        self.meta[-1]["shape"] = f"{x.C}->{cm} k111 + dw k333 s122 in{x.T}x{x.H}x{x.W} out{y.T}x{y.H}x{y.W}"
+        self.meta[-1]["shape"] = f"{x.C}->{cm} k111 + dw k333 s1{s[1]}{s[2]} in{x.T}x{x.H}x{x.W} out{y.T}x{y.H}x{y.W}"
         self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], a[4], a[5], ptrs[yb],
                                                        ptrs[pb_] if pb_ is not None else 0, re_, rd_, code, st)))
         if pool:

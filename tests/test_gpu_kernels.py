@@ -447,20 +447,20 @@ def test_conv_with_fused_strided_shortcut(inner, cout, cin2, thw, gate, monkeypa
 
 
 @pytest.mark.parametrize("se", [False, True])
-@pytest.mark.parametrize("cin,cm,n,thw", [(24, 54, 2, (4, 16, 30)), (24, 108, 3, (5, 13, 17)), (24, 54, 2, (18, 12, 56)), (16, 40, 2, (3, 7, 9)),
-                                          (24, 54, 1, (2, 2, 3))])
-def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, se):
-    """Front half of an X3D stage's first block: 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 stride-(1,2,2) conv + BN (+ Swish, or the
-    squeeze-excite pool partial rows) in ONE launch with the expanded activation in LDS (pasn_x3d_expdw_fwd) -- against torch on the
+@pytest.mark.parametrize("cin,cm,n,thw,stride", [(24, 54, 2, (4, 16, 30), 2), (24, 108, 3, (5, 13, 17), 2), (24, 54, 2, (18, 12, 56), 2),
+                                                 (16, 40, 2, (3, 7, 9), 2), (24, 54, 1, (2, 2, 3), 2), (8, 72, 2, (3, 11, 16), 2)])
+def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, stride, se):
+    """Front half of an X3D stage's first block: 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 conv, stride (1,2,2), + BN (+ Swish, or
+    the squeeze-excite pool partial rows) in ONE launch with the expanded activation in LDS (pasn_x3d_expdw_fwd) -- against torch on the
     bf16-rounded operands and against the two launches.  Even and odd planes (the last strided row / column exists or not), planes
-    smaller than a region, several regions and T chunks, two channel quads (108), channel counts that are not multiples of 16, T = 18
-    (chunked march), clips of 2 frames."""
+    smaller than a region, several regions and T chunks, two channel quads (108), block widths of 8 / 16 / 24 channels, channel counts
+    that are not multiples of 16, T = 18 (chunked march), clips of 2 frames."""
     dtype = torch.bfloat16
     torch.manual_seed(cin + cm + n)
     t, hi, wi = thw
     x = torch.randn(n, cin, t, hi, wi)
     conv_a = nn.Conv3d(cin, cm, 1, bias=False)
-    conv_b = nn.Conv3d(cm, cm, 3, (1, 2, 2), 1, groups=cm, bias=False)
+    conv_b = nn.Conv3d(cm, cm, 3, (1, stride, stride), 1, groups=cm, bias=False)
     bn_a, bn_b = nn.BatchNorm3d(cm), nn.BatchNorm3d(cm)
     with torch.no_grad():
         conv_b.weight.mul_(3.0)
@@ -472,7 +472,7 @@ def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, se):
     bn_a.eval(), bn_b.eval()
     act_b = "none" if se else "swish"
     e_ref = _rt(F.relu(bn_a(F.conv3d(_rt(x, dtype), _rt(conv_a.weight.data, dtype)))), dtype)
-    pre = bn_b(F.conv3d(e_ref, _rt(conv_b.weight.data, dtype), stride=(1, 2, 2), padding=1, groups=cm)).detach()
+    pre = bn_b(F.conv3d(e_ref, _rt(conv_b.weight.data, dtype), stride=(1, stride, stride), padding=1, groups=cm)).detach()
     ref = pre if se else pre * torch.sigmoid(pre)
     conv_a, conv_b, bn_a, bn_b = conv_a.to(DEV), conv_b.to(DEV), bn_a.to(DEV), bn_b.to(DEV)
 

@@ -309,10 +309,13 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
         m0.cnn_backbone(x)
     meta0 = m0.cnn_backbone.plan_for(x).meta
     n_prologue = len([k for k in meta0 if k["kind"] in ("conv+se", "conv_pair+se")])
-    assert len([k for k in meta0 if k["kind"] == "dwconv+se"]) == 5 and len([k for k in meta0 if k["kernel"].startswith("se_gate")]) + n_prologue == 10
+    # (the first blocks of stages 2 and 3 run expand conv + stencil as one launch, x3d_expdw.hip, followed by a stand-alone gate)
+    assert len([k for k in meta0 if k["kind"] == "expand+dwconv"]) == 2
+    assert len([k for k in meta0 if k["kind"] == "dwconv+se"]) == 3 and len([k for k in meta0 if k["kernel"].startswith("se_gate")]) + n_prologue == 12
     if shape[2:] == (16, 160, 160):
         assert n_prologue == 10, n_prologue  # both wide stages: no stand-alone gate launch left
-    monkeypatch.setenv("PASN_SE_FUSE_MAXC", "1024")  # the mechanism itself: every SE layer fused
+    monkeypatch.setenv("PASN_EXPDW", "0")  # the mechanism itself: every SE layer on the stencil launch with the fused gate
+    monkeypatch.setenv("PASN_SE_FUSE_MAXC", "1024")
     m = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
     with torch.no_grad():
         runs = [m.cnn_backbone(x).float().clone() for _ in range(6)]
