@@ -273,9 +273,16 @@ def main():
                 "mfma_tflops": round(tflops, 2),
             }
         result["kernel_ms_per_step"] = kernel_ms
+    # Two byte counts for the whole step.  "bytes_per_clip" is what the launches of THIS build move algorithmically (a fused launch counts
+    # its own inputs and outputs only).  "layerwise_bytes_per_clip" is SURVEY section 8(d)'s accounting -- every layer's input and output
+    # once, norm / activation fused, residual read once -- i.e. the same plan compiled with every cross-layer fusion switched off; it does
+    # not move when a fusion removes traffic, so it is the figure the throughput can be compared against across rounds.
+    layerwise = _layerwise_bytes(trunk, x, dtype)
     result["trunk_algorithmic"] = {
         "bytes_per_clip": int(total_bytes / args.batch), "flops_per_clip": int(total_flops / args.batch),
         "hbm_frac_whole_step": round(total_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        "layerwise_bytes_per_clip": int(layerwise / args.batch) if layerwise else None,
+        "hbm_frac_whole_step_layerwise": round(layerwise * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4) if layerwise else None,
         "arena_bytes": plan.arena_bytes,
     }
 
@@ -317,6 +324,32 @@ def main():
     print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+_UNFUSED = {"PASN_EXPDW": "0", "PASN_NO_XPAIR": "1", "PASN_WSPAIR": "0", "PASN_NO_SHORTFUSE": "1", "PASN_NO_SE_PROLOGUE": "1",
+            "PASN_NO_SE_FUSE": "1"}
+
+
+def _layerwise_bytes(trunk, x, dtype):
+    """Algorithmic bytes of one batch through the trunk with every cross-layer fusion off (plan compiled, never run): SURVEY 8(d)'s
+    per-layer accounting.  None for trunks without a plan builder."""
+    from protoasnet_amd.plan import PlanBuilder
+
+    if not hasattr(trunk, "build_plan"):
+        return None
+    saved = {k: os.environ.get(k) for k in _UNFUSED}
+    try:
+        os.environ.update(_UNFUSED)
+        pb = PlanBuilder(x.device, dtype, dtype)
+        x_in = pb.input(tuple(x.shape))
+        pb.finish(x_in, trunk.build_plan(pb, x_in))
+        return float(sum(m["bytes"] for m in pb.meta))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _kernel_roofline(trunk, step, plan, dtype_name: str, reps: int = 3):
