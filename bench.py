@@ -176,12 +176,23 @@ def main():
             step()
         torch.cuda.synchronize()
         trunk._timers = None
-        per_kernel = {}
+        # The dominant kernel is chosen by FAMILY (the __global__ function, all template instances together): per instance the step's
+        # largest entries are within 2 % of one another (8 stride-1 Swish stencils ~ 2 fused expand + stencil launches) and the choice
+        # flipped from run to run; by family the depthwise stencil (22 launches, ~28 % of the step) is the largest by a wide margin.
+        per_kernel, per_instance = {}, {}
         for i, evs in probe.items():
             ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-            per_kernel.setdefault(plan.meta[i]["kernel"], [0.0, []])
-            per_kernel[plan.meta[i]["kernel"]][0] += ms
-            per_kernel[plan.meta[i]["kernel"]][1].append(i)
+            inst = plan.meta[i]["kernel"]
+            fam = inst.split("<")[0]
+            per_kernel.setdefault(fam, [0.0, []])
+            per_kernel[fam][0] += ms
+            per_kernel[fam][1].append(i)
+            per_instance.setdefault(inst, [0.0, 0, 0.0, 0.0])
+            pi = per_instance[inst]
+            pi[0] += ms
+            pi[1] += 1
+            pi[2] += plan.meta[i]["bytes"]
+            pi[3] += plan.meta[i]["flops"]
         if args.per_op and rank == 0:  # per-launch table for the optimisation log (not part of the JSON contract)
             with open(args.per_op, "w") as fh:
                 for i, evs in probe.items():
@@ -250,9 +261,11 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 table = json.load(open(pmc_path))
-                # the profiler prints defaulted template arguments the plan's kernel names leave out (march stencil: "<1,3,false>")
-                entry = table.get(dominant) or table.get(dominant[:-1] + ",false>" if dominant.endswith(">") else dominant) or {}
-                traffic = entry.get("traffic_bytes_per_launch")
+                # launch-weighted mean over the family's instances as the profiler names them (it prints defaulted template arguments
+                # the plan's names leave out)
+                rows = [v for k, v in table.items() if k.split("<")[0] == dominant and v.get("launches_sampled")]
+                if rows:
+                    traffic = int(sum(v["traffic_bytes_per_launch"] * v["launches_sampled"] for v in rows) / sum(v["launches_sampled"] for v in rows))
             except (ValueError, OSError):
                 traffic = None
         tflops = avg_flops / (avg_ms * 1e-3) / 1e12
@@ -273,6 +286,14 @@ def main():
                 "mfma_tflops": round(tflops, 2),
             }
         result["kernel_ms_per_step"] = kernel_ms
+        # the five largest template instances with their own fractions (event-timed in the two probe steps): bound by the same rule
+        balance = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+        top = sorted(per_instance.items(), key=lambda kv: -kv[1][0])[:5]
+        result["roofline_instances"] = [
+            {"kernel": k, "launches_per_step": v[1], "ms_per_step": round(v[0], 4),
+             **({"bound": "mfma", "frac": round(v[3] / (v[0] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4)} if v[3] / max(v[2], 1.0) > balance
+                else {"bound": "hbm", "frac": round(v[2] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})}
+            for k, v in top]
     # Two byte counts for the whole step.  "bytes_per_clip" is what the launches of THIS build move algorithmically (a fused launch counts
     # its own inputs and outputs only).  "layerwise_bytes_per_clip" is SURVEY section 8(d)'s accounting -- every layer's input and output
     # once, norm / activation fused, residual read once -- i.e. the same plan compiled with every cross-layer fusion switched off; it does

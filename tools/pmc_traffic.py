@@ -17,7 +17,12 @@ import sys
 
 
 def pretty(mangled: str) -> str:
-    """_ZN4pasn21dwconv3d_strip_kernelIDF16bLi7ELi3ELi1EEEv... -> dwconv3d_strip_kernel<bf16,7,3,1>"""
+    """_ZN4pasn21dwconv3d_strip_kernelIDF16bLi7ELi3ELi1EEEv... -> dwconv3d_strip_kernel<bf16,7,3,1>; the profiler prints some names demangled
+    ("void pasn::x3d_expdw_kernel<2, 0, 2, false>(...)" -> x3d_expdw_kernel<2,0,2,false>)"""
+    dm = re.match(r"(?:void )?pasn::([A-Za-z0-9_]+)(?:<(.*?)>)?\(", mangled)
+    if dm:
+        args = (dm.group(2) or "").replace(" ", "").replace("__hip_bfloat16", "bf16").replace("float", "f32")
+        return f"{dm.group(1)}<{args}>" if args else dm.group(1)
     m = re.match(r"_ZN4pasn\d+([a-z0-9_]+?)I(.*?)EEv", mangled)
     if not m:
         m2 = re.match(r"_ZN4pasn\d+([a-z0-9_]+)", mangled)
