@@ -138,7 +138,7 @@ struct DwMfmaGeom {
 };
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
-                   const DwMfmaGeom& g, hipStream_t s);
+                   const DwMfmaGeom& g, hipStream_t s, int stats = 0);  // stats: pool = [N][chunks][2][Cp] (sum, sum of squares) of the raw outputs
 // x3d_expdw.hip: expand conv (1x1x1 + BN + ReLU) -> depthwise 3x3x3 stride-(1,s,s) stencil, s = 1 or 2, (+BN, act, SE partial sums) in one launch, both on
 // the matrix cores, the expanded activation only ever in LDS (the first block of an X3D stage); ok = 0: not covered
 struct XeGeom {

@@ -91,7 +91,9 @@ __device__ __forceinline__ void dwf_wait_all_but(int n) {  // n wave-uniform: ev
 __device__ __forceinline__ void dwf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ACT: the epilogue activation compiled in (none / Swish: what X3D uses), -1 = the descriptor's.
-template <int RPT, bool ABLB = false, int ACT = -1>
+// STATS (training forward): `pool` receives [N][chunks][2][Cp] = (sum, sum of squares) of the raw outputs per (clip, chunk) -- the batch
+// statistics' partial rows in the layout bn_finalize_kernel reads (dwmarch.hip's `stats` launch writes the same).
+template <int RPT, bool ABLB = false, int ACT = -1, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ scale, const float* __restrict__ bias,
                                                                __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         bs[i] = cev ? bias[ce + i] : 0.0f;
     }
     float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float psq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     const long fstride = (long)Hi * Wi * Cp;  // elements per frame
@@ -291,6 +294,10 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                         if (pool) {  // block-uniform
 #pragma unroll
                             for (int i = 0; i < 4; ++i) psum[i] += ok ? v[i] : 0.0f;
+                            if (STATS) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) psq[i] = fmaf(ok ? v[i] : 0.0f, v[i], psq[i]);
+                            }
                         }
                         // (a run-time activation switch per tile is ~10 scalar branches x NT per frame on a kernel bound by instruction issue)
                         if constexpr (ACT == PASN_ACT_SWISH) {
@@ -351,9 +358,21 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
             s += __shfl_xor(s, 8);
             psum[i] = s;
         }
+        if (STATS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = psq[i];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 8);
+                psq[i] = s;
+            }
+        }
         if (m == 0 && cev) {
-            float* pr = pool + ((long)n * g.chunks + chunk) * Cp + ce;
+            float* pr = pool + ((long)n * g.chunks + chunk) * (STATS ? 2 : 1) * Cp + ce;
             *reinterpret_cast<f32x4*>(pr) = f32x4{psum[0], psum[1], psum[2], psum[3]};
+            if (STATS) *reinterpret_cast<f32x4*>(pr + Cp) = f32x4{psq[0], psq[1], psq[2], psq[3]};
         }
     }
 }
@@ -419,9 +438,17 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
 }
 
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
-                   const DwMfmaGeom& g, hipStream_t s) {
+                   const DwMfmaGeom& g, hipStream_t s, int stats) {
     const dim3 grid(g.bpc * d.N), block(256);
     const size_t lds = (size_t)DWF_RING * g.NI * 1024;
+    if (stats) {  // training forward: raw outputs + (sum, sum of squares) partial rows
+        PASN_REQUIRE(pool && d.act == PASN_ACT_NONE && !g.abl, "dwconv3d_mfma: the statistics instance writes the raw conv output");
+        if (g.RPT == 2)
+            hipLaunchKernelGGL((dwconv3d_mfma_kernel<2, false, PASN_ACT_NONE, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+        else
+            hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, false, PASN_ACT_NONE, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+        return check_launch("dwconv3d_mfma_kernel (statistics)");
+    }
 #define PASN_DWF(RPT_, ABL_, ACT_) \
     hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
     if (g.abl) PASN_DWF(1, true, -1);

@@ -615,7 +615,10 @@ extern "C" int pasn_dwconv3d_stats_rows(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0 || d->Cout_p > 2048) return 0;
     if (const char* e = getenv("PASN_NO_DW_STATS"))
         if (e[0] == '1') return 0;
-    // (the matrix-core stencil does not matter here: pasn_dwconv3d_stats_fwd launches the VALU stencil itself)
+    // stride-1 layers: the matrix-core stencil with the statistics epilogue (one partial row pair per (clip, chunk)); PASN_DW_STATS_MFMA=0: the
+    // VALU stencil everywhere, as before round 3
+    if (!(getenv("PASN_DW_STATS_MFMA") && getenv("PASN_DW_STATS_MFMA")[0] == '0'))
+        if (const DwMfmaGeom mf = dw_mfma_geom(*d, dtype); mf.ok && !mf.abl) return mf.chunks;
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     return m.WT ? m.bpc : 0;
 }
@@ -630,8 +633,14 @@ extern "C" int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const floa
     PASN_REQUIRE(rows > 0, "layer not covered (pasn_dwconv3d_stats_rows returns 0)");
     hipStream_t s = (hipStream_t)stream;
     const int Cp = d->Cout_p, S = d->To * d->Ho * d->Wo;
-    const DwMarchGeom m = dw_march_geom(*d, dtype);
-    const int rc = launch_dw_march(x, w, scale, bias, y, ws, *d, m, s, DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, 1);
+    int rc;
+    const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
+    if (mf.ok && !mf.abl && mf.chunks == rows && !(getenv("PASN_DW_STATS_MFMA") && getenv("PASN_DW_STATS_MFMA")[0] == '0')) {
+        rc = launch_dw_mfma(x, w, scale, bias, y, ws, *d, mf, s, 1);
+    } else {
+        const DwMarchGeom m = dw_march_geom(*d, dtype);
+        rc = launch_dw_march(x, w, scale, bias, y, ws, *d, m, s, DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, 1);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)nullptr, gamma, beta, running_mean,
                        running_var, momentum, eps, stat, pool_u, d->N, S, d->Cout, Cp, rows);
