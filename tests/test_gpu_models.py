@@ -342,6 +342,32 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
     assert err_fused < 1.25 * err_alone + 1e-3, (err_fused, err_alone)
 
 
+@pytest.mark.parametrize("cfg_name", ["x3d", "r2p1d"])
+def test_default_forward_is_bitwise_reproducible(cfg_name):
+    """The benchmarked path as routed by default -- fused expand + stencil launch, SE gates in consumer prologues, chained pairs, head B as
+    one chained launch + finish -- gives bit-identical logits, similarities, occurrence maps and pushed features across repeated runs and
+    across two models built from the same weights: every reduction (SE pool partial rows, pooling slabs, last-block hand-offs) has a fixed
+    order, nothing accumulates with atomics."""
+    cfg = CFG_VIDEO_X3D if cfg_name == "x3d" else CFG_VIDEO_R2P1D
+    shape = (3, 3, 16, 160, 160) if cfg_name == "x3d" else (2, 3, 16, 112, 112)
+    x = synth.echo_clips(shape).to(DEV).bfloat16()
+    models = [_gpu(cfg).set_compute_dtype(torch.bfloat16) for _ in range(2)]
+    outs = []
+    with torch.no_grad():
+        for m in models:
+            for _ in range(3):
+                logits, sim, occ = m(x)
+                feats = m.push_forward(x)[0]
+                outs.append((logits.clone(), sim.clone(), occ.clone(), feats.clone()))
+    if cfg_name == "x3d":
+        kinds = [k["kind"] for k in models[0].cnn_backbone.plan_for(x).meta]
+        assert "expand+dwconv" in kinds and "conv_pair+se" in kinds, kinds
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)
+    assert all(torch.isfinite(t).all() for t in outs[0])
+
+
 def test_ppnet_callable_prototype_activation():
     """ProtoPNet.py:217-223: ``prototype_activation_function`` may be a callable on the distances.  The kernel supplies the minima; the
     callable and the last layer then run in torch -- same logits as the built-in 'log' when the callable is the log formula."""
