@@ -20,7 +20,9 @@ namespace pasn {
 // SM_PC: patch columns staged per row = 2 * 64 + 4 (the last window ends at patch column 131).  It was 192: 72.5 KB of LDS, two blocks per
 // CU with every wave of a block in the same phase (stage / barrier / MFMA / epilogue) -- nothing above 40 % busy.  132: 53 KB, THREE
 // blocks per CU (145-153 VGPRs), a third fewer staging loads: stem 191 -> ~150 us, 8.80 k -> 8.91 k clips/s end to end.
-constexpr int SM_ROWS = 4, SM_COLS = 64, SM_PC = 132, SM_PR = 2 * (SM_ROWS - 1) + 3, SM_RING = 6;
+// Round 3: a block owns 56 of the 64 columns its two MFMA column tiles span (112 = 2 x 56: no 64 + 48 split, 116 staged patch columns
+// instead of 132; the columns beyond 56 are computed from whatever follows in the ring and never stored): 152 -> 149 us.
+constexpr int SM_ROWS = 4, SM_COLS = 56, SM_PC = 116, SM_PR = 2 * (SM_ROWS - 1) + 3, SM_RING = 6;
 static_assert(SM_PC % 4 == 0 && SM_PC >= 2 * SM_COLS + 4, "whole 4-column staging units, every window inside the patch");
 constexpr int SM_PF = 3;  // k-steps of fragment reads in flight ahead of the MFMAs
 
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void x3d_stem_mfma_kernel(const TIN* __rest
         }
         igemm_epilogue<NT, MT>(acc, img, scb, nullptr, y, 0, cgs, d, lane, [&](int j, long& mbase, int& nvalid) {
             mbase = (((long)n * d.To + to) * d.Ho + oh) * d.Wo + ow0 + 32 * j;
-            nvalid = oh < d.Ho ? min(32, d.Wo - (ow0 + 32 * j)) : 0;
+            nvalid = oh < d.Ho ? min(min(32, SM_COLS - 32 * j), d.Wo - (ow0 + 32 * j)) : 0;  // a block owns SM_COLS columns of its 64-wide MFMA tile
         });
     };
 
