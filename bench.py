@@ -365,6 +365,9 @@ def _layerwise_bytes(trunk, x, dtype):
         x_in = pb.input(tuple(x.shape))
         pb.finish(x_in, trunk.build_plan(pb, x_in))
         return float(sum(m["bytes"] for m in pb.meta))
+    except Exception as e:  # an accounting extra must never cost the bench line
+        print(f"bench.py: layerwise byte count unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
     finally:
         for k, v in saved.items():
             if v is None:
