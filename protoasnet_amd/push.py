@@ -119,6 +119,20 @@ def shard_batches(num_batches: int, rank: int, world_size: int) -> range:
     return range(min(rank * per, num_batches), min((rank + 1) * per, num_batches))
 
 
+def _labels_to_device(labels, device, pinned: list) -> torch.Tensor:
+    """The batch's labels as int64 on the device WITHOUT stalling the host: a pageable host tensor's ``.to(device)`` returns only
+    when the copy has run, i.e. after every launch already queued -- per batch that drained the queue and left the GPU idle while the
+    next batch's ~80 launches were enqueued (push sweep over 10 000 clips: 8.8 k clips/s against 10.5 k for the bare forward).  Labels go
+    through a pinned staging tensor and a non-blocking copy; ``pinned`` keeps the last few staging tensors alive until their copies ran."""
+    labels = torch.as_tensor(labels)
+    if labels.device.type != "cpu" or torch.device(device).type == "cpu":
+        return labels.to(device=device, dtype=torch.int64).contiguous()
+    stage = labels.to(torch.int64).contiguous().pin_memory()
+    pinned.append(stage)
+    del pinned[:-8]
+    return stage.to(device, non_blocking=True)
+
+
 def _iter_shard(dataloader, rank: int, world_size: int):
     """Yields ``(batch index, global index of the batch's first clip, sample)`` for this rank's contiguous batch range.
 
@@ -184,11 +198,12 @@ def push_prototypes(dataloader, model, class_specific=True, abstain_class=True, 
     lib = _lib.lib()
     save = root_dir_for_saving_prototypes is not None
     rec, names, ar = None, {}, torch.arange(P, device=device)
+    pinned = []
     for i, base, sample in _iter_shard(dataloader, rank, world_size):
         x = sample["cine"]
         if preprocess_input_function is not None:
             x = preprocess_input_function(x)
-        labels = sample["target_AS"].to(device=device, dtype=torch.int64).contiguous()
+        labels = _labels_to_device(sample["target_AS"], device, pinned)
         xdev = x.to(device)
         with torch.no_grad():
             feats, proto_dist, occ, logits = model.push_forward(xdev)
@@ -313,11 +328,12 @@ def push_prototypes_ppnet(dataloader, model, class_specific=True, preprocess_inp
     search_batch_size = dataloader.batch_size
     save = root_dir_for_saving_prototypes is not None
     rec, hw, img_side = None, None, None
+    pinned = []
     for i, _, sample in _iter_shard(dataloader, rank, world_size):
         x = sample["cine"]
         if preprocess_input_function is not None:
             x = preprocess_input_function(x)
-        labels = sample["target_AS"].to(device=device, dtype=torch.int64).contiguous()
+        labels = _labels_to_device(sample["target_AS"], device, pinned)
         with torch.no_grad():
             z, (n, h, w) = model._conv_rows(x.to(device))
             _, _, dist = model._head(z, n, h * w, want_dist=True)
