@@ -796,6 +796,8 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     PASN_REQUIRE(dtype == PASN_F32 || dtype == PASN_BF16, "unknown dtype");
     if (const WsGeom wg = pw_ws_geom(*d, dtype, gate != nullptr, residual != nullptr); wg.ok)  // weight-stationary persistent blocks (bf16, fragment-major weights)
         return launch_pw_ws(x, w, scale, bias, residual, gate, y, *d, wg, s);
+    if (pw_tiny_applicable(*d, dtype, gate != nullptr))  // fp32, few positions (the image heads): one wave per 32 x 32 output tile
+        return launch_pw_tiny(x, w, scale, bias, residual, y, *d, s);
     const bool xt_first = prefer_xtile(*d, dtype, gate != nullptr);
     const PwGeom pg = xt_first ? PwGeom{0, 0, 0, 0} : pw_geom(*d, dtype);  // 1x1x1 stride-1 convs: the row-streaming kernel
     PASN_REQUIRE(d->w_frag == 0 || (pw_xtile_applicable(*d, dtype) && !pg.TM),
@@ -914,6 +916,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags
         df.w_frag = 1;
         if (const int v = pw_ws_variant(df, dtype, has_gate != 0, has_res != 0)) return v;
     }
+    if (pw_tiny_applicable(*d, dtype, has_gate != 0)) return 2002;  // pwconv_tiny_f32_kernel
     const PwGeom pg = prefer_xtile(*d, dtype, has_gate != 0) ? PwGeom{0, 0, 0, 0} : pw_geom(*d, dtype);
     if (pg.TM) return 1000 + pg.TM * 10 + pg.xrow;  // pwconv_persist_kernel<dtype, KS, NT>
     if (pw_xtile_applicable(*d, dtype))               // pwconv_xtile_kernel<dtype, input transform?>
