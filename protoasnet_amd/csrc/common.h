@@ -150,10 +150,10 @@ struct XeGeom {
 XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype);
 int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
                      void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s);
-// pwconv_tiny.hip: fp32 pointwise conv on few positions (the image heads): one wave per 32 x 32 output tile, operands straight from global
+// pwconv_tiny.hip: fp32 / bf16 pointwise conv on few positions (the image heads): one wave per 32 x 32 output tile, operands straight from global
 bool pw_tiny_applicable(const pasn_conv_desc& d, int dtype, bool has_gate);
 int launch_pw_tiny(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y, const pasn_conv_desc& d,
-                   hipStream_t s);
+                   int dtype, hipStream_t s);
 // igemm.hip: windowed dense convs (bf16) as an implicit GEMM with direct-to-LDS staging; NT = 0: not covered
 int igemm_nt(const pasn_conv_desc& d, int dtype);
 // first_conv_mfma.hip: the 7x7 stride-2 stems on the matrix cores (bf16 out); slot < 0: not covered

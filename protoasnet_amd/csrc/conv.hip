@@ -797,7 +797,7 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     if (const WsGeom wg = pw_ws_geom(*d, dtype, gate != nullptr, residual != nullptr); wg.ok)  // weight-stationary persistent blocks (bf16, fragment-major weights)
         return launch_pw_ws(x, w, scale, bias, residual, gate, y, *d, wg, s);
     if (pw_tiny_applicable(*d, dtype, gate != nullptr))  // fp32, few positions (the image heads): one wave per 32 x 32 output tile
-        return launch_pw_tiny(x, w, scale, bias, residual, y, *d, s);
+        return launch_pw_tiny(x, w, scale, bias, residual, y, *d, dtype, s);
     const bool xt_first = prefer_xtile(*d, dtype, gate != nullptr);
     const PwGeom pg = xt_first ? PwGeom{0, 0, 0, 0} : pw_geom(*d, dtype);  // 1x1x1 stride-1 convs: the row-streaming kernel
     PASN_REQUIRE(d->w_frag == 0 || (pw_xtile_applicable(*d, dtype) && !pg.TM),

@@ -311,7 +311,7 @@ class PlanBuilder:
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
         self._note("conv", f"pwconv_ws_kernel<{(variant - 7000) // 10},{variant % 10},{'true' if (in_gate is not None or in_swish) else 'false'},{'true' if residual is not None else 'false'}>" if variant >= 7000 else
                    _igemm_name(variant - 6000) if variant >= 6000 else f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if 2500 <= variant < 6000 else
-                   "pwconv_tiny_f32_kernel" if variant == 2002 else
+                   f"pwconv_tiny_kernel<{self.tname}>" if variant == 2002 else
                    f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else
                    f"pwconv_persist_kernel<{self.tname},{(variant - 1000) // 10},{variant % 10},{'true' if residual is not None else 'false'}>" if variant >= 1000 else
                    f"conv3d_mfma_kernel<{self.tname},{variant // 10},{variant % 10}>",

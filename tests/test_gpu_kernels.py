@@ -708,7 +708,7 @@ def test_conv_kernel_routing():
 
     lib = _lib.lib()
 
-    def desc(cin, cout, s=784, n=2, in_swish=0):
+    def desc(cin, cout, s=784, n=32, in_swish=0):  # the benchmark batch: few-position layers have their own kernel (last lines)
         rup = lambda v, m: (v + m - 1) // m * m
         return ConvDesc(N=n, Ti=1, Hi=1, Wi=s, Cin=cin, Cin_p=rup(cin, 8), To=1, Ho=1, Wo=s, Cout=cout, Cout_p=rup(cout, 8),
                         kt=1, kh=1, kw=1, st=1, sh=1, sw=1, pt=0, ph=0, pw=0, act=0, in_swish=in_swish,
@@ -731,6 +731,11 @@ def test_conv_kernel_routing():
     assert v(desc(108, 48, in_swish=1), 3) == 1000 + 8 * 10 + 2    # gated narrow project conv: stays on the persistent kernel
     assert v(desc(96, 432)) == 7000 + 6 * 10 + 2          # wide expand conv
     assert v(desc(192, 432)) == 2500 + 2 * 12             # stays on the x-tile kernel
+    # few positions (<= 8192): one wave per 32 x 32 tile straight from global memory -- fp32 from 64 input channels, bf16 from 256 (the image heads)
+    f32 = _lib.dtype_code(torch.float32)
+    assert int(lib.pasn_conv3d_variant(ctypes.byref(desc(512, 512, s=49, n=8)), f32, 0)) == 2002
+    assert v(desc(512, 512, s=49, n=8)) == 2002 and v(desc(432, 192, n=2)) == 2002
+    assert v(desc(192, 256, s=49, n=8)) != 2002            # bf16 below 256 input channels: the tiled kernels
 
 
 FIRST_CASES = [

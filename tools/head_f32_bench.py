@@ -5,9 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from protoasnet_amd import model_builder, synth
 
+DT = os.environ.get("DT", "f32")
 cfg = dict(checkpoint_path="", name="XProtoNet", base_architecture="resnet18", pretrained=False, prototype_shape="(40, 512, 1, 1)", num_classes=4, img_size=224)
 m = model_builder.build(cfg); synth.load_synth(m); m = m.to("cuda").eval()
+if DT == "bf16": m.set_compute_dtype(torch.bfloat16)
 x = synth.echo_clips((8, 3, 224, 224)).to("cuda")
+if DT == "bf16": x = x.bfloat16()
 with torch.no_grad():
     feat = m.cnn_backbone(x)
     orig = m.cnn_backbone
