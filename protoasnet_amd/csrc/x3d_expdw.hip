@@ -393,7 +393,10 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     // 28 + 60 / 28 + 52 at 28 x 28; 10.34 k vs 10.58 k clips/s end to end (profiles/README.md entry 74).  At stride 1 the expanded tensor is
     // no larger than the stencil's output, the unfused pair is not bound by its bytes, and the expand epilogue's ~3 vector instructions per
     // element land on a kernel that is already bound by vector issue.
-    if (ss != 2) return g;
+    // One exception: the SE blocks of the widest stride-1 stage (no Swish in the stencil epilogue, planes >= 56 wide): 148 vs 55 + 107 us,
+    // 10.56 -> 10.67 k clips/s end to end (entry 80).  PASN_EXPDW_S1=0: off.
+    const bool s1 = ss == 1 && d.act == PASN_ACT_NONE && d.Wo >= 56 && !(getenv("PASN_EXPDW_S1") && getenv("PASN_EXPDW_S1")[0] == '0');
+    if (ss != 2 && !s1) return g;
     const bool dw = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sw == ss && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
                     d.To == d.Ti && d.Ho == (d.Hi - 1) / ss + 1 && d.Wo == (d.Wi - 1) / ss + 1 && d.Cin_p == d.Cout_p && d.Cin == d.Cout &&
                     d.Cout_p % 8 == 0;
@@ -461,7 +464,11 @@ int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float
         else if (d.act == PASN_ACT_SWISH) PASN_XE(KS_, PASN_ACT_SWISH, SS_, false); \
         else PASN_XE(KS_, -1, SS_, false);                                          \
     } while (0)
-    PASN_REQUIRE(g.SS == 2, "x3d_expdw: stride-2 instances only");
+    if (g.SS == 1) {
+        PASN_REQUIRE(d.act == PASN_ACT_NONE && !g.abl, "x3d_expdw: the stride-1 instance serves the SE blocks only");
+        PASN_XE(2, PASN_ACT_NONE, 1, false);
+        return check_launch("x3d_expdw_kernel (stride 1)");
+    }
     if (g.abl) PASN_XE(2, -1, 2, true);
     else PASN_XEK(2, 2);
 #undef PASN_XEK

@@ -543,7 +543,7 @@ class PlanBuilder:
         if _triple(conv_a.kernel_size, 1) != one or _triple(conv_a.stride, 1) != one or _triple(conv_a.padding, 0) != zero:
             return None
         k, s, p = _triple(conv_b.kernel_size, 1), _triple(conv_b.stride, 1), _triple(conv_b.padding, 0)
-        if k != (3, 3, 3) or s != (1, 2, 2) or p != (1, 1, 1) or conv_b.in_channels != conv_a.out_channels:  # (stride 1: measured slower)
+        if k != (3, 3, 3) or s not in ((1, 1, 1), (1, 2, 2)) or p != (1, 1, 1) or conv_b.in_channels != conv_a.out_channels:
             return None
         cm = conv_a.out_channels
         mid = Act(x.N, x.T, x.H, x.W, cm, round_up(cm, 8), -1)  # the expanded activation: never materialised

@@ -310,7 +310,7 @@ def test_fused_se_gate_equals_stand_alone_gate_and_is_reproducible(shape, monkey
     meta0 = m0.cnn_backbone.plan_for(x).meta
     n_prologue = len([k for k in meta0 if k["kind"] in ("conv+se", "conv_pair+se")])
     # (the first blocks of stages 2 and 3 run expand conv + stencil as one launch, x3d_expdw.hip, followed by a stand-alone gate)
-    assert len([k for k in meta0 if k["kind"] == "expand+dwconv"]) == 2
+    assert len([k for k in meta0 if k["kind"] == "expand+dwconv"]) in (2, 3)  # + the stride-1 SE block where the plane is >= 56 wide
     assert len([k for k in meta0 if k["kind"] == "dwconv+se"]) == 3 and len([k for k in meta0 if k["kernel"].startswith("se_gate")]) + n_prologue == 12
     if shape[2:] == (16, 160, 160):
         assert n_prologue == 10, n_prologue  # both wide stages: no stand-alone gate launch left
