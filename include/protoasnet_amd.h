@@ -276,7 +276,9 @@ typedef struct pasn_xproto_desc {
  * instantiated by the reference's x3d trunks; replaces pasn_conv3d_fwd + pasn_dwconv3d_fwd for that pair -- the expanded activation (2.25x
  * the block width at the input resolution) stays in LDS.
  *   x  : block input, channels-last [N][T][H][W][de->Cin_p];   y : [N][T][Ho][Wo][d->Cout_p]
- *   wa : conv_a weights FRAGMENT-MAJOR (w_frag = 1), scale_a / bias_a: folded norm_a [de->w_rows] (zero beyond the channels)
+ *   wa : conv_a weights FRAGMENT-MAJOR (w_frag = 1), scale_a / bias_a: folded norm_a [de->w_rows] (zero beyond the channels).
+ *        scale_a == NULL: the caller has folded norm_a's scale into wa (W * scale, rounded to bf16 once); bias_a then initialises the
+ *        fp32 accumulators and the expand epilogue is ReLU + rounding only (what the plan compiler passes)
  *   w  : conv_b weights fp32 [27][Cp], scale / bias: folded norm_b [Cp]
  *   pool_partial : NULL or fp32 [N][pasn_x3d_expdw_pool_blocks()][Cp] (sums of the pre-activation output over positions, fixed order)
  * _supported() == 0: issue the two launches.

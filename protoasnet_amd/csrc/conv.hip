@@ -987,7 +987,7 @@ extern "C" int pasn_x3d_expdw_pool_blocks(const pasn_conv_desc* de, const pasn_c
 extern "C" int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, const float* bias_a, const float* w, const float* scale,
                                   const float* bias, void* y, float* pool_partial, const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype,
                                   void* stream) {
-    PASN_REQUIRE(x && wa && scale_a && bias_a && w && scale && bias && y, "null pointer");
+    PASN_REQUIRE(x && wa && bias_a && w && scale && bias && y, "null pointer");  // scale_a may be NULL: norm_a's scale folded into wa by the caller
     PASN_REQUIRE(conv_desc_ok(de) && conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
     PASN_REQUIRE(dtype == PASN_BF16 && de->w_frag == 1, "bf16 with fragment-major expand weights only");
     const XeGeom g = xe_geom(*de, *d, dtype);

@@ -64,7 +64,7 @@ __device__ __forceinline__ void xe_wait_all_but(int n) {  // n wave-uniform
 __device__ __forceinline__ void xe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // KS: k-steps of the expand conv held in registers (K = block width <= 16 KS channels); ACT: the stencil's epilogue activation
-template <int KS, int ACT, int SS, bool ABLB = false>  // ABLB: timing-only ablation instance (PASN_EXPDW_ABL; results are wrong when set)
+template <int KS, int ACT, int SS, bool ABLB = false, bool FOLD = false>  // ABLB: timing-only ablation instance (PASN_EXPDW_ABL; results are wrong when set)
 __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wa,
                                                            const float* __restrict__ sa, const float* __restrict__ ba,
                                                            const float* __restrict__ w, const float* __restrict__ scale,
@@ -135,10 +135,17 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     }
     if (threadIdx.x < 64) {
         const int ch = cq * 64 + threadIdx.x;
-        scb[threadIdx.x] = ch < Cp ? sa[ch] : 0.0f;
+        scb[threadIdx.x] = (ch < Cp && sa) ? sa[ch] : 1.0f;
         scb[64 + threadIdx.x] = ch < Cp ? ba[ch] : 0.0f;
     }
     __syncthreads();
+    // FOLD (scale_a == NULL, the plan's form): norm_a's scale is folded into the expand weights (W * scale rounded to bf16 ONCE, by the host) and its
+    // bias is the accumulator's initial value -- the epilogue is then lane swap, ReLU, rounding: a third fewer vector instructions per
+    // expanded element on a kernel bound by vector issue.  biasC: this lane's 16 accumulator rows = channels 32 ect + acc_row(r, h32)
+    constexpr bool folded = FOLD;  // (a compile-time property: the host launches the FOLD instance when scale_a == NULL)
+    f32x16 biasC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) biasC[r] = folded ? scb[64 + 32 * ect + acc_row(r, h32)] : 0.0f;
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     const long fx = (long)Hi * Wi * Cin_p;  // elements per x frame
     const unsigned fx_bytes = (unsigned)(fx * 2);
@@ -224,8 +231,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                 for (int ks = 0; ks < KS; ++ks) {
                     bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + min(2 * ks + h32, XS - 1) * 16);
                     if (ks == 0) {
-                        const f32x16 z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        acc = (abl & 1) ? z : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[0], b, z, 0, 0, 0);
+                        acc = (abl & 1) ? biasC : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[0], b, biasC, 0, 0, 0);
                     } else if (!(abl & 1)) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], b, acc, 0, 0, 0);
                     }
@@ -233,9 +239,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                 const bool keep = (keepm >> i) & 1u;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    float v[8], esc[8], ebs[8];
-                    load8(scb + 32 * ect + 16 * pr + 8 * h32, esc);  // this lane's 8 channels after the lane swap: 32 ect + 16 pr + 8 h32 ..
-                    load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs);
+                    float v[8];
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * pr + qq]), __float_as_uint(acc[8 * pr + 4 + qq]), false, false);
@@ -247,8 +251,16 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e & 1];
                     } else {
+                        if (folded) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[e] + ebs[e], 0.0f);
+                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e], 0.0f);
+                        } else {  // separate scale / bias (this lane's 8 channels after the lane swap: 32 ect + 16 pr + 8 h32 ..)
+                            float esc[8], ebs[8];
+                            load8(scb + 32 * ect + 16 * pr + 8 * h32, esc);
+                            load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[e] + ebs[e], 0.0f);
+                        }
                     }
                     xe_u32x4 ou = __builtin_bit_cast(xe_u32x4, o);
                     if (!all_in) {  // wave-uniform: only regions on the image border select
@@ -452,11 +464,16 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
 int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
                      void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s) {
     const dim3 grid((unsigned)(g.bpc * d.N)), block(256);
-#define PASN_XE(KS_, ACT_, SS_, ABL_)                                                                                             \
+#define PASN_XEF(KS_, ACT_, SS_, ABL_, FOLD_)                                                                                    \
     do {                                                                                                                         \
-        PASN_MAX_LDS(96 * 1024, x3d_expdw_kernel<KS_, ACT_, SS_, ABL_>);                                                         \
-        hipLaunchKernelGGL((x3d_expdw_kernel<KS_, ACT_, SS_, ABL_>), grid, block, (size_t)g.lds, s, (const __bf16*)x, (const __bf16*)wa, sa, \
-                           ba, w, scale, bias, (__bf16*)y, pool, d, de.Cin_p, de.w_kc / 16, g);                                  \
+        PASN_MAX_LDS(96 * 1024, x3d_expdw_kernel<KS_, ACT_, SS_, ABL_, FOLD_>);                                                  \
+        hipLaunchKernelGGL((x3d_expdw_kernel<KS_, ACT_, SS_, ABL_, FOLD_>), grid, block, (size_t)g.lds, s, (const __bf16*)x,     \
+                           (const __bf16*)wa, sa, ba, w, scale, bias, (__bf16*)y, pool, d, de.Cin_p, de.w_kc / 16, g);           \
+    } while (0)
+#define PASN_XE(KS_, ACT_, SS_, ABL_)                          \
+    do {                                                       \
+        if (sa == nullptr) PASN_XEF(KS_, ACT_, SS_, ABL_, true); \
+        else PASN_XEF(KS_, ACT_, SS_, ABL_, false);            \
     } while (0)
 #define PASN_XEK(KS_, SS_)                                                          \
     do {                                                                            \
@@ -473,6 +490,7 @@ int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float
     else PASN_XEK(2, 2);
 #undef PASN_XEK
 #undef PASN_XE
+#undef PASN_XEF
     return check_launch("x3d_expdw_kernel");
 }
 

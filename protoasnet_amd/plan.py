@@ -17,6 +17,7 @@ when a parameter changes (``load_state_dict``, optimizer step, ``.to()``).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -547,7 +548,13 @@ class PlanBuilder:
             return None
         cm = conv_a.out_channels
         mid = Act(x.N, x.T, x.H, x.W, cm, round_up(cm, 8), -1)  # the expanded activation: never materialised
-        wa, kca, rowsa = pack_conv_weight(conv_a.weight, x.Cp, self.dtype)
+        # norm_a's scale goes INTO the expand weights (W * scale, rounded to bf16 once) and its bias becomes the accumulator's initial
+        # value: the fused kernel's expand epilogue is then swap + ReLU + rounding (PASN_EXPDW_FOLD=0: scale and bias applied in fp32
+        # after the MFMAs, the rounding points of the two separate launches)
+        fold = os.environ.get("PASN_EXPDW_FOLD", "1") != "0"
+        sa_full, _ = fold_norm(norm_a, conv_a.bias, cm, cm, self.device)
+        w_src = conv_a.weight.detach().float() * sa_full.to(conv_a.weight.device).view(-1, 1, 1, 1, 1) if fold else conv_a.weight
+        wa, kca, rowsa = pack_conv_weight(w_src, x.Cp, self.dtype)
         de = self._desc(x, mid, one, one, zero, "relu", False, kca, rowsa)
         probe = ConvDesc(N=x.N, Ti=x.T, Hi=x.H, Wi=x.W, Cin=cm, Cin_p=mid.Cp, To=x.T, Ho=(x.H - 1) // s[1] + 1, Wo=(x.W - 1) // s[2] + 1, Cout=cm,
                          Cout_p=mid.Cp, kt=3, kh=3, kw=3, st=1, sh=s[1], sw=s[2], pt=1, ph=1, pw=1, act=_lib.ACT[act_b])
@@ -568,6 +575,8 @@ class PlanBuilder:
             pool_buf = self._new_buf(y.N * pool_blocks * y.Cp * 4)
         fn, code = self.lib.pasn_x3d_expdw_fwd, self.code
         a = tuple(t.data_ptr() for t in (waf, sa, ba, wp, sb, bb))
+        if fold:
+            a = (a[0], 0) + a[2:]
         xb, yb, pb_, re_, rd_ = x.buf, y.buf, pool_buf, ctypes.byref(de), ctypes.byref(d)
         self._use(xb, yb, pb_)
         in_pos, out_pos = x.N * x.positions, y.N * y.positions
