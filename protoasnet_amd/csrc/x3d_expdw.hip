@@ -407,7 +407,9 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     // element land on a kernel that is already bound by vector issue.
     // One exception: the SE blocks of the widest stride-1 stage (no Swish in the stencil epilogue, planes >= 56 wide): 148 vs 55 + 107 us,
     // 10.56 -> 10.67 k clips/s end to end (entry 80).  PASN_EXPDW_S1=0: off.
-    const bool s1 = ss == 1 && d.act == PASN_ACT_NONE && d.Wo >= 56 && !(getenv("PASN_EXPDW_S1") && getenv("PASN_EXPDW_S1")[0] == '0');
+    // With the ReLU-only expand epilogue (entry 81) the Swish (non-SE) blocks of those planes win too, narrowly (10 845 -> 10 875 clips/s).
+    const char* s1m = getenv("PASN_EXPDW_S1");  // 0: off; 1: the SE blocks only
+    const bool s1 = ss == 1 && d.Wo >= 56 && !(s1m && s1m[0] == '0') && (d.act == PASN_ACT_NONE || (d.act == PASN_ACT_SWISH && !(s1m && s1m[0] == '1')));
     if (ss != 2 && !s1) return g;
     const bool dw = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sw == ss && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
                     d.To == d.Ti && d.Ho == (d.Hi - 1) / ss + 1 && d.Wo == (d.Wi - 1) / ss + 1 && d.Cin_p == d.Cout_p && d.Cin == d.Cout &&
@@ -482,8 +484,9 @@ int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float
         else PASN_XE(KS_, -1, SS_, false);                                          \
     } while (0)
     if (g.SS == 1) {
-        PASN_REQUIRE(d.act == PASN_ACT_NONE && !g.abl, "x3d_expdw: the stride-1 instance serves the SE blocks only");
-        PASN_XE(2, PASN_ACT_NONE, 1, false);
+        PASN_REQUIRE((d.act == PASN_ACT_NONE || d.act == PASN_ACT_SWISH) && !g.abl, "x3d_expdw: stride-1 instances: activation none / Swish");
+        if (d.act == PASN_ACT_NONE) PASN_XE(2, PASN_ACT_NONE, 1, false);
+        else PASN_XE(2, PASN_ACT_SWISH, 1, false);
         return check_launch("x3d_expdw_kernel (stride 1)");
     }
     if (g.abl) PASN_XE(2, -1, 2, true);

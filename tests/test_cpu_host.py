@@ -163,8 +163,8 @@ def test_plan_shapes_and_arena(cfg, shape):
     se_prologue = 0 if (os.environ.get("PASN_NO_SE_PROLOGUE") == "1" or os.environ.get("PASN_WS") == "0") else 10
     # (x3d_expdw.hip runs expand conv + stride-2 stencil of the first blocks of stages 2 and 3 as one launch; those blocks trade the
     # stencil-fused gate for a stand-alone one: same count)
-    # ... and, at stride 1, the SE block of the 56-wide stage (expand + stencil + gate -> fused launch + gate)
-    expdw_s1 = 0 if (os.environ.get("PASN_EXPDW") == "0" or os.environ.get("PASN_EXPDW_S1") == "0") else 1
+    # ... and, at stride 1, the two blocks of the 56-wide stage (expand + stencil [+ gate] -> fused launch [+ gate])
+    expdw_s1 = 0 if (os.environ.get("PASN_EXPDW") == "0" or os.environ.get("PASN_EXPDW_S1") == "0") else 1 if os.environ.get("PASN_EXPDW_S1") == "1" else 2
     assert n_ops == {"x3d_s": 1 + 26 * 3 - fused - paired + 4 + gates - short_fused - se_prologue - expdw_s1, "resnet2p1d_18": 2 + 6 * 4 + 2, "resnet18": 2 + 16 + 3}[cfg["base_architecture"]], n_ops
 
 

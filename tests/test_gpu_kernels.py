@@ -452,13 +452,11 @@ def test_conv_with_fused_strided_shortcut(inner, cout, cin2, thw, gate, monkeypa
                                                  (24, 54, 2, (4, 14, 56), 1), (24, 54, 2, (18, 7, 59), 1), (16, 40, 3, (3, 13, 70), 1)])
 def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, stride, se):
     """Front half of an X3D block: 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 conv, stride (1,2,2) (a stage's first block) or stride 1
-    (the SE blocks of planes >= 56 wide), + BN (+ Swish, or the squeeze-excite pool partial rows) in ONE launch with the expanded activation in LDS (pasn_x3d_expdw_fwd) -- against torch on the
+    (the blocks of planes >= 56 wide), + BN (+ Swish, or the squeeze-excite pool partial rows) in ONE launch with the expanded activation in LDS (pasn_x3d_expdw_fwd) -- against torch on the
     bf16-rounded operands and against the two launches.  Even and odd planes (the last strided row / column exists or not), planes
     smaller than a region, several regions and T chunks, two channel quads (108), block widths of 8 / 16 / 24 channels, channel counts
     that are not multiples of 16, T = 18 (chunked march), clips of 2 frames."""
     dtype = torch.bfloat16
-    if stride == 1 and not se:
-        pytest.skip("stride 1 is routed for the squeeze-excite blocks only (no activation in the stencil epilogue): measured, entry 74 / 80")
     torch.manual_seed(cin + cm + n)
     t, hi, wi = thw
     x = torch.randn(n, cin, t, hi, wi)
