@@ -305,6 +305,8 @@ def main():
         "layerwise_bytes_per_clip": int(layerwise / args.batch) if layerwise else None,
         "hbm_frac_whole_step_layerwise": round(layerwise * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4) if layerwise else None,
         "arena_bytes": plan.arena_bytes,
+        "note": "bytes_per_clip counts what this build's launches move (fused launches skip their intermediates); layerwise_bytes_per_clip is the "
+                "per-layer count of SURVEY 8(d), constant across builds: compare rounds on hbm_frac_whole_step_layerwise",
     }
 
     # ---- CPU baseline: the oracle (restated reference op sequence) on a bounded sample of the same workload ---------
