@@ -120,7 +120,8 @@ struct DwSeArgs {
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
                     const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se = DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
                     int stats = 0,  // stats: `pool` is the batch-statistics partial buffer [N][bpc][2][Cp] (sum, sum of squares)
-                    const struct DwRedArgs* red = nullptr);  // red: the launch is a dgrad whose outputs also feed the producer unit's backward sums
+                    const struct DwRedArgs* red = nullptr,   // red: the launch is a dgrad whose outputs also feed the producer unit's backward sums
+                    const float* shift = nullptr);           // stats without red: per-channel shift of the moments (NULL: 0)
 // backward sums of the unit that PRODUCED the stencil's input (training): y = that unit's raw conv output (same geometry as the stencil's
 // output), stat = its (mean, invstd, sc, sh) table, act = its activation; `pool` then receives [N][bpc][2][Cp] = (sum d', sum d' yhat)
 struct DwRedArgs {
@@ -138,7 +139,7 @@ struct DwMfmaGeom {
 };
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
-                   const DwMfmaGeom& g, hipStream_t s, int stats = 0);  // stats: pool = [N][chunks][2][Cp] (sum, sum of squares) of the raw outputs
+                   const DwMfmaGeom& g, hipStream_t s, int stats = 0, const float* shift = nullptr);  // stats: pool = [N][chunks][2][Cp]: (sum, sum of squares) of (raw output - shift[c])
 // x3d_expdw.hip: expand conv (1x1x1 + BN + ReLU) -> depthwise 3x3x3 stride-(1,s,s) stencil, s = 1 or 2, (+BN, act, SE partial sums) in one launch, both on
 // the matrix cores, the expanded activation only ever in LDS (the first block of an X3D stage); ok = 0: not covered
 struct XeGeom {

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
                                                              int CG, int R, int strips, int Tc, int bpc, DwSeArgs se, int stats,
-                                                             DwRedArgs rd) {
+                                                             DwRedArgs rd, const float* __restrict__ shift) {
     // [27 taps + scale + bias][2 halves][DWM_CGS slots][4] fp32 (fixed slot stride: every tap is an immediate ds_read
     // offset), then [R][Cp] pool scratch
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -72,6 +72,12 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
     float psum[8], psq[8];  // psq: second moments for the training path's batch statistics (stats != 0)
 #pragma unroll
     for (int j = 0; j < 8; ++j) psum[j] = psq[j] = 0.0f;
+    // batch statistics (stats, not RED): moments of (y - k) with a per-channel shift k known before the launch (the running mean; NULL: 0):
+    // sum (y - k)^2 does not cancel against the squared mean when |mean| >> std.  The first moment is sum y - count k, taken at the end.
+    float kshift[8];
+    int kcount = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kshift[j] = (!RED && stats && shift) ? shift[cg * 8 + j] : 0.0f;
 
     if (item < items) {
         const int strip = item % strips;
@@ -221,7 +227,11 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
                         }
                     } else if (stats) {  // block-uniform
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) psq[j] = fmaf(v[j], v[j], psq[j]);
+                        for (int j = 0; j < 8; ++j) {
+                            const float dv = v[j] - kshift[j];
+                            psq[j] = fmaf(dv, dv, psq[j]);
+                        }
+                        ++kcount;
                     }
                     act_vec(v, d.act);
                     if (d.Cout - cg * 8 < 8) mask_tail(v, d.Cout - cg * 8);  // only the last channel group has padding
@@ -243,12 +253,12 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
         }
     }
     if (pool && stats) {
-        // training path: this block's row of the batch-statistics partials, ws[n][bx][2][Cp] = (sum y, sum y^2) of the fp32 outputs (the
-        // layout bn_finalize_kernel reads, shift 0), reduced over the R items in fixed order
+        // training path: this block's row of the batch-statistics partials, ws[n][bx][2][Cp] = (sum (y - k), sum (y - k)^2) of the fp32
+        // outputs (the layout bn_finalize_kernel reads, with the same shift k), reduced over the R items in fixed order
         for (int pass = 0; pass < 2; ++pass) {
             if (pass) __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[r * Cp + cg * 8 + j] = pass ? psq[j] : psum[j];
+            for (int j = 0; j < 8; ++j) red[r * Cp + cg * 8 + j] = pass ? psq[j] : (RED ? psum[j] : psum[j] - (float)kcount * kshift[j]);
             __syncthreads();
             for (int ch = threadIdx.x; ch < Cp; ch += blockDim.x) {
                 float s = 0.0f;
@@ -383,13 +393,14 @@ bool dw_march_red_ok(const pasn_conv_desc& d, const DwMarchGeom& g) {
 }
 
 int launch_dw_march(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool,
-                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se, int stats, const DwRedArgs* red) {
+                    const pasn_conv_desc& d, const DwMarchGeom& g, hipStream_t s, const DwSeArgs& se, int stats, const DwRedArgs* red,
+                    const float* shift) {
     const dim3 grid(g.bpc * d.N), block(g.CG * g.R);
     const size_t lds = dwm_lds_bytes(g.R, d.Cout_p, red != nullptr);
     const DwRedArgs rd = red ? *red : DwRedArgs{nullptr, nullptr, 0};
 #define PASN_DWM(SW_, WT_, RED_)                                                                                             \
     hipLaunchKernelGGL((dwconv3d_march_kernel<SW_, WT_, RED_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, \
-                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, se, stats, rd)
+                       (__bf16*)y, pool, d, g.CG, g.R, g.strips, g.Tc, g.bpc, se, stats, rd, shift)
     if (red) {  // dgrad of a stride-1 "same" conv + the producer unit's backward sums (stats layout of `pool`)
         if (!dw_march_red_ok(d, g) || !pool || !stats) {
             set_error("launch_dw_march: the fused backward sums need a stride-1 launch with a statistics buffer");

@@ -97,7 +97,7 @@ template <int RPT, bool ABLB = false, int ACT = -1, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ scale, const float* __restrict__ bias,
                                                                __bf16* __restrict__ y, float* __restrict__ pool, pasn_conv_desc d,
-                                                               DwMfmaGeom g) {
+                                                               DwMfmaGeom g, const float* __restrict__ shift) {
     constexpr int SS = 1;  // stride in H and W (the stride-2 instance of round 2 was retired: see the file header)
     extern __shared__ __attribute__((aligned(1024))) char ring[];  // [DWF_RING][NI x 1024]: frame images, position stride 160 bytes
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -145,6 +145,13 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     }
     float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float psq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // STATS: moments of (y - k) with a per-channel shift k known BEFORE the launch (the running mean): sum (y - k)^2 does not cancel
+    // against the squared mean when |mean| >> std.  NULL: k = 0.
+    float kshift[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (STATS && shift && cev) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kshift[i] = shift[ce + i];
+    }
 
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     const long fstride = (long)Hi * Wi * Cp;  // elements per frame
@@ -292,11 +299,16 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = P[l][i] * sc[i] + bs[i];
                         if (pool) {  // block-uniform
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) psum[i] += ok ? v[i] : 0.0f;
                             if (STATS) {
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) psq[i] = fmaf(ok ? v[i] : 0.0f, v[i], psq[i]);
+                                for (int i = 0; i < 4; ++i) {
+                                    const float dv = ok ? v[i] - kshift[i] : 0.0f;
+                                    psum[i] += dv;
+                                    psq[i] = fmaf(dv, dv, psq[i]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) psum[i] += ok ? v[i] : 0.0f;
                             }
                         }
                         // (a run-time activation switch per tile is ~10 scalar branches x NT per frame on a kernel bound by instruction issue)
@@ -438,19 +450,19 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
 }
 
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
-                   const DwMfmaGeom& g, hipStream_t s, int stats) {
+                   const DwMfmaGeom& g, hipStream_t s, int stats, const float* shift) {
     const dim3 grid(g.bpc * d.N), block(256);
     const size_t lds = (size_t)DWF_RING * g.NI * 1024;
     if (stats) {  // training forward: raw outputs + (sum, sum of squares) partial rows
         PASN_REQUIRE(pool && d.act == PASN_ACT_NONE && !g.abl, "dwconv3d_mfma: the statistics instance writes the raw conv output");
         if (g.RPT == 2)
-            hipLaunchKernelGGL((dwconv3d_mfma_kernel<2, false, PASN_ACT_NONE, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+            hipLaunchKernelGGL((dwconv3d_mfma_kernel<2, false, PASN_ACT_NONE, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g, shift);
         else
-            hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, false, PASN_ACT_NONE, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g);
+            hipLaunchKernelGGL((dwconv3d_mfma_kernel<1, false, PASN_ACT_NONE, true>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g, shift);
         return check_launch("dwconv3d_mfma_kernel (statistics)");
     }
 #define PASN_DWF(RPT_, ABL_, ACT_) \
-    hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g)
+    hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g, (const float*)nullptr)
     if (g.abl) PASN_DWF(1, true, -1);
     else if (g.RPT == 2) {
         if (d.act == PASN_ACT_NONE) PASN_DWF(2, false, PASN_ACT_NONE);

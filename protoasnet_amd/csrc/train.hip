@@ -87,15 +87,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restri
 // fixed order).  Per-clip pool (squeeze-excite only): a part owns whole clips, no cross-thread combine at all.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ y, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          const float* __restrict__ beta, float* rmean, float* rvar,  // (no restrict: `shift` may alias rmean)
                                                           float momentum, float eps, float* __restrict__ stat, float* __restrict__ pool_u,
-                                                          int N, int S, int C, int Cp, int chunks) {
+                                                          int N, int S, int C, int Cp, int chunks, const float* shift) {
     __shared__ float red[2][16][16];
     __shared__ float scsh[2][16];
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool live = c < Cp;
-    const float k = live && y ? (float)y[c] : 0.0f;  // y == nullptr: unshifted partials (the stencil's fused statistics)
+    // the shift the partials were taken with: y[0][0][c] (bn_stats_partial_kernel), or `shift` (the stencils' fused statistics: the running
+    // mean as it stood BEFORE this update -- read here ahead of the barrier, written below behind it), or 0
+    float k = !live ? 0.0f : y ? (float)y[c] : shift ? shift[c] : 0.0f;
+    asm volatile("" : "+v"(k));  // the value is taken HERE: `shift` may be the running mean this kernel updates behind the barrier
     float a1 = 0.0f, a2 = 0.0f;
     if (live) {
         const int total = N * chunks;
@@ -598,11 +601,11 @@ extern "C" int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, c
     if (dtype == PASN_BF16) {
         hipLaunchKernelGGL(bn_stats_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, ws, S, Cp, g.CG, g.CGb, g.rows_per_chunk, g.chunks);
         hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)y, gamma, beta, running_mean,
-                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks);
+                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr);
     } else {
         hipLaunchKernelGGL(bn_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)y, ws, S, Cp, g.CG, g.CGb, g.rows_per_chunk, g.chunks);
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const float*)y, gamma, beta, running_mean,
-                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks);
+                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr);
     }
     return check_launch("bn_stats_fwd");
 }
@@ -636,14 +639,14 @@ extern "C" int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const floa
     int rc;
     const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
     if (mf.ok && !mf.abl && mf.chunks == rows && !(getenv("PASN_DW_STATS_MFMA") && getenv("PASN_DW_STATS_MFMA")[0] == '0')) {
-        rc = launch_dw_mfma(x, w, scale, bias, y, ws, *d, mf, s, 1);
-    } else {
+        rc = launch_dw_mfma(x, w, scale, bias, y, ws, *d, mf, s, 1, running_mean);  // moments shifted by the running mean (as it stands now:
+    } else {                                                                           // the finalize kernel reads it before updating it)
         const DwMarchGeom m = dw_march_geom(*d, dtype);
-        rc = launch_dw_march(x, w, scale, bias, y, ws, *d, m, s, DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, 1);
+        rc = launch_dw_march(x, w, scale, bias, y, ws, *d, m, s, DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, 1, nullptr, running_mean);
     }
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)nullptr, gamma, beta, running_mean,
-                       running_var, momentum, eps, stat, pool_u, d->N, S, d->Cout, Cp, rows);
+                       running_var, momentum, eps, stat, pool_u, d->N, S, d->Cout, Cp, rows, (const float*)running_mean);
     return check_launch("dwconv3d_stats_fwd");
 }
 

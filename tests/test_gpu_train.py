@@ -356,6 +356,58 @@ def test_depthwise_stencil_with_fused_batch_statistics(c, s, shape, se, monkeypa
     assert torch.equal(st1, st2), "fixed summation order: bitwise reproducible statistics"
 
 
+@pytest.mark.parametrize("stencil", ["matrix-core", "valu"])
+@pytest.mark.parametrize("c,s,shape", [(54, 1, (2, 6, 14, 14)), (216, 1, (3, 5, 7, 7)), (108, 2, (2, 4, 14, 18))])
+def test_stencil_statistics_are_shifted_by_the_running_mean(c, s, shape, stencil, monkeypatch):
+    """The stencils' fused batch statistics take the moments of (y - k), k = the running mean as it stands before the step, so that
+    sum (y - k)^2 does not cancel against the squared mean: with |mean| ~ 300 std and the running mean at the batch mean (a network a few
+    steps into training) the inverse standard deviation matches torch's fp64 value to 2e-3; the same call from a running mean of zero
+    (k = 0: what the first step sees, and what every step saw before round 3) is visibly worse.  Both the matrix-core stencil with the
+    statistics epilogue (stride 1, default) and the VALU stencil (stride 2 / PASN_DWMFMA=0)."""
+    if stencil == "valu":
+        monkeypatch.setenv("PASN_DWMFMA", "0")
+    lib = _lib.lib()
+    n, t, h, w = shape
+    g = torch.Generator().manual_seed(7 * c + s)
+    x = (40.0 + 0.05 * torch.randn(n, c, t, h, w, generator=g)).bfloat16().float()
+    wt = torch.rand(c, 1, 3, 3, 3, generator=g) * 0.2 + 0.05   # positive taps: |mean(y)| >> std(y) away from the borders
+    if stencil == "matrix-core" and s == 1:
+        wt = wt.bfloat16().float()  # the matrix-core stencil's weight operands are bf16 (as every other bf16 conv's)
+    yref = F.conv3d(x.double(), wt.double(), stride=(1, s, s), padding=1, groups=c)
+    d = _desc(x, yref, (3, 3, 3), (1, s, s), (1, 1, 1))
+    cp = d.Cout_p
+    rows = lib.pasn_dwconv3d_stats_rows(ctypes.byref(d), BF16)
+    assert rows > 0
+    wp = torch.zeros(27, cp, device=DEV)
+    wp[:, :c] = wt.reshape(c, 27).t().to(DEV)
+    one, zero = torch.ones(cp, device=DEV), torch.zeros(cp, device=DEV)
+    gm, bt = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    xd = _cl(x, dtype=torch.bfloat16)
+    mean = yref.mean(dim=(0, 2, 3, 4))
+    invstd = 1.0 / torch.sqrt(yref.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5)
+
+    def run(rm0):
+        y = torch.empty(n, yref.shape[2], yref.shape[3], yref.shape[4], cp, dtype=torch.bfloat16, device=DEV)
+        stat = torch.zeros(4 * cp, device=DEV)
+        rm, rv = rm0.clone().to(DEV), torch.ones(c, device=DEV)
+        ws = torch.zeros(n * rows * 2 * cp, device=DEV)
+        _lib.check(lib.pasn_dwconv3d_stats_fwd(xd.data_ptr(), wp.data_ptr(), one.data_ptr(), zero.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                               gm.data_ptr(), bt.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, stat.data_ptr(), 0,
+                                               ctypes.byref(d), BF16, _st()))
+        torch.cuda.synchronize()
+        st = stat.view(4, cp).cpu().double()
+        return st[0, :c], st[1, :c], rm.cpu().double()
+
+    m1, i1, rm1 = run(mean.float())
+    err_shifted = float(((i1 - invstd).abs() / invstd).max())
+    assert float(((m1 - mean).abs() / mean.abs()).max()) < 1e-5
+    assert err_shifted < 2e-3, err_shifted
+    assert float(((rm1 - mean).abs() / mean.abs()).max()) < 1e-5      # 0.9 * mean + 0.1 * batch mean: the update reads the shift first
+    _, i0, _ = run(torch.zeros(c))
+    err_plain = float(((i0 - invstd).abs() / invstd).max())
+    assert err_shifted < 0.5 * err_plain or err_plain < 2e-3, (err_shifted, err_plain)
+
+
 @pytest.mark.parametrize("c,shape,act", [(54, (2, 5, 11, 13), "relu"), (432, (3, 9, 7, 7), "relu"), (108, (2, 4, 14, 28), "swish")])
 def test_depthwise_dgrad_with_fused_backward_sums(c, shape, act, monkeypatch):
     """pasn_dwconv3d_dgrad_reduce (opt-in): dx identical to the stencil dgrad (pasn_dwconv3d_fwd with reversed taps), and coef / dgamma / dbeta
