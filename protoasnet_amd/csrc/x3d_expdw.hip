@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
         constexpr int NU = (R::TILES + 1) / 2;  // expand tiles per wave, at most
         const bool lane_used = c32 < R::TP;
         unsigned keepm = 0;
-        bool all_in = true, any_in[NU];
+        bool all_in = true;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int tile = (wave >> 1) + 2 * i;
@@ -204,72 +204,80 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
             keepm |= in ? (1u << i) : 0u;
             const bool lane_counts = lane_used && tile < R::TILES;
             all_in = all_in && (__ballot(lane_counts && !in) == 0);
-            any_in[i] = __ballot(lane_counts && in) != 0;
         }
         // expand frame ti from its x tile into its ring image.  (K columns beyond the block width carry zero WEIGHTS -- the packed rows
         // are zero-padded to w_kc -- so the lanes that supply them read a real piece instead of selecting a zero fragment.)
+        // Straight-line, two tiles at a time: the fragment reads of BOTH tiles, then their MFMA chains, then the two epilogues -- with a
+        // wave-uniform branch per tile (rows of the zero padding, a wave's missing fourth tile) every tile paid an LDS round trip and an
+        // MFMA chain latency on its own (read -> wait -> MFMA -> read -> wait -> MFMA -> swap ...: ~450 cycles each, four per frame).
+        // Tiles of the padding and tiles beyond the frame run like the others (clamped addresses) and are masked at the write.
         auto produce = [&](int ti) {
             if (!staged(ti)) return;
             const char* xb = xt + slot_of(ti) * g.xtb;
             char* rb = ring + slot_of(ti) * XE_FRB;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const int tile = (wave >> 1) + 2 * i;
-                if (tile >= R::TILES) break;  // wave-uniform
-                const int pos = tile * R::TP + min(c32, R::TP - 1);
-                char* const rp = rb + (pos * XE_SLOTS + 4 * ect + h32) * 16;
-                if (!any_in[i]) {  // wave-uniform: a tile of the zero padding
-                    if (lane_used) {
+            for (int i0 = 0; i0 < NU; i0 += 2) {
+                constexpr int PAIR = 2;
+                bf16x8 xf[PAIR][KS];
+                char* rp[PAIR];
+                bool wr[PAIR];
 #pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) *reinterpret_cast<uint4*>(rp + pr * 32) = uint4{0u, 0u, 0u, 0u};
-                    }
-                    continue;
+                for (int u = 0; u < PAIR; ++u) {
+                    const int i = min(i0 + u, NU - 1);
+                    const int tile = (wave >> 1) + 2 * i;
+                    const int tl = min(tile, R::TILES - 1);
+                    const int pos = tl * R::TP + min(c32, R::TP - 1);
+                    rp[u] = rb + (pos * XE_SLOTS + 4 * ect + h32) * 16;
+                    wr[u] = lane_used && tile < R::TILES && i0 + u < NU;
+                    const char* xp = xb + pos * XS * 16;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) xf[u][ks] = *reinterpret_cast<const bf16x8*>(xp + min(2 * ks + h32, XS - 1) * 16);
                 }
-                const char* xp = xb + pos * XS * 16;
-                f32x16 acc;
+                f32x16 acc[PAIR];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + min(2 * ks + h32, XS - 1) * 16);
-                    if (ks == 0) {
-                        acc = (abl & 1) ? biasC : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[0], b, biasC, 0, 0, 0);
-                    } else if (!(abl & 1)) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], b, acc, 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int u = 0; u < PAIR; ++u) {
+                        if (abl & 1) acc[u] = biasC;
+                        else acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], xf[u][ks], ks == 0 ? biasC : acc[u], 0, 0, 0);
                     }
-                }
-                const bool keep = (keepm >> i) & 1u;
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    float v[8];
+                for (int u = 0; u < PAIR; ++u) {
+                    const bool keep = (keepm >> min(i0 + u, NU - 1)) & 1u;
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * pr + qq]), __float_as_uint(acc[8 * pr + 4 + qq]), false, false);
-                        v[qq] = __uint_as_float(sw[0]);
-                        v[4 + qq] = __uint_as_float(sw[1]);
-                    }
-                    bf16x8 o;
-                    if (abl & 2) {
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float v[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e & 1];
-                    } else {
-                        if (folded) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e], 0.0f);
-                        } else {  // separate scale / bias (this lane's 8 channels after the lane swap: 32 ect + 16 pr + 8 h32 ..)
-                            float esc[8], ebs[8];
-                            load8(scb + 32 * ect + 16 * pr + 8 * h32, esc);
-                            load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[e] + ebs[e], 0.0f);
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[u][8 * pr + qq]), __float_as_uint(acc[u][8 * pr + 4 + qq]), false, false);
+                            v[qq] = __uint_as_float(sw[0]);
+                            v[4 + qq] = __uint_as_float(sw[1]);
                         }
+                        bf16x8 o;
+                        if (abl & 2) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e & 1];
+                        } else {
+                            if (folded) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e], 0.0f);
+                            } else {  // separate scale / bias (this lane's 8 channels after the lane swap: 32 ect + 16 pr + 8 h32 ..)
+                                float esc[8], ebs[8];
+                                load8(scb + 32 * ect + 16 * pr + 8 * h32, esc);
+                                load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[e] + ebs[e], 0.0f);
+                            }
+                        }
+                        xe_u32x4 ou = __builtin_bit_cast(xe_u32x4, o);
+                        if (!all_in) {  // wave-uniform: only regions on the image border select (incl. whole tiles of the zero padding)
+                            ou.x = keep ? ou.x : 0u;
+                            ou.y = keep ? ou.y : 0u;
+                            ou.z = keep ? ou.z : 0u;
+                            ou.w = keep ? ou.w : 0u;
+                        }
+                        if (wr[u]) *reinterpret_cast<xe_u32x4*>(rp[u] + pr * 32) = ou;
                     }
-                    xe_u32x4 ou = __builtin_bit_cast(xe_u32x4, o);
-                    if (!all_in) {  // wave-uniform: only regions on the image border select
-                        ou.x = keep ? ou.x : 0u;
-                        ou.y = keep ? ou.y : 0u;
-                        ou.z = keep ? ou.z : 0u;
-                        ou.w = keep ? ou.w : 0u;
-                    }
-                    if (lane_used) *reinterpret_cast<xe_u32x4*>(rp + pr * 32) = ou;
                 }
             }
         };
