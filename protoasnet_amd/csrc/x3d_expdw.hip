@@ -25,6 +25,9 @@
 namespace pasn {
 
 typedef __attribute__((ext_vector_type(4))) unsigned xe_u32x4;
+typedef __attribute__((ext_vector_type(2))) short xe_s16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 xe_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float xe_f32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned xe_u32x2;
 typedef __attribute__((address_space(3))) void* xe_lds_ptr_t;
 
@@ -244,32 +247,27 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
 #pragma unroll
                 for (int u = 0; u < PAIR; ++u) {
                     const bool keep = (keepm >> min(i0 + u, NU - 1)) & 1u;
+                    // ReLU and the bf16 rounding BEFORE the lane swap, on packed pairs: v_cvt_pk_bf16_f32 + v_pk_max_i16 (a bf16 is
+                    // negative iff it is negative as an int16; rounding keeps the sign, so max(round(v), 0) == round(max(v, 0)) and
+                    // -0 becomes +0 either way) and half the swaps -- 14 vector instructions per 8 x 64 outputs where the float path
+                    // (swap, canonicalise, max, convert) took 34, on a kernel bound by vector issue.
+                    unsigned P[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xe_f32x2 a = {acc[u][2 * j], acc[u][2 * j + 1]};
+                        if (!folded) {  // separate scale / bias: rows acc_row(2j, h32), +1 of this lane's 16 (before the swap)
+                            a.x = a.x * scb[32 * ect + acc_row(2 * j, h32)] + scb[64 + 32 * ect + acc_row(2 * j, h32)];
+                            a.y = a.y * scb[32 * ect + acc_row(2 * j + 1, h32)] + scb[64 + 32 * ect + acc_row(2 * j + 1, h32)];
+                        }
+                        xe_s16x2 m = __builtin_bit_cast(xe_s16x2, __builtin_convertvector(a, xe_bf16x2));  // one v_cvt_pk_bf16_f32
+                        if (!(abl & 2)) m = __builtin_elementwise_max(m, xe_s16x2{0, 0});
+                        P[j] = __builtin_bit_cast(unsigned, m);
+                    }
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
-                        float v[8];
-#pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) {
-                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[u][8 * pr + qq]), __float_as_uint(acc[u][8 * pr + 4 + qq]), false, false);
-                            v[qq] = __uint_as_float(sw[0]);
-                            v[4 + qq] = __uint_as_float(sw[1]);
-                        }
-                        bf16x8 o;
-                        if (abl & 2) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e & 1];
-                        } else {
-                            if (folded) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e], 0.0f);
-                            } else {  // separate scale / bias (this lane's 8 channels after the lane swap: 32 ect + 16 pr + 8 h32 ..)
-                                float esc[8], ebs[8];
-                                load8(scb + 32 * ect + 16 * pr + 8 * h32, esc);
-                                load8(scb + 64 + 32 * ect + 16 * pr + 8 * h32, ebs);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e] * esc[e] + ebs[e], 0.0f);
-                            }
-                        }
-                        xe_u32x4 ou = __builtin_bit_cast(xe_u32x4, o);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(P[4 * pr + 0], P[4 * pr + 2], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(P[4 * pr + 1], P[4 * pr + 3], false, false);
+                        xe_u32x4 ou = {s0[0], s1[0], s0[1], s1[1]};  // this lane's 8 consecutive channels 32 ect + 16 pr + 8 h32 ..
                         if (!all_in) {  // wave-uniform: only regions on the image border select (incl. whole tiles of the zero padding)
                             ou.x = keep ? ou.x : 0u;
                             ou.y = keep ? ou.y : 0u;

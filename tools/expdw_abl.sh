@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for A in "$@"; do
-  if [ "$A" != "0" ]; then export PASN_EXPDW_ABL=$A; else unset PASN_EXPDW_ABL; fi
+  if [ "$A" != "0" ]; then export PASN_EXPDW_ABL=$A PASN_EXPDW_S1=0; else unset PASN_EXPDW_ABL PASN_EXPDW_S1; fi  # (the ablation instances exist at stride 2 only)
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_xe -o p -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-clips 0 --no-secondary --no-roofline > $R/gpurun_out/prof_xe.log 2>&1 || true
   f=$(find $R/gpurun_out/prof_xe -name "*kernel_stats.csv" | head -1)
   echo "abl=$A $(python3 -c "
