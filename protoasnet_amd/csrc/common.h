@@ -310,9 +310,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each); an IEEE division here costs ~10 VALU instructions per element
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// ReLU as a signed-integer max on the bit pattern (a float is negative iff its bits are a negative int32): ONE v_max_i32.  fmaxf costs
+// two vector instructions wherever the compiler cannot prove its operand free of signalling NaNs (a value that went through a lane swap or
+// a run-time activation switch: v_max_f32 v, v, v to quieten it first) -- 8 of ~50 per 8 outputs in epilogues bound by vector issue.
+// -0 -> +0; a NaN with the sign bit clear passes through (as torch.relu propagates it), one with the sign bit set becomes 0.
+__device__ __forceinline__ float relu_f32(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
-        case PASN_ACT_RELU: return fmaxf(v, 0.0f);
+        case PASN_ACT_RELU: return relu_f32(v);
         case PASN_ACT_SIGMOID: return sigmoidf_(v);
         case PASN_ACT_SWISH: return v * sigmoidf_(v);
         case PASN_ACT_ABS: return fabsf(v);
@@ -344,7 +349,7 @@ __device__ __forceinline__ void act_vec(float (&v)[N], int act) {
     switch (act) {
         case PASN_ACT_RELU:
 #pragma unroll
-            for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.0f);
+            for (int j = 0; j < N; ++j) v[j] = relu_f32(v[j]);
             break;
         case PASN_ACT_SIGMOID:
 #pragma unroll

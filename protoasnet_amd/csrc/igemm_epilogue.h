@@ -27,7 +27,7 @@ template <int ACT, int N>
 __device__ __forceinline__ void igemm_act(float (&v)[N], int act) {
     if constexpr (ACT == PASN_ACT_RELU) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.0f);
+        for (int e = 0; e < N; ++e) v[e] = relu_f32(v[e]);
     } else if constexpr (ACT != PASN_ACT_NONE) {
         act_vec(v, act);
     }

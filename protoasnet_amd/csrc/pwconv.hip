@@ -26,7 +26,7 @@ template <int ACTC, int N>
 __device__ __forceinline__ void act_vec_c(float (&v)[N], int act) {
     if constexpr (ACTC == PASN_ACT_RELU) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.0f);
+        for (int j = 0; j < N; ++j) v[j] = relu_f32(v[j]);
     } else {
         act_vec(v, act);
     }
