@@ -147,6 +147,7 @@ struct XeGeom {
     int CQ, RTH, RTW;               // 64-channel quads, regions (3 x 14 outputs) per frame
     int Tc, nT, upb, chunks, bpc;   // T chunk (+count), units per block, SE partial rows per clip, blocks per clip
     int abl;                        // timing ablations (PASN_EXPDW_ABL; results are wrong when set)
+    int fuse;                       // steady-state step as one scheduling region (PASN_EXPDW_FUSE=0: expand, then stencil)
 };
 XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype);
 int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     char* const xt = smem + 2 * XE_FRB;                               // [2][g.xtb] x rows of the region: [position][XS slots]
     float* const scb = reinterpret_cast<float*>(xt + 2 * g.xtb);      // [2][64] expand scale | bias of this quad
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const dummy = reinterpret_cast<char*>(scb) + 512 + lane * 16;  // [64 x 16 + 32] where lanes without a position put their stores (never read)
     const int m = lane & 15, q = lane >> 4;   // stencil roles
     const int c32 = lane & 31, h32 = lane >> 5;  // expand roles
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     const bool wave_live = c0 < Cp;
     const bool wave_tail = c0 + 16 > d.Cout;
     const int XS = g.XS, pieces = Cin_p >> 3;
+    const bool fuse = g.fuse != 0;
     const int abl = ABLB ? g.abl : 0;  // 1: no expand MFMAs, 2: no expand epilogue arithmetic, 4: no x DMA, 8: no stencil MFMAs, 16: no output epilogue / stores
 
     // ---- stencil: block-diagonal weight operands (dwmfma.hip) ----
@@ -210,73 +212,79 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
         }
         // expand frame ti from its x tile into its ring image.  (K columns beyond the block width carry zero WEIGHTS -- the packed rows
         // are zero-padded to w_kc -- so the lanes that supply them read a real piece instead of selecting a zero fragment.)
+        // The three parts of expand tile i of this wave (tile (wave >> 1) + 2 i of the frame), shared by produce() and by the fused step:
+        // p_read: the x fragments; p_mma: the chain of KS 32x32x16 MFMAs; p_epi: ReLU + rounding + lane swap + border mask + 2 ds_write_b128.
+        // Lanes / tiles that hold nothing (lanes 29-31 at stride 2, the fourth tile of waves 2 and 3) run like the others on clamped
+        // addresses and store into a dummy region instead of branching around the store (a branch ends the scheduling region).
+        auto p_read = [&](int i, const char* xb, bf16x8 (&xf)[KS]) {
+            const int tile = (wave >> 1) + 2 * i;
+            const int tl = min(tile, R::TILES - 1);
+            const int pos = tl * R::TP + min(c32, R::TP - 1);
+            const char* xp = xb + pos * XS * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + min(2 * ks + h32, XS - 1) * 16);
+        };
+        auto p_mma = [&](const bf16x8 (&xf)[KS], f32x16& acc) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (abl & 1) acc = biasC;
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], xf[ks], ks == 0 ? biasC : acc, 0, 0, 0);
+            }
+        };
+        auto p_epi = [&](int i, char* rb, const f32x16& acc) {
+            const int tile = (wave >> 1) + 2 * i;
+            const int tl = min(tile, R::TILES - 1);
+            const int pos = tl * R::TP + min(c32, R::TP - 1);
+            const bool wr = lane_used && tile < R::TILES;
+            char* const rp = wr ? rb + (pos * XE_SLOTS + 4 * ect + h32) * 16 : dummy;
+            const bool keep = (keepm >> i) & 1u;
+            // ReLU and the bf16 rounding BEFORE the lane swap, on packed pairs: v_cvt_pk_bf16_f32 + v_pk_max_i16 (a bf16 is
+            // negative iff it is negative as an int16; rounding keeps the sign, so max(round(v), 0) == round(max(v, 0)) and
+            // -0 becomes +0 either way) and half the swaps -- 14 vector instructions per 8 x 64 outputs where the float path
+            // (swap, canonicalise, max, convert) took 34, on a kernel bound by vector issue.
+            unsigned P[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xe_f32x2 a = {acc[2 * j], acc[2 * j + 1]};
+                if (!folded) {  // separate scale / bias: rows acc_row(2j, h32), +1 of this lane's 16 (before the swap)
+                    a.x = a.x * scb[32 * ect + acc_row(2 * j, h32)] + scb[64 + 32 * ect + acc_row(2 * j, h32)];
+                    a.y = a.y * scb[32 * ect + acc_row(2 * j + 1, h32)] + scb[64 + 32 * ect + acc_row(2 * j + 1, h32)];
+                }
+                xe_s16x2 m = __builtin_bit_cast(xe_s16x2, __builtin_convertvector(a, xe_bf16x2));  // one v_cvt_pk_bf16_f32
+                if (!(abl & 2)) m = __builtin_elementwise_max(m, xe_s16x2{0, 0});
+                P[j] = __builtin_bit_cast(unsigned, m);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(P[4 * pr + 0], P[4 * pr + 2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(P[4 * pr + 1], P[4 * pr + 3], false, false);
+                xe_u32x4 ou = {s0[0], s1[0], s0[1], s1[1]};  // this lane's 8 consecutive channels 32 ect + 16 pr + 8 h32 ..
+                if (!all_in) {  // wave-uniform: only regions on the image border select (incl. whole tiles of the zero padding)
+                    ou.x = keep ? ou.x : 0u;
+                    ou.y = keep ? ou.y : 0u;
+                    ou.z = keep ? ou.z : 0u;
+                    ou.w = keep ? ou.w : 0u;
+                }
+                *reinterpret_cast<xe_u32x4*>(rp + pr * 32) = ou;
+            }
+        };
         // Straight-line, two tiles at a time: the fragment reads of BOTH tiles, then their MFMA chains, then the two epilogues -- with a
         // wave-uniform branch per tile (rows of the zero padding, a wave's missing fourth tile) every tile paid an LDS round trip and an
         // MFMA chain latency on its own (read -> wait -> MFMA -> read -> wait -> MFMA -> swap ...: ~450 cycles each, four per frame).
-        // Tiles of the padding and tiles beyond the frame run like the others (clamped addresses) and are masked at the write.
         auto produce = [&](int ti) {
             if (!staged(ti)) return;
             const char* xb = xt + slot_of(ti) * g.xtb;
             char* rb = ring + slot_of(ti) * XE_FRB;
 #pragma unroll
             for (int i0 = 0; i0 < NU; i0 += 2) {
-                constexpr int PAIR = 2;
-                bf16x8 xf[PAIR][KS];
-                char* rp[PAIR];
-                bool wr[PAIR];
-#pragma unroll
-                for (int u = 0; u < PAIR; ++u) {
-                    const int i = min(i0 + u, NU - 1);
-                    const int tile = (wave >> 1) + 2 * i;
-                    const int tl = min(tile, R::TILES - 1);
-                    const int pos = tl * R::TP + min(c32, R::TP - 1);
-                    rp[u] = rb + (pos * XE_SLOTS + 4 * ect + h32) * 16;
-                    wr[u] = lane_used && tile < R::TILES && i0 + u < NU;
-                    const char* xp = xb + pos * XS * 16;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) xf[u][ks] = *reinterpret_cast<const bf16x8*>(xp + min(2 * ks + h32, XS - 1) * 16);
-                }
-                f32x16 acc[PAIR];
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int u = 0; u < PAIR; ++u) {
-                        if (abl & 1) acc[u] = biasC;
-                        else acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AE[ks], xf[u][ks], ks == 0 ? biasC : acc[u], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int u = 0; u < PAIR; ++u) {
-                    const bool keep = (keepm >> min(i0 + u, NU - 1)) & 1u;
-                    // ReLU and the bf16 rounding BEFORE the lane swap, on packed pairs: v_cvt_pk_bf16_f32 + v_pk_max_i16 (a bf16 is
-                    // negative iff it is negative as an int16; rounding keeps the sign, so max(round(v), 0) == round(max(v, 0)) and
-                    // -0 becomes +0 either way) and half the swaps -- 14 vector instructions per 8 x 64 outputs where the float path
-                    // (swap, canonicalise, max, convert) took 34, on a kernel bound by vector issue.
-                    unsigned P[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        xe_f32x2 a = {acc[u][2 * j], acc[u][2 * j + 1]};
-                        if (!folded) {  // separate scale / bias: rows acc_row(2j, h32), +1 of this lane's 16 (before the swap)
-                            a.x = a.x * scb[32 * ect + acc_row(2 * j, h32)] + scb[64 + 32 * ect + acc_row(2 * j, h32)];
-                            a.y = a.y * scb[32 * ect + acc_row(2 * j + 1, h32)] + scb[64 + 32 * ect + acc_row(2 * j + 1, h32)];
-                        }
-                        xe_s16x2 m = __builtin_bit_cast(xe_s16x2, __builtin_convertvector(a, xe_bf16x2));  // one v_cvt_pk_bf16_f32
-                        if (!(abl & 2)) m = __builtin_elementwise_max(m, xe_s16x2{0, 0});
-                        P[j] = __builtin_bit_cast(unsigned, m);
-                    }
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(P[4 * pr + 0], P[4 * pr + 2], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(P[4 * pr + 1], P[4 * pr + 3], false, false);
-                        xe_u32x4 ou = {s0[0], s1[0], s0[1], s1[1]};  // this lane's 8 consecutive channels 32 ect + 16 pr + 8 h32 ..
-                        if (!all_in) {  // wave-uniform: only regions on the image border select (incl. whole tiles of the zero padding)
-                            ou.x = keep ? ou.x : 0u;
-                            ou.y = keep ? ou.y : 0u;
-                            ou.z = keep ? ou.z : 0u;
-                            ou.w = keep ? ou.w : 0u;
-                        }
-                        if (wr[u]) *reinterpret_cast<xe_u32x4*>(rp[u] + pr * 32) = ou;
-                    }
-                }
+                bf16x8 xf0[KS], xf1[KS];
+                f32x16 acc0, acc1;
+                p_read(i0, xb, xf0);
+                if (i0 + 1 < NU) p_read(i0 + 1, xb, xf1);
+                p_mma(xf0, acc0);
+                if (i0 + 1 < NU) p_mma(xf1, acc1);
+                p_epi(i0, rb, acc0);
+                if (i0 + 1 < NU) p_epi(i0 + 1, rb, acc1);
             }
         };
 
@@ -334,6 +342,8 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                     N[l] = zero4;
                 }
             }
+        };
+        auto emit = [&](int ti, f32x4 (&P)[XE_NT]) {  // output frame ti - 1 has now seen frames ti - 2, ti - 1, ti
             const int to = ti - 1;
             if (wave_live && to >= t0 && to < t1 && !(abl & 16)) {
                 const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yclip + (long)to * ofs, 0, fr_bytes, 0x00020000);
@@ -362,6 +372,93 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
             }
         };
 
+        // The steady-state step as ONE scheduling region: the expand conv of frame ti + 1 (LDS reads, two 32x32x16 chains and ~60 vector
+        // instructions per pair of tiles) is issued between the stencil MFMAs of frame ti, which leave the vector ALU idle for 16 cycles
+        // each -- back to back the two halves left each wave waiting ~60 % of its time with two waves per SIMD (SQ counters: MFMA pipe
+        // 31 %, VALU 21 % busy).  Pair p rides under stencil tile p.
+        auto fused = [&](int ti, f32x4 (&P)[XE_NT], f32x4 (&C)[XE_NT], f32x4 (&N)[XE_NT]) {
+            static_assert(SS != 2 || (NU == 4 && XE_NT == 3), "the pinned schedule below is written for 4 expand tiles under 3 stencil tiles");
+            const char* xb = xt + slot_of(ti + 1) * g.xtb;
+            char* rb = ring + slot_of(ti + 1) * XE_FRB;
+            int fbo = slot_of(ti) * XE_FRB + lbase0;
+            asm volatile("" : "+v"(fbo));
+            const char* ta[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ta[j] = ring + fbo + tapoff[j];
+            bf16x8 Bq[2][5];
+            bf16x8 xf[KS];
+            f32x16 acc;
+            unsigned Pk[8];
+            // the expand epilogue of tile i in ten steps: eight packed convert + ReLU pairs, two (lane swap, border mask, store) halves
+            auto e_cvt = [&](int j) {
+                xe_f32x2 a = {acc[2 * j], acc[2 * j + 1]};
+                if (!folded) {
+                    a.x = a.x * scb[32 * ect + acc_row(2 * j, h32)] + scb[64 + 32 * ect + acc_row(2 * j, h32)];
+                    a.y = a.y * scb[32 * ect + acc_row(2 * j + 1, h32)] + scb[64 + 32 * ect + acc_row(2 * j + 1, h32)];
+                }
+                xe_s16x2 mm = __builtin_bit_cast(xe_s16x2, __builtin_convertvector(a, xe_bf16x2));
+                mm = __builtin_elementwise_max(mm, xe_s16x2{0, 0});
+                Pk[j] = __builtin_bit_cast(unsigned, mm);
+            };
+            auto e_out = [&](int i, int pr) {
+                const int tile = (wave >> 1) + 2 * i;
+                const int tl = min(tile, R::TILES - 1);
+                const int pos = tl * R::TP + min(c32, R::TP - 1);
+                const bool wr = lane_used && tile < R::TILES;
+                char* const rp = wr ? rb + (pos * XE_SLOTS + 4 * ect + h32) * 16 : dummy;
+                const bool keep = (keepm >> i) & 1u;
+                const auto s0 = __builtin_amdgcn_permlane32_swap(Pk[4 * pr + 0], Pk[4 * pr + 2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(Pk[4 * pr + 1], Pk[4 * pr + 3], false, false);
+                xe_u32x4 ou = {s0[0], s1[0], s0[1], s1[1]};
+                if (!all_in) {
+                    ou.x = keep ? ou.x : 0u;
+                    ou.y = keep ? ou.y : 0u;
+                    ou.z = keep ? ou.z : 0u;
+                    ou.w = keep ? ou.w : 0u;
+                }
+                *reinterpret_cast<xe_u32x4*>(rp + pr * 32) = ou;
+            };
+            p_read(0, xb, xf);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            p_mma(xf, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            // 45 stencil MFMAs (16 cycles of the matrix pipe each); behind MFMA g, fenced, the vector work of slot g: expand tile E (0..3)
+            // converts in slots 9E+2 .. 9E+5 (its chain was issued 4 slots earlier), the next chain goes out in slot 9E+6 with E's first
+            // store half, the second half and the next tile's fragment reads follow in slot 9E+7
+#pragma unroll
+            for (int gq = 0; gq < 15 * XE_NT; ++gq) {
+                const int l = gq / 15, j = (gq % 15) / 3, role = gq % 3;
+                const bf16x8 B = Bq[l & 1][j];
+                if (role == 0) P[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, j == 0 ? C[l] : P[l], 0, 0, 0);
+                if (role == 1) C[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, j == 0 ? N[l] : C[l], 0, 0, 0);
+                if (role == 2) N[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : N[l], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int E = gq / 9, r = gq % 9;
+                if (gq % 15 == 0 && l + 1 < XE_NT) {  // the next stencil tile's operands (its buffer was last read one tile ago)
+#pragma unroll
+                    for (int jj = 0; jj < 5; ++jj) Bq[(l + 1) & 1][jj] = *reinterpret_cast<const bf16x8*>(ta[jj] + (l + 1) * lstep);
+                }
+                if (E < NU) {
+                    if (r >= 2 && r <= 5) {
+                        e_cvt(2 * (r - 2));
+                        e_cvt(2 * (r - 2) + 1);
+                    }
+                    if (r == 6) {
+                        if (E + 1 < NU) p_mma(xf, acc);
+                        e_out(E, 0);
+                    }
+                    if (r == 7) {
+                        e_out(E, 1);
+                        if (E + 2 < NU) p_read(E + 2, xb, xf);
+                    }
+                    if (r == 0 && E == 0) p_read(1, xb, xf);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
         // prologue: frame t0 - 1 expanded, x rows of frame t0 requested
         issue_x(t0 - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -374,9 +471,16 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
             // have, frame ti's image (written in step ti - 1) is complete, and nobody still reads the image / x tile of frame ti - 1
             xe_wait_all_but(stored(ti - 2));
             xe_barrier();
-            produce(ti + 1);
-            issue_x(ti + 2);
-            frame(ti, S0, S1, S2);
+            if (SS == 2 && staged(ti + 1) && wave_live && ti >= 0 && ti < Ti && !(abl & 8) && fuse) {  // wave-uniform: the steady state (stride 1: 6 stencil tiles' accumulators leave no room, 66 spilled VGPRs)
+                issue_x(ti + 2);  // (its x tile held frame ti: everyone is past produce(ti))
+                fused(ti, S0, S1, S2);
+                emit(ti, S0);
+            } else {
+                produce(ti + 1);
+                issue_x(ti + 2);
+                frame(ti, S0, S1, S2);
+                emit(ti, S0);
+            }
         }
         __syncthreads();
     }
@@ -433,7 +537,8 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     g.KS = 2;
     g.XS = (de.Cin_p / 8) | 1;
     g.xtb = ((POS + 3) * g.XS * 16 + 1023) / 1024 * 1024;  // + 3 positions: lanes 29 .. 31 of the last staged row read past it (stride 2)
-    g.lds = 2 * FRB + 2 * g.xtb + 512;
+    g.fuse = !(getenv("PASN_EXPDW_FUSE") && getenv("PASN_EXPDW_FUSE")[0] == '0');
+    g.lds = 2 * FRB + 2 * g.xtb + 512 + 1088;
     // two blocks per CU: block width 24 takes 78.5 KB.  (48 channels -- stage 4's first block -- need 107 KB = one block per CU: built,
     // correct, and slower end to end, 10.37 k vs 10.58 k clips/s: not taken.)
     if (g.lds > 80 * 1024 || (POS * g.XS + 63) / 64 > 4 * XE_NE) return XeGeom{};
