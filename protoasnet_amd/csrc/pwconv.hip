@@ -244,11 +244,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 2 &&
                         gv[j + 3] = q[3];
                     }
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        float v = (float)Bc[ks][j] * gv[j];
-                        if (in_swish) v = v * sigmoidf_(v);
-                        Bc[ks][j] = (T)v;
+                    for (int j = 0; j < CH; ++j) gv[j] *= (float)Bc[ks][j];
+                    if (in_swish) {  // one wave-uniform branch around the piece (inside the element loop it compiles to a select per element)
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) gv[j] = gv[j] * sigmoidf_(gv[j]);
                     }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) Bc[ks][j] = (T)gv[j];
                 }
             }
         }

@@ -200,12 +200,15 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
                 const float* gp = gl + ((r0 + r >= S) ? GPR * 4 : 0) + p * 8;
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
                 if (!(abl & 8)) {
+                    float f[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float f = (float)v[e] * (e < 4 ? g0[e & 3] : g1[e & 3]);
-                        if (in_swish) f = f * sigmoidf_(f);
-                        v[e] = (__bf16)f;
+                    for (int e = 0; e < 8; ++e) f[e] = (float)v[e] * (e < 4 ? g0[e & 3] : g1[e & 3]);
+                    if (in_swish) {  // ONE wave-uniform branch around the eight: inside the element loop it compiled to eight selects
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = f[e] * sigmoidf_(f[e]);
                     }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)f[e];
                 }
                 *reinterpret_cast<bf16x8*>(sb + idx * 16) = v;
             }

@@ -120,11 +120,13 @@ void pwconv_xpair_kernel(const __bf16* __restrict__ x, const __bf16* __restrict_
                 for (int i = 0; i < 4; ++i) gq[j + i] = q4[i];
             }
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                float f = (float)e[j] * gq[j];
-                if (in_swish) f = f * sigmoidf_(f);
-                e[j] = (__bf16)f;
+            for (int j = 0; j < CH; ++j) gq[j] *= (float)e[j];
+            if (in_swish) {  // one wave-uniform branch around the piece (inside the element loop it compiles to a select per element)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) gq[j] = gq[j] * sigmoidf_(gq[j]);
             }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) e[j] = (__bf16)gq[j];
         }
         *reinterpret_cast<uint4*>(xs + (size_t)prow * KP1 + pcol * CH) = xv;
     }
