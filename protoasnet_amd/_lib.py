@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_long, 
 F32, BF16, U8 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "swish": 3, "abs": 4}
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libprotoasnet_amd.so")
+# (PASN_LIB_PATH: another build of the same C-ABI library -- A/B runs of two commits on one GPU box, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("PASN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libprotoasnet_amd.so")
 
 
 class ConvDesc(ctypes.Structure):
