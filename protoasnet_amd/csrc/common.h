@@ -174,7 +174,6 @@ int igemm_halo_mode(const pasn_conv_desc& d);
 bool igemm_halo_fits(const pasn_conv_desc& d, int mode, int nt, int mt);
 int launch_igemm_halo(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,
                       const pasn_conv_desc& d, int mode, int nt, int mt, hipStream_t s);
-int igemm_direct_epilogue();  // 1: accumulators -> registers -> 16-byte stores (default); PASN_IGEMM_EPI=image: through the LDS image
 int launch_igemm(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y,
                  const pasn_conv_desc& d, int nt, hipStream_t s);
 template <typename T>

@@ -33,7 +33,7 @@ template <int NT, int MT>
 __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
                                                             const __bf16* __restrict__ res, __bf16* __restrict__ y, pasn_conv_desc d,
-                                                            int scb_off, int direct) {
+                                                            int scb_off) {
     constexpr int BN = NT * 32, IG_BM = 128 * MT, XG = 2 * MT;  // XG: 16-row DMA groups of the activation tile per wave
     constexpr int XBYTES = IG_BM * 64, WBYTES = BN * 64, STAGE = XBYTES + WBYTES;
     constexpr int WGROUPS = BN / 16;               // 16-row DMA groups of the weight tile
@@ -180,22 +180,17 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
     }
 
     // ---- epilogue: scale / bias -> wave-private LDS image of 32 positions x BN channels -> residual + activation + whole-row stores ----
-    __bf16* img = reinterpret_cast<__bf16*>(smem) + (size_t)wave * 32 * OROW;
     const int width = min(BN, Cout_p - n0);  // channels of this block that exist (multiple of 8)
     const int cgs = width / 8;
     auto tile_rows = [&](int j, long& mbase, int& nvalid) {
         mbase = m0 + wave * MT * 32 + j * 32;
         nvalid = (int)max(0L, min((long)32, M - mbase));
     };
-    if (direct) igemm_epilogue_direct<NT, MT>(acc, scb, res, y, n0, cgs, d, lane, tile_rows);  // block-uniform
-    else igemm_epilogue<NT, MT>(acc, img, scb, res, y, n0, cgs, d, lane, tile_rows);
+    // (the LDS-image epilogue is no longer compiled into these kernels: a second epilogue body behind a run-time flag cost them ~2 %,
+    // profiles/README entries 92 / 94; the MFMA stems still use it)
+    igemm_epilogue_direct<NT, MT>(acc, scb, res, y, n0, cgs, d, lane, tile_rows);
 }
 
-// Epilogue without the LDS image (igemm_epilogue.h); PASN_IGEMM_EPI=image keeps the wave-private image + whole-row stores (A/B switch)
-int igemm_direct_epilogue() {
-    const char* e = getenv("PASN_IGEMM_EPI");
-    return !(e && e[0] == 'i');
-}
 
 // Instance for this layer: NT channel tiles per block in the low decimal digit, MT position tiles per wave in the next; 0 = not this kernel.
 int igemm_nt(const pasn_conv_desc& d, int dtype) {
@@ -246,7 +241,7 @@ int launch_igemm(const void* x, const void* w, const float* scale, const float* 
         const size_t scb_off = tiles > image ? tiles : image, lds = scb_off + (size_t)NT_ * 32 * 8;                           \
         if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_glds_kernel<NT_, MT_>);                                            \
         hipLaunchKernelGGL((igemm_glds_kernel<NT_, MT_>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale, bias, \
-                           (const __bf16*)res, (__bf16*)y, dk, (int)scb_off, igemm_direct_epilogue());                        \
+                           (const __bf16*)res, (__bf16*)y, dk, (int)scb_off);                        \
         return check_launch("igemm_glds_kernel");                                                                             \
     }
     PASN_IG(2, 4)

@@ -37,7 +37,7 @@ template <int NT, int MT, int MODE, int ABL = 0, bool SP = false>  // ABL: timin
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
                                                             const __bf16* __restrict__ res, __bf16* __restrict__ y, pasn_conv_desc d,
-                                                            int rows16, int scb_off, int direct) {
+                                                            int rows16, int scb_off) {
     constexpr int BN = NT * 32, BM = 128 * MT, BT = 4 * MT;
     constexpr bool PIPE = PASN_HALO_PIPE;
     constexpr int WBYTES = BN * 64, WGROUPS = BN / 16;
@@ -299,7 +299,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
 
     // ---- epilogue: scale / bias -> wave-private LDS image of 32 positions x BN channels -> residual + activation + whole-row stores ----
     if ((ABL & 8) && acc[0][0][0] != 1.2345f) return;
-    __bf16* img = reinterpret_cast<__bf16*>(smem) + (size_t)wave * 32 * OROW;
     const int width = min(BN, Cout_p - n0);  // channels of this block that exist (multiple of 8)
     const int cgs = width / 8;
     auto tile_rows = [&](int j, long& mbase, int& nvalid) {  // rows of tile j that are output positions
@@ -312,8 +311,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
             nvalid = t < T ? min(32, FR - p0) : 0;
         }
     };
-    if (direct) igemm_epilogue_direct<NT, MT>(acc, scb, res, y, n0, cgs, d, lane, tile_rows);  // block-uniform
-    else igemm_epilogue<NT, MT>(acc, img, scb, res, y, n0, cgs, d, lane, tile_rows);
+    // (the LDS-image epilogue is no longer compiled into these kernels: a second epilogue body behind a run-time flag cost them ~2 %,
+    // profiles/README entries 92 / 94; the MFMA stems still use it)
+    igemm_epilogue_direct<NT, MT>(acc, scb, res, y, n0, cgs, d, lane, tile_rows);
 }
 
 // Geometry of the halo tile for this layer: tile rows (padded to 16) or 0 when the layer is not a stride-1 "same" (1,k,k) / (3,1,1) conv
@@ -362,7 +362,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
     if (nt == NT_ && mt == MT_ && mode == MODE_ + 1) {                                                                            \
         if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_halo_kernel<NT_, MT_, MODE_>);                                         \
         hipLaunchKernelGGL((igemm_halo_kernel<NT_, MT_, MODE_>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale,  \
-                           bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off, igemm_direct_epilogue());                                               \
+                           bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                                               \
         return check_launch("igemm_halo_kernel");                                                                                 \
     }
     if (const char* e = getenv("PASN_HALO_ABL")) {  // timing-only builds of the 160-channel spatial instance
@@ -371,7 +371,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
         if (abl == A_ && nt == 5 && mt == 2 && mode == 1) {                                                                       \
             PASN_MAX_LDS(96 * 1024, igemm_halo_kernel<5, 2, 0, A_>);                                                              \
             hipLaunchKernelGGL((igemm_halo_kernel<5, 2, 0, A_>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale,  \
-                               bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off, igemm_direct_epilogue());                                           \
+                               bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                                           \
             return check_launch("igemm_halo_kernel");                                                                             \
         }
         PASN_IHA(1) PASN_IHA(2) PASN_IHA(4) PASN_IHA(8) PASN_IHA(3) PASN_IHA(15) PASN_IHA(16)
@@ -381,7 +381,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
     if (sp && nt == NT_ && mt == MT_) {                                                                                           \
         if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_halo_kernel<NT_, MT_, 1, 0, true>);                                    \
         hipLaunchKernelGGL((igemm_halo_kernel<NT_, MT_, 1, 0, true>), grid, block, lds, s, (const __bf16*)x, (const __bf16*)w, scale, \
-                           bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off, igemm_direct_epilogue());                   \
+                           bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                   \
         return check_launch("igemm_halo_kernel (slice pipeline)");                                                                \
     }
     PASN_IHS(2, 2) PASN_IHS(2, 1) PASN_IHS(4, 1)

@@ -77,7 +77,11 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
     const int PPR = Cin_p >> 3;
     const int RPL = (Cout_p >> 3) | 1;  // 16-byte slots per staged residual row (odd)
     const unsigned xrow = (unsigned)Cin_p * 2u, yrow = (unsigned)Cout_p * 2u;
-    const int abl = g.abl;  // timing ablations (PASN_WS_ABL; results are wrong when set)
+#ifdef PASN_WS_ABLATE
+    const int abl = g.abl;  // timing ablations (PASN_WS_ABL; results are wrong when set) -- a build with -DPASN_WS_ABLATE only (tools/ws_abl.sh)
+#else
+    constexpr int abl = 0;  // (as a run-time value its tests sat in front of every store and DMA group of the product kernel)
+#endif
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, row1 * xrow, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, row1 * yrow, 0x00020000);

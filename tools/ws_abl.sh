@@ -1,5 +1,6 @@
 # pwconv_ws kernel time per step under its timing ablations (PASN_WS_ABL bits: 1 MFMAs, 2 output stores, 4 x DMA, 8 input transform, 16 residual DMA, 32 all DMA)
 #   bash tools/ws_abl.sh 0 1 2 3 8 16     (0 = the product path; results are wrong when a bit is set)
+# NEEDS a library built with -DPASN_WS_ABLATE (the product kernel compiles the flag tests out: they cost 0.5 % of the step, log entry 96)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for A in "$@"; do
