@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     float sc[4], bs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        sc[i] = cev ? scale[ce + i] : 0.0f;
-        bs[i] = cev ? bias[ce + i] : 0.0f;
+        // (zero for the padded channels: act(0 * P + 0) = 0 for none / ReLU / Swish -- the epilogue stores without a tail mask)
+        sc[i] = (cev && ce + i < d.Cout) ? scale[ce + i] : 0.0f;
+        bs[i] = (cev && ce + i < d.Cout) ? bias[ce + i] : 0.0f;
     }
     float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float psq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         // frame's stores to be acknowledged: ~1.5 us per frame, the whole step serialised)
         const unsigned yvoff = lane_ok ? (unsigned)((((h0 + mrow) * d.Wo + w0 + mcol) * Cp + ce) * 2) : 0x80000000u;
         const unsigned fr_bytes = (unsigned)(ofs * 2);
-        const int kst = wave_live ? ntl : 0;
+        const int kst = wave_live ? NT : 0;  // stores per emitted frame: one per tile, whether or not its rows exist
 
         f32x4 S0[NT], S1[NT], S2[NT];
         const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -291,14 +292,18 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                 int mr = mrow_lim;
                 asm volatile("" : "+v"(mr));
                 const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yclip + (long)to * ofs, 0, fr_bytes, 0x00020000);
+                // Straight-line over ALL tiles (no per-tile branch: a tile below the plane stores out of the descriptor's range and counts
+                // nothing; the pool sums are formed whether or not the launch has a row to write them to; the padded channels carry zero
+                // scale and bias instead of a tail mask) -- with three wave-uniform branches per tile every tile's epilogue was its own
+                // scheduling region and its store waited for its own arithmetic only
 #pragma unroll
                 for (int l = 0; l < NT; ++l)
-                    if (l < ntl) {  // wave-uniform
+                    {
                         float v[4];
                         const bool ok = l * RPT + mr < rows_valid;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = P[l][i] * sc[i] + bs[i];
-                        if (pool) {  // block-uniform
+                        {
                             if (STATS) {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
                         } else if constexpr (ACT != PASN_ACT_NONE) {
                             act_vec(v, d.act);
                         }
-                        if (wave_tail) mask_tail(v, d.Cout - ce);  // wave-uniform: only the tile that holds the padded channels pays the selects
+                        if (ACT == -1 && wave_tail) mask_tail(v, d.Cout - ce);  // (run-time activation: sigmoid(0) is not 0)
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
