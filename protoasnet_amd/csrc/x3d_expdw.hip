@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     float sc[4], bs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        sc[i] = cev ? scale[ce + i] : 0.0f;
-        bs[i] = cev ? bias[ce + i] : 0.0f;
+        // (zero for the padded channels: act(0 * P + 0) = 0 for none / ReLU / Swish -- the epilogue stores without a tail mask)
+        sc[i] = (cev && ce + i < d.Cout) ? scale[ce + i] : 0.0f;
+        bs[i] = (cev && ce + i < d.Cout) ? bias[ce + i] : 0.0f;
     }
     float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
         const long ofs = (long)d.Ho * d.Wo * Cp;
         const unsigned yvoff = lane_ok ? (unsigned)(((h0 * d.Wo + w0 + m) * Cp + ce) * 2) : XE_OOB;
         const unsigned fr_bytes = (unsigned)(ofs * 2);
-        const int kst = wave_live ? ntl : 0;
+        const int kst = wave_live ? XE_NT : 0;  // stores per emitted frame: one per tile, whether or not its row exists
         auto stored = [&](int to) -> int { return (to >= t0 && to < t1 && !(abl & 16)) ? kst : 0; };
 
         f32x4 S0[XE_NT], S1[XE_NT], S2[XE_NT];
@@ -347,15 +348,18 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
             const int to = ti - 1;
             if (wave_live && to >= t0 && to < t1 && !(abl & 16)) {
                 const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yclip + (long)to * ofs, 0, fr_bytes, 0x00020000);
+                // straight-line over ALL tiles, as in dwmfma.hip: a row below the plane stores out of the descriptor's range and counts nothing,
+                // the pool sums are formed whether or not the launch has a row for them, padded channels carry zero scale and bias
 #pragma unroll
                 for (int l = 0; l < XE_NT; ++l)
-                    if (l < ntl) {  // wave-uniform
+                    {
                         float v[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = P[l][i] * sc[i] + bs[i];
-                        if (pool) {
+                        {
+                            const bool ok = lane_ok && l < ntl;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) psum[i] += lane_ok ? v[i] : 0.0f;
+                            for (int i = 0; i < 4; ++i) psum[i] += ok ? v[i] : 0.0f;
                         }
                         if constexpr (ACT == PASN_ACT_SWISH) {
 #pragma unroll
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                         } else if constexpr (ACT != PASN_ACT_NONE) {
                             act_vec(v, d.act);
                         }
-                        if (wave_tail) mask_tail(v, d.Cout - ce);
+                        if (ACT == -1 && wave_tail) mask_tail(v, d.Cout - ce);  // (run-time activation: sigmoid(0) is not 0)
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
