@@ -342,6 +342,38 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     }
 }
 
+// dv[j] *= act'(u[j]) for a whole register vector behind ONE wave-uniform switch (act_grad per element compiles to a ladder of scalar
+// compares and branches per ELEMENT: 348 branches in bn_bwd_apply_kernel's loop body)
+template <int N>
+__device__ __forceinline__ void act_grad_mul(float (&dv)[N], const float (&u)[N], int act) {
+    switch (act) {
+        case PASN_ACT_RELU:
+#pragma unroll
+            for (int j = 0; j < N; ++j) dv[j] = u[j] > 0.0f ? dv[j] : 0.0f;
+            break;
+        case PASN_ACT_SIGMOID:
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float s = sigmoidf_(u[j]);
+                dv[j] *= s * (1.0f - s);
+            }
+            break;
+        case PASN_ACT_SWISH:
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float s = sigmoidf_(u[j]);
+                dv[j] *= s * (1.0f + u[j] * (1.0f - s));
+            }
+            break;
+        case PASN_ACT_ABS:
+#pragma unroll
+            for (int j = 0; j < N; ++j) dv[j] *= u[j] > 0.0f ? 1.0f : (u[j] < 0.0f ? -1.0f : 0.0f);
+            break;
+        default:
+            break;
+    }
+}
+
 // Activation of a whole register vector behind ONE wave-uniform switch.  (hipcc does not hoist the per-element
 // switch of apply_act out of unrolled epilogue loops: every element got its own scalar branch ladder.)
 template <int N>

@@ -240,24 +240,28 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
 #pragma unroll
                     for (int j = 0; j < 8; ++j) u[j] += q[j];
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dv[j] *= act_grad(u[j], act);
+                act_grad_mul(dv, u, act);
             } else if (MODE == 1) {
+                float u[8], ug[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float u = fmaf(v[j], sc[j], sh[j]);
-                    dv[j] *= act_grad(u * g[j], act);
-                    acc[0][j] = fmaf(dv[j], u, acc[0][j]);
+                    u[j] = fmaf(v[j], sc[j], sh[j]);
+                    ug[j] = u[j] * g[j];
                 }
+                act_grad_mul(dv, ug, act);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[0][j] = fmaf(dv[j], u[j], acc[0][j]);
             } else if (MODE == 4) {
                 // as mode 1, but the sums the squeeze-excite unit's norm needs are taken here, per clip: (sum d', sum d' yhat, sum yhat).
                 // d'' = d' gate + add[n] is affine in d' per clip, so sum d'' and sum d'' yhat follow without a second pass over (d, y)
                 // (pasn_se_gate_bwd_stat), and sum d' u = gamma sum d' yhat + beta sum d' (the gate's gradient) as well
+                float ug[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ug[j] = fmaf(v[j], sc[j], sh[j]) * g[j];
+                act_grad_mul(dv, ug, act);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float u = fmaf(v[j], sc[j], sh[j]);
                     const float yh = (v[j] - mean[j]) * invstd[j];
-                    dv[j] *= act_grad(u * g[j], act);
                     acc[0][j] += dv[j];
                     acc[1][j] = fmaf(dv[j], yh, acc[1][j]);
                     acc[W - 1][j] += yh;
@@ -339,8 +343,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         load8(y + o, v);
         load8(d + o, dv);
         if (act != PASN_ACT_NONE) {
+            float u[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dv[j] *= act_grad(fmaf(v[j], sc[j], sh[j]), act);
+            for (int j = 0; j < 8; ++j) u[j] = fmaf(v[j], sc[j], sh[j]);
+            act_grad_mul(dv, u, act);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (dv[j] - m1[j] - (v[j] - mean[j]) * invstd[j] * m2[j]);
