@@ -41,6 +41,19 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.lib()
 
 
+def test_library_path_override_is_read_at_import_and_still_fails_loudly():
+    """PASN_LIB_PATH (A/B runs of two builds of the C-ABI library on one box) replaces the in-tree path; a wrong one is an error, not a fallback."""
+    import subprocess
+    import sys
+
+    code = ("import protoasnet_amd._lib as L\n"
+            "assert L.LIB_PATH == '/nonexistent/other.so', L.LIB_PATH\n"
+            "try:\n    L.lib()\nexcept RuntimeError as e:\n    assert 'no CPU fallback' in str(e)\n    print('loud')\n")
+    env = dict(os.environ, PASN_LIB_PATH="/nonexistent/other.so", PYTHONPATH=REPO)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "loud" in out.stdout, out.stderr[-500:]
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(REPO, "protoasnet_amd")
     for root, _, files in os.walk(pkg):
