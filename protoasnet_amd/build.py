@@ -37,8 +37,10 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OUT_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "protoasnet_amd.h")]
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    # every header of csrc/ (igemm_epilogue.h is shared by three kernels' files: an edit there must rebuild them) + the C-ABI header
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(os.path.dirname(HERE), "include", "protoasnet_amd.h")]
+    flags_extra = os.environ.get("PASN_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPASN_WS_ABLATE for tools/ws_abl.sh (use with force=True / a clean obj dir)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + flags_extra
 
     def compile_one(src: str) -> str:
         s, o = os.path.join(CSRC, src), os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
