@@ -93,6 +93,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from the host instead of replaying the captured hipGraph")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=16)
@@ -154,7 +155,21 @@ def main():
         x = x[:, :1].contiguous()
     trunk = model.cnn_backbone
 
+    # The step: hipGraph replay of the whole forward (protoasnet_amd/graph.py: the launch list is static per shape, captured once;
+    # --no-graph: one host enqueue per launch).  Steps that bracket launches with HIP events (the roofline samples) run launch by launch.
+    from protoasnet_amd.graph import GraphedForward
+    graphed = None if args.no_graph else GraphedForward(model)
+    if graphed is not None:
+        try:
+            graphed(x)  # capture now: a capture that fails is reported and the run goes on launch by launch (same kernels, same results)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench: hipGraph capture failed ({e!r}); falling back to one host enqueue per launch", file=sys.stderr)
+            graphed = None
+            torch.cuda.synchronize()
+
     def step():
+        if graphed is not None and getattr(trunk, "_timers", None) is None:
+            return graphed(x)
         with torch.no_grad():
             return model(x)
 
@@ -241,7 +256,8 @@ def main():
         "config": {"workload": f"Video ProtoASNet forward, {args.arch} trunk + prototype layer (P={args.prototypes}, D=256, "
                                f"K={args.classes}), {args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU"
                                + (" [single-channel grey input: device-side input pipeline, NOT the headline configuration]" if args.input == "grey" else ""),
-                   "global_batch": args.batch * world, "parallelism": f"dp{world} (independent clips, no collective)"},
+                   "global_batch": args.batch * world, "parallelism": f"dp{world} (independent clips, no collective)",
+                   "launch": "host enqueue per launch" if graphed is None else "hipGraph replay of the forward's launch list (one graph launch per step)"},
     }
 
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------

@@ -368,6 +368,37 @@ def test_default_forward_is_bitwise_reproducible(cfg_name):
     assert all(torch.isfinite(t).all() for t in outs[0])
 
 
+def test_graph_replay_of_the_forward_is_the_forward():
+    """protoasnet_amd.graph.GraphedForward: the forward's launch list captured once into a hipGraph and replayed -- bit-identical to the
+    launch-by-launch forward, and it follows the clip when the input tensor is refreshed in place (the tensor's address is what the graph
+    holds).  A tensor at another address gets its own capture."""
+    from protoasnet_amd.graph import GraphedForward
+
+    m = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
+    x = synth.echo_clips((2, 3, 16, 160, 160)).to(DEV).bfloat16()
+    x2 = (synth.echo_clips((2, 3, 16, 160, 160)).flip(0) * 0.5).to(DEV).bfloat16()
+    with torch.no_grad():
+        want1 = [t.clone() for t in m(x)]
+        want2 = [t.clone() for t in m(x2)]
+    assert not torch.equal(want1[0], want2[0])
+    g = GraphedForward(m)
+    got = g(x)
+    for a, b in zip(got, want1):
+        assert torch.equal(a, b)
+    x.copy_(x2)  # same storage, new clip
+    got = g(x)
+    for a, b in zip(got, want2):
+        assert torch.equal(a, b)
+    y = x2.clone()  # another address: its own graph
+    got = g(y)
+    for a, b in zip(got, want2):
+        assert torch.equal(a, b)
+    assert len(g._graphs) == 2
+    with pytest.raises(RuntimeError, match="eval"):
+        GraphedForward(m.train())
+    m.eval()
+
+
 def test_ppnet_callable_prototype_activation():
     """ProtoPNet.py:217-223: ``prototype_activation_function`` may be a callable on the distances.  The kernel supplies the minima; the
     callable and the last layer then run in torch -- same logits as the built-in 'log' when the callable is the log formula."""
