@@ -29,7 +29,9 @@ class GraphedForward:
                 self.model(x)
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
+        # thread_local: calls other threads make while this one captures (the RCCL watchdog of an initialised process group polls events) do not
+        # invalidate the capture
+        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             out = self.model(x)
         return g, out
 
