@@ -25,6 +25,41 @@ import torch.nn as nn
 from . import plan as _plan
 
 
+# ----------------------------------------------------------------------------- pretrained weight files
+# The reference fetches these with ``model_zoo.load_url(url, model_dir="./pretrained_models")`` (resnet_features.py:8-18): the file is
+# cached as ``<model_dir>/<basename of the url>`` and read from there on every later run.  This build has no network, so the cache file
+# IS the interface: drop the file the reference would have downloaded into ``./pretrained_models`` (relative to the working directory,
+# like the reference) and ``pretrained: True`` configs build unchanged; a missing file is an error that names it.
+model_urls = {
+    "resnet18": "https://download.pytorch.org/models/resnet18-5c106cde.pth",
+    "resnet2p1d_18": "https://download.pytorch.org/models/r2plus1d_18-91a641e6.pth",
+}
+model_dir = "./pretrained_models"
+
+
+def load_pretrained(name: str) -> dict:
+    url = model_urls[name]
+    cached = os.path.join(model_dir, os.path.basename(url))
+    if not os.path.exists(cached):
+        raise FileNotFoundError(
+            f"pretrained=True: {cached} not found.  The reference downloads {url} into {model_dir}/ (resnet_features.py:8-18); this "
+            f"build never touches the network -- place that file there, or construct with pretrained=False and load_state_dict() a "
+            f"checkpoint"
+        )
+    return torch.load(cached, map_location="cpu")
+
+
+def _r2plus1d_keys_to_backbone(sd: dict, n_children: int) -> dict:
+    """torchvision ``r2plus1d_18`` keys (``stem.*``, ``layerK.*``, ``fc.*``) -> the ``backbone.<child index>.*`` keys of the slice."""
+    out = {}
+    for k, v in sd.items():
+        head, _, rest = k.partition(".")
+        idx = 0 if head == "stem" else int(head[5:]) if head.startswith("layer") and head[5:].isdigit() else -1
+        if 0 <= idx < n_children:
+            out[f"backbone.{idx}.{rest}"] = v
+    return out
+
+
 # ----------------------------------------------------------------------------- 2-D ResNet-18
 class _BasicBlock2d(nn.Module):
     def __init__(self, inplanes: int, planes: int, stride: int):
@@ -96,12 +131,14 @@ class ResNet18Features(_plan.HipTrunk):
 
 
 def resnet18_features(pretrained: bool = False, **kwargs) -> ResNet18Features:
+    """resnet_features.py:236-248: ``pretrained`` loads the ImageNet file from ``model_dir`` with ``fc.*`` popped, ``strict=False``."""
+    model = ResNet18Features()
     if pretrained:
-        raise RuntimeError(
-            "pretrained=True downloads ImageNet weights in the reference (resnet_features.py:243-247); "
-            "this build has no network -- construct with pretrained=False and load_state_dict() a checkpoint"
-        )
-    return ResNet18Features()
+        my_dict = load_pretrained("resnet18")
+        my_dict.pop("fc.weight")  # KeyError when absent, like the reference
+        my_dict.pop("fc.bias")
+        model.load_state_dict(my_dict, strict=False)
+    return model
 
 
 # ----------------------------------------------------------------------------- R(2+1)D-18
@@ -139,11 +176,6 @@ class resnet2p1d_18(_plan.HipTrunk):  # noqa: N801 -- name is part of the refere
 
     def __init__(self, pretrained: bool = True, last_layer_num: int = -3, **kwargs):
         super().__init__()
-        if pretrained:
-            raise RuntimeError(
-                "pretrained=True downloads Kinetics weights in the reference (resnet_features.py:317-319); "
-                "this build has no network -- construct with pretrained=False and load_state_dict() a checkpoint"
-            )
         n_children = 7 + last_layer_num
         if not 1 <= n_children <= 5:
             raise ValueError("last_layer_num must keep between 1 and 5 convolutional children (-6..-2)")
@@ -159,6 +191,10 @@ class resnet2p1d_18(_plan.HipTrunk):  # noqa: N801 -- name is part of the refere
             inplanes = planes
         self.backbone = nn.Sequential(*children)
         self.out_channels = inplanes
+        if pretrained:
+            # resnet_features.py:316-319 loads the Kinetics file into the WHOLE torchvision model (strict=False) and then keeps
+            # children[:last_layer_num]: stem -> backbone.0, layerK -> backbone.K; fc.* and the layers beyond the cut are dropped with it.
+            self.load_state_dict(_r2plus1d_keys_to_backbone(load_pretrained("resnet2p1d_18"), n_children), strict=False)
 
     def __repr__(self):
         return f"resnet2p1d_18(children={len(self.backbone)}, out_channels={self.out_channels})"
@@ -357,13 +393,13 @@ class X3DFeatures(_plan.HipTrunk):
 
 def x3d_s(pretrained: bool = False, **kwargs) -> X3DFeatures:
     if pretrained:
-        raise RuntimeError("no pretrained X3D weights exist for this build (no network); use pretrained=False")
+        raise RuntimeError("x3d_*: the reference ships no X3D trunk and no weight file for one (resnet_features.py:8-16); use pretrained=False")
     return X3DFeatures("x3d_s")
 
 
 def x3d_m(pretrained: bool = False, **kwargs) -> X3DFeatures:
     if pretrained:
-        raise RuntimeError("no pretrained X3D weights exist for this build (no network); use pretrained=False")
+        raise RuntimeError("x3d_*: the reference ships no X3D trunk and no weight file for one (resnet_features.py:8-16); use pretrained=False")
     return X3DFeatures("x3d_m")
 
 

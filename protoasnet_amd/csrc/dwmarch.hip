@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
     float kshift[8];
     int kcount = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kshift[j] = (!RED && stats && shift) ? shift[cg * 8 + j] : 0.0f;
+    for (int j = 0; j < 8; ++j) kshift[j] = (!RED && stats && shift && cg * 8 + j < d.Cout) ? shift[cg * 8 + j] : 0.0f;  // `shift` holds Cout floats
 
     if (item < items) {
         const int strip = item % strips;

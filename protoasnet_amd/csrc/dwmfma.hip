@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     float kshift[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (STATS && shift && cev) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) kshift[i] = shift[ce + i];
+        for (int i = 0; i < 4; ++i) kshift[i] = ce + i < d.Cout ? shift[ce + i] : 0.0f;  // `shift` holds Cout floats, not Cout_p
     }
 
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;

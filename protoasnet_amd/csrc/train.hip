@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const bool live = c < Cp;
     // the shift the partials were taken with: y[0][0][c] (bn_stats_partial_kernel), or `shift` (the stencils' fused statistics: the running
     // mean as it stood BEFORE this update -- read here ahead of the barrier, written below behind it), or 0
-    float k = !live ? 0.0f : y ? (float)y[c] : shift ? shift[c] : 0.0f;
+    float k = !live ? 0.0f : y ? (float)y[c] : (shift && c < C) ? shift[c] : 0.0f;  // `shift` holds C floats (padded channels: 0)
     asm volatile("" : "+v"(k));  // the value is taken HERE: `shift` may be the running mean this kernel updates behind the barrier
     float a1 = 0.0f, a2 = 0.0f;
     if (live) {

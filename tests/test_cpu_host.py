@@ -83,7 +83,7 @@ def test_model_builder_contract():
         model_builder.build({k: v for k, v in CFG_VIDEO_R2P1D.items() if k != "checkpoint_path"})
     with pytest.raises(AssertionError):
         model_builder.build(dict(CFG_VIDEO_R2P1D, prototype_shape="(41, 256, 1, 1, 1)"))  # P % K != 0, ProtoPNet.py:332
-    with pytest.raises(RuntimeError, match="no network"):
+    with pytest.raises(FileNotFoundError, match="resnet18-5c106cde.pth"):  # (tests/test_cpu_dropin.py covers the file being there)
         model_builder.build(dict(CFG_XPROTO, pretrained=True))
 
 

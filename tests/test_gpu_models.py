@@ -399,6 +399,66 @@ def test_graph_replay_of_the_forward_is_the_forward():
     m.eval()
 
 
+def test_graph_replay_follows_weight_updates():
+    """A captured graph addresses packed weights / folded norms made at capture time.  (a) the reference's push write
+    ``prototype_vectors.data.copy_()`` (push_abs_revision.py:346; bumps no version counter) is seen by the next replay because the head
+    reads the prototypes in place; (b) ``load_state_dict`` / an in-place parameter update bumps the counters: the stale graph is dropped
+    and re-captured, never replayed; (c) an eager forward between the update and the replay (it re-plans and frees the old arena) does not
+    disturb it; (d) static_input=True takes a fresh tensor per call with ONE capture; (e) the zero-copy cache is bounded."""
+    from protoasnet_amd.graph import GraphedForward
+
+    m = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
+    x = synth.echo_clips((2, 3, 16, 160, 160)).to(DEV).bfloat16()
+    g = GraphedForward(m)
+    first = [t.clone() for t in g(x)]
+    assert g.captures == 1
+    # (a) push-style write
+    with torch.no_grad():
+        m.prototype_vectors.data.copy_(torch.rand_like(m.prototype_vectors) * 0.5)
+        want = [t.clone() for t in m(x)]
+    got = g(x)
+    assert g.captures == 1
+    assert not torch.equal(want[0], first[0])
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # (b) + (c) trunk and head weights change through load_state_dict; an eager forward re-plans in between
+    sd = {k: (v * 1.25 if v.is_floating_point() and ("conv_c.weight" in k or "add_on_layers.0.weight" in k) else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        want = [t.clone() for t in m(x)]
+        junk = torch.full((64 << 20,), 7, dtype=torch.uint8, device=DEV)  # whatever the freed arena is reused for
+    got = g(x)
+    assert g.captures == 2 and len(g._graphs) == 1
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(want[2], first[2])
+    del junk
+    with torch.no_grad():  # an optimizer-style in-place step
+        m.cnn_backbone.stages[3][6].bn_c.weight.mul_(0.5)
+        want = [t.clone() for t in m(x)]
+    got = g(x)
+    assert g.captures == 3
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # (d) one capture, any input tensor
+    gs = GraphedForward(m, static_input=True)
+    for i in range(3):
+        xi = (x.float() * (1.0 - 0.2 * i)).bfloat16()
+        with torch.no_grad():
+            want = [t.clone() for t in m(xi)]
+        got = gs(xi)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert gs.captures == 1
+    # (e) bounded zero-copy cache
+    g2 = GraphedForward(m, max_graphs=2)
+    keep = [x.clone() for _ in range(3)]
+    with pytest.warns(RuntimeWarning, match="static_input"):
+        for xi in keep:
+            g2(xi)
+    assert len(g2._graphs) == 2 and g2.captures == 3
+
+
 def test_ppnet_callable_prototype_activation():
     """ProtoPNet.py:217-223: ``prototype_activation_function`` may be a callable on the distances.  The kernel supplies the minima; the
     callable and the last layer then run in torch -- same logits as the built-in 'log' when the callable is the log formula."""

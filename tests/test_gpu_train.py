@@ -408,6 +408,54 @@ def test_stencil_statistics_are_shifted_by_the_running_mean(c, s, shape, stencil
     assert err_shifted < 0.5 * err_plain or err_plain < 2e-3, (err_shifted, err_plain)
 
 
+@pytest.mark.parametrize("stencil", ["matrix-core", "valu"])
+@pytest.mark.parametrize("c,s,shape", [(54, 1, (2, 6, 14, 14)), (108, 1, (2, 4, 7, 7)), (108, 2, (2, 4, 14, 18))])
+def test_stencil_statistics_never_read_past_the_running_mean(c, s, shape, stencil, monkeypatch):
+    """``running_mean`` holds C floats, the kernels' channel stride is Cp = round_up(C, 8) (54 -> 56, 108 -> 112): the shift of a padded
+    channel is 0, never the bytes behind the buffer.  Here those bytes are NaN: the partial rows, the statistics table and the pooled
+    means stay finite, and the real channels are bit-identical to a run whose running mean sits in a clean, padded buffer."""
+    if stencil == "valu":
+        monkeypatch.setenv("PASN_DWMFMA", "0")
+    lib = _lib.lib()
+    n, t, h, w = shape
+    g = torch.Generator().manual_seed(11 * c + s)
+    x = torch.randn(n, c, t, h, w, generator=g).bfloat16().float()
+    wt = (torch.randn(c, 1, 3, 3, 3, generator=g) * 0.2).bfloat16().float()
+    yref = F.conv3d(x, wt, stride=(1, s, s), padding=1, groups=c)
+    d = _desc(x, yref, (3, 3, 3), (1, s, s), (1, 1, 1))
+    cp = d.Cout_p
+    assert cp > c
+    rows = lib.pasn_dwconv3d_stats_rows(ctypes.byref(d), BF16)
+    assert rows > 0
+    wp = torch.zeros(27, cp, device=DEV)
+    wp[:, :c] = wt.reshape(c, 27).t().to(DEV)
+    one, zero = torch.ones(cp, device=DEV), torch.zeros(cp, device=DEV)
+    gm, bt = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    xd = _cl(x, dtype=torch.bfloat16)
+    rm0 = yref.mean(dim=(0, 2, 3, 4)) * 0.9
+
+    def run(tail):
+        buf = torch.full((c + 64,), tail, device=DEV)
+        buf[:c] = rm0.to(DEV)
+        rm, rv = buf[:c], torch.ones(c, device=DEV)
+        y = torch.empty(n, yref.shape[2], yref.shape[3], yref.shape[4], cp, dtype=torch.bfloat16, device=DEV)
+        stat = torch.zeros(4 * cp, device=DEV)
+        pool = torch.zeros(n * cp, device=DEV)
+        ws = torch.zeros(n * rows * 2 * cp, device=DEV)
+        _lib.check(lib.pasn_dwconv3d_stats_fwd(xd.data_ptr(), wp.data_ptr(), one.data_ptr(), zero.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                               gm.data_ptr(), bt.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, stat.data_ptr(),
+                                               pool.data_ptr(), ctypes.byref(d), BF16, _st()))
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(buf[c:]).all()) or tail == 0.0   # the tail is only ever read, never written
+        return ws.cpu(), stat.view(4, cp).cpu(), pool.view(n, cp).cpu(), buf[:c].cpu()
+
+    ws_n, st_n, pool_n, rm_n = run(float("nan"))
+    ws_c, st_c, pool_c, rm_c = run(0.0)
+    for name, a in (("partial rows", ws_n), ("statistics", st_n), ("pooled means", pool_n), ("running mean", rm_n)):
+        assert bool(torch.isfinite(a).all()), name
+    assert torch.equal(ws_n, ws_c) and torch.equal(st_n, st_c) and torch.equal(pool_n, pool_c) and torch.equal(rm_n, rm_c)
+
+
 @pytest.mark.parametrize("c,shape,act", [(54, (2, 5, 11, 13), "relu"), (432, (3, 9, 7, 7), "relu"), (108, (2, 4, 14, 28), "swish")])
 def test_depthwise_dgrad_with_fused_backward_sums(c, shape, act, monkeypatch):
     """pasn_dwconv3d_dgrad_reduce (opt-in): dx identical to the stencil dgrad (pasn_dwconv3d_fwd with reversed taps), and coef / dgamma / dbeta
