@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling there is ~6300 GB/s
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: ~6.3 TB/s achievable; measured on this pool's boxes: copy 4.7-5.3 TB/s, fill 6.9 -- DESIGN.md section 6)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.0}  # dense peaks, same guide (never the 2:1-sparsity figures)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
@@ -257,7 +257,11 @@ def main():
                                f"K={args.classes}), {args.batch}x{args.frames}x{args.size}x{args.size} echo clips per GPU"
                                + (" [single-channel grey input: device-side input pipeline, NOT the headline configuration]" if args.input == "grey" else ""),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent clips, no collective)",
-                   "launch": "host enqueue per launch" if graphed is None else "hipGraph replay of the forward's launch list (one graph launch per step)"},
+                   "launch": "host enqueue per launch" if graphed is None else
+                             ("hipGraph replay of the forward's launch list (one graph launch per step"
+                              + ("" if args.no_roofline else f"; the {len({0, args.steps // 2, args.steps - 1})} roofline-sample steps of the timed region run launch by "
+                                                            "launch with HIP events around the dominant kernel's launches") + ")"),
+                   "tuning": _tuning_in_force()},
     }
 
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------
@@ -365,8 +369,22 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def _tuning_in_force():
+    """PASN_* switches in the library's snapshot (csrc/tuning.h) + unknown PASN_* names in the environment: {} on a default run."""
+    from protoasnet_amd import _lib
+
+    out = {}
+    for ln in _lib.tuning_report().splitlines():
+        if ln.startswith("unknown: "):
+            out["unknown"] = ln[9:].split()
+        elif "=" in ln:
+            k, v = ln.split("=", 1)
+            out[k] = v
+    return out
+
+
 _UNFUSED = {"PASN_EXPDW": "0", "PASN_NO_XPAIR": "1", "PASN_WSPAIR": "0", "PASN_NO_SHORTFUSE": "1", "PASN_NO_SE_PROLOGUE": "1",
-            "PASN_NO_SE_FUSE": "1"}
+            "PASN_NO_SE_FUSE": "1", "PASN_NO_BLOCK": "1"}
 
 
 def _layerwise_bytes(trunk, x, dtype):
@@ -376,9 +394,12 @@ def _layerwise_bytes(trunk, x, dtype):
 
     if not hasattr(trunk, "build_plan"):
         return None
+    from protoasnet_amd import _lib
+
     saved = {k: os.environ.get(k) for k in _UNFUSED}
     try:
         os.environ.update(_UNFUSED)
+        _lib.tuning_reload()  # the library routes on ONE snapshot of the PASN_* switches (csrc/tuning.h)
         pb = PlanBuilder(x.device, dtype, dtype)
         x_in = pb.input(tuple(x.shape))
         pb.finish(x_in, trunk.build_plan(pb, x_in))
@@ -392,6 +413,7 @@ def _layerwise_bytes(trunk, x, dtype):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _lib.tuning_reload()
 
 
 def _kernel_roofline(trunk, step, plan, dtype_name: str, reps: int = 3):
@@ -474,18 +496,82 @@ def secondary(dev) -> dict:
                 "trunk_tflops": round(sum(mm["flops"] for mm in plan.meta) / sec / 1e12, 1), "roofline": _kernel_roofline(m.cnn_backbone, f, plan, "bf16")}
 
     def cfg5():
-        m = build("x3d_m", 60, 3, 312).eval().set_compute_dtype(bf16)
-        x = synth.echo_clips((8, 3, 32, 312, 312)).to(dev).to(bf16)
+        # BASELINE config 5 / SURVEY 8(d): "fp32 vs bf16 tolerance sweep": clips/s in both precisions + the error table of bf16 against fp32
+        m = build("x3d_m", 60, 3, 312).eval()
+        x32 = synth.echo_clips((8, 3, 32, 312, 312)).to(dev)
+        res = {"workload": "BASELINE config 5: X3D-M trunk + prototype layer (P=60, K=3), 8x32x312x312 echo clips, fp32 and bf16"}
+        outs = {}
+        for name, dt in (("fp32", torch.float32), ("bf16", bf16)):
+            m.set_compute_dtype(dt)
+            x = x32.to(dt)
 
-        def f():
+            def f():
+                with torch.no_grad():
+                    return m(x)
+
+            sec = timed(f, 2, 3 if name == "fp32" else 8)
+            outs[name] = [t.float().clone() for t in f()]
+            plan = m.cnn_backbone.plan_for(x)
+            tb = sum(mm["bytes"] for mm in plan.meta)
+            res[name] = {"value": round(8 / sec, 1), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 3),
+                         "hbm_frac_whole_step": round(tb / sec / 1e9 / HBM_PEAK_GBS, 4)}
+            del x
+        res["value"], res["unit"], res["ms_per_step"] = res["bf16"]["value"], "clips/s", res["bf16"]["ms_per_step"]
+        res["hbm_frac_whole_step"] = res["bf16"]["hbm_frac_whole_step"]
+        table = {}
+        for key, a, b in zip(("logits", "similarity", "occurrence_map"), outs["fp32"], outs["bf16"]):
+            d = (a - b).abs()
+            table[key] = {"max_abs_err": round(float(d.max()), 6), "mean_abs_err": round(float(d.mean()), 7), "max_abs_fp32": round(float(a.abs().max()), 5),
+                          "rel_mean_err": round(float(d.mean() / a.abs().mean().clamp_min(1e-30)), 6)}
+        table["argmax_logit_agreement"] = float((outs["fp32"][0].argmax(1) == outs["bf16"][0].argmax(1)).float().mean())
+        res["bf16_vs_fp32"] = table
+        return res
+
+    def cfg1():
+        # BASELINE config 1 / BASELINE.md section 4 case (i): Ours_ProtoASNet_Image.yml:13-16,85 -- XProtoNet on ResNet-18, 10 prototypes per
+        # class x 4 classes, 224^2 frames, batch 8 -- the configuration the reference itself can run on a CPU
+        import oracle
+
+        m = model_builder.build(dict(checkpoint_path="", name="XProtoNet", base_architecture="resnet18", pretrained=False,
+                                     prototype_shape="(40, 512, 1, 1)", num_classes=4, img_size=224, add_on_layers_type="regular"))
+        synth.load_synth(m)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        x = synth.echo_clips((8, 3, 224, 224))
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        torch.set_num_threads(cores)
+        with torch.no_grad():
+            oracle.nets.xprotonet_forward(sd, x[:1], arch="resnet18")
+            t0, reps = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 4.0:
+                ref = oracle.nets.xprotonet_forward(sd, x, arch="resnet18")
+                reps += 1
+            t_cpu = (time.perf_counter() - t0) / reps
+        m = m.to(dev).eval()
+        res = {"workload": "BASELINE config 1: Image ProtoASNet (XProtoNet), ResNet-18, P=40, D=512, K=4, 8x3x224x224 synthetic frames",
+               "unit": "images/s",
+               "cpu_baseline": {"value": round(8 / t_cpu, 1), "unit": "images/s", "cores": cores, "kind": "port",
+                                "sample": f"{reps} batches of 8 frames, fp32 torch oracle, {t_cpu * reps:.1f} s of CPU work"}}
+        for name, dt in (("fp32", torch.float32), ("bf16", bf16)):
+            m.set_compute_dtype(dt)
+            xin = x.to(dev).to(dt)
+
+            def f():
+                with torch.no_grad():
+                    return m(xin)
+
+            sec = timed(f, 5, 50)
+            out = f()
+            res[name] = {"value": round(8 / sec, 1), "ms_per_step": round(sec * 1e3, 4),
+                         "max_abs_similarity_diff_vs_cpu": round(float((out[1].float().cpu() - ref["similarity"]).abs().max()), 6)}
+        res["value"], res["ms_per_step"] = res["bf16"]["value"], res["bf16"]["ms_per_step"]
+        xb = synth.echo_clips((256, 3, 224, 224)).to(dev).to(bf16)
+
+        def g():
             with torch.no_grad():
-                return m(x)
+                return m(xb)
 
-        sec = timed(f, 3, 8)
-        plan = m.cnn_backbone.plan_for(x)
-        tb = sum(mm["bytes"] for mm in plan.meta)
-        return {"workload": "BASELINE config 5: X3D-M trunk + prototype layer (P=60, K=3), 8x32x312x312 echo clips", "value": round(8 / sec, 1),
-                "unit": "clips/s", "ms_per_step": round(sec * 1e3, 3), "hbm_frac_whole_step": round(tb / sec / 1e9 / HBM_PEAK_GBS, 4)}
+        res["bf16"]["images_per_s_batch256"] = round(256 / timed(g, 3, 10), 1)
+        return res
 
     def cfg4():
         m = build("x3d_s", 30, 3, 224).eval().set_compute_dtype(bf16)
@@ -509,8 +595,32 @@ def secondary(dev) -> dict:
         res = push_prototypes(Loader(), m, class_specific=True, abstain_class=False, replace_prototypes=True, log=lambda *_: None)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        return {"workload": "BASELINE config 4: push_prototypes sweep, 10 000 clips 3x16x224x224 (313 batches), X3D-S, 30 prototypes, class specific",
+        line = {"workload": "BASELINE config 4: push_prototypes sweep, 10 000 clips 3x16x224x224 (313 batches), X3D-S, 30 prototypes, class specific",
                 "value": round(10000 / dt, 1), "unit": "clips/s", "seconds": round(dt, 3), "winners_found": int((res["proto_index"] >= 0).sum())}
+        # BASELINE.md section 4 case (iii): the reference's push sweep on the host cores -- push_forward per batch (oracle), everything to numpy,
+        # the per-prototype masked-argmin loop (push_abs_revision.py:268-307; its own timing is :213,347-348) -- on a bounded sample
+        import numpy as np
+
+        import oracle
+
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+        xc = xs[:8].float().cpu()
+        ident = m.prototype_class_identity.numpy()
+        batches, t0, done = [], time.perf_counter(), 0
+        with torch.no_grad():
+            while done < 24 and time.perf_counter() - t0 < 10.0:
+                ref = oracle.nets.xprotonet_forward(sd, xc, arch="x3d_s")
+                occ = ref["occurrence_map"].numpy()  # the reference copies the whole map and the batch to the host as well (:278-285)
+                batches.append((ref["features_extracted"].numpy(), 1.0 - ref["similarity"].numpy(), (np.arange(8) + done) % 3))
+                done += 8
+            oracle.push.xproto_push_select(batches, ident, 3, True, False)
+        dtc = time.perf_counter() - t0
+        del occ
+        line["cpu_baseline"] = {"value": round(done / dtc, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+                                "sample": f"{done} clips (batches of 8) through the oracle's push_forward + the reference's numpy selection loop, {dtc:.1f} s of CPU work"}
+        return line
 
     def cfg3():
         m = build("x3d_s", 30, 3, 224).train().set_compute_dtype(bf16)
@@ -538,6 +648,7 @@ def secondary(dev) -> dict:
                 "unit": "clips/s", "ms_per_step": round(sec * 1e3, 2)}
 
     guarded("r2plus1d_18_forward", r2p1d)
+    guarded("config1_image_forward", cfg1)
     guarded("config5_x3d_m_forward", cfg5)
     guarded("config4_push_sweep", cfg4)
     guarded("config3_train_step", cfg3)

@@ -39,6 +39,16 @@ enum { PASN_OK = 0, PASN_ERR_ARG = 1, PASN_ERR_LAUNCH = 2, PASN_ERR_UNSUPPORTED 
 int pasn_version(void);
 const char* pasn_last_error(void);
 
+/* Tuning switches (csrc/tuning.h).  The reference has no counterpart: its kernels are cuDNN's, picked by `cudnn.benchmark = True`
+ * (src/agents/base.py:20).  Here the routing of a layer onto a kernel is a pure function of its descriptor and of the PASN_* switches
+ * that were set in the environment WHEN THE LIBRARY FIRST LOOKED (one snapshot; registered names only).  pasn_tuning_reload() takes a new
+ * snapshot (tests and A/B tools call it after changing the environment); pasn_tuning_get() returns a switch's value in the snapshot or
+ * NULL; pasn_tuning_report() writes "NAME=VALUE" lines of the switches in force (+ an "unknown: ..." line for PASN_* names the library
+ * does not know, + the registry "name<TAB>class<TAB>meaning" when with_registry != 0) and returns the length needed. */
+void pasn_tuning_reload(void);
+const char* pasn_tuning_get(const char* name);
+int pasn_tuning_report(char* buf, int cap, int with_registry);
+
 /* Geometry of one convolution / pooling window over channels-last activations. */
 typedef struct pasn_conv_desc {
     int32_t N, Ti, Hi, Wi;    /* input extent                                              */

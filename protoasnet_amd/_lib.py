@@ -35,6 +35,9 @@ SIGNATURES = {
     "pasn_allreduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "pasn_comm_destroy": (c_int, [c_void_p]),
     "pasn_last_error": (c_char_p, []),
+    "pasn_tuning_reload": (None, []),
+    "pasn_tuning_get": (c_char_p, [c_char_p]),
+    "pasn_tuning_report": (c_int, [c_char_p, c_int, c_int]),
     "pasn_first_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
     "pasn_first_conv_gray_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_float, c_float, c_void_p]),
     "pasn_first_conv_mfma_slot": (c_int, [POINTER(ConvDesc), c_int, c_int]),
@@ -164,3 +167,48 @@ def current_stream() -> int:
     import torch
 
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- tuning switches (csrc/tuning.h): the library reads the PASN_* environment ONCE ----------------------------------------------------
+def tuning_reload() -> None:
+    """Take a new snapshot of the PASN_* environment (after ``os.environ`` / ``monkeypatch.setenv`` changed it: tests, A/B tools)."""
+    lib().pasn_tuning_reload()
+
+
+def tuning_get(name: str):
+    """A registered switch's value in the library's snapshot, or None.  The Python host side routes on the same snapshot."""
+    v = lib().pasn_tuning_get(name.encode())
+    return None if v is None else v.decode()
+
+
+def tuning_report(with_registry: bool = False) -> str:
+    n = lib().pasn_tuning_report(None, 0, int(with_registry))
+    buf = ctypes.create_string_buffer(n + 1)
+    lib().pasn_tuning_report(buf, n + 1, int(with_registry))
+    return buf.value.decode()
+
+
+class tuning_env:
+    """``with tuning_env(PASN_X="0", PASN_Y=None): ...`` -- set / unset switches for a block, snapshot reloaded on entry and exit."""
+
+    def __init__(self, **kv):
+        self.kv, self.saved = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.saved[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        tuning_reload()
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        tuning_reload()
+        return False

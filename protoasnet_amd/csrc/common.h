@@ -7,6 +7,7 @@
 #include <string>
 
 #include "../../include/protoasnet_amd.h"
+#include "tuning.h"
 
 namespace pasn {
 

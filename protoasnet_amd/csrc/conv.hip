@@ -532,7 +532,7 @@ static DwGeom dw_geom(const pasn_conv_desc& d) {
         // stride 2 touches 2*WT+1 columns per row: WT = 4 keeps the double-buffered row (prefetch) within the register
         // budget (measured 370 vs 450 us on the 54-channel 112^2 layer); stride 1 prefers long strips (fewer reloads)
         g.WT = d.sw == 2 ? 4 : (d.Wo % 7 == 0) ? 7 : 8;
-        if (const char* e = getenv("PASN_DW_WT")) {  // tuning knob: 4, 7 or 8
+        if (const char* e = tune_dev("PASN_DW_WT")) {  // tuning knob: 4, 7 or 8
             const int v = atoi(e);
             if (v == 4 || v == 7 || v == 8) g.WT = v;
         }
@@ -735,7 +735,7 @@ static bool prefer_xtile(const pasn_conv_desc& d, int dtype, bool has_gate) {
     if (!pw_xtile_applicable(d, dtype)) return false;
     if (has_gate || d.in_swish) {  // PASN_XTILE_GATED=1: the X-tile kernel on gated layers too.  Re-measured after its gate reads became whole
         // pieces (round 2): still behind the persistent kernel on the three gated 108 -> 48 layers (9.00 k vs 9.04 k clips/s end to end)
-        const char* e = getenv("PASN_XTILE_GATED");
+        const char* e = tune("PASN_XTILE_GATED");
         if (!(e && e[0] == '1')) return false;
     }
     if (d.st != 1 || d.sh != 1 || d.sw != 1) return true;  // strided 1x1x1 (shortcut convs): the only specialised kernel
@@ -833,7 +833,7 @@ extern "C" int pasn_conv3d_pair_variant(const pasn_conv_desc* d1, const pasn_con
 // The chained pair with the first conv's squeeze-excite gate computed in the launch's prologue (pasn_conv3d_se_fwd + pasn_conv3d_pair_fwd in one).
 extern "C" int pasn_conv3d_pair_se_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype, int Cse) {
     if (!conv_desc_ok(d1) || !conv_desc_ok(d2) || Cse <= 0 || Cse > 32 || Cse % 4 != 0 || d1->Cin > 512) return 0;
-    if (const char* e = getenv("PASN_NO_SE_PROLOGUE"))
+    if (const char* e = tune("PASN_NO_SE_PROLOGUE"))
         if (e[0] == '1') return 0;
     pasn_conv_desc f1 = *d1, f2 = *d2;
     f1.w_frag = f2.w_frag = 1;
@@ -874,7 +874,7 @@ extern "C" int pasn_conv3d_pair_fwd(const void* x, const void* w1, const float* 
 
 extern "C" int pasn_conv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse, int has_residual) {
     if (!conv_desc_ok(d) || Cse <= 0 || Cse > 32 || Cse % 4 != 0 || d->Cin > 512) return 0;
-    if (const char* e = getenv("PASN_NO_SE_PROLOGUE"))
+    if (const char* e = tune("PASN_NO_SE_PROLOGUE"))
         if (e[0] == '1') return 0;
     pasn_conv_desc df = *d;
     df.w_frag = 1;
@@ -999,7 +999,7 @@ extern "C" int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* sc
 // stencil covers the layer -- pasn_dwconv3d_se_supported says so, the caller otherwise issues pasn_dwconv3d_fwd + pasn_se_gate_fwd.
 extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, int Cse) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0 || Cse <= 0) return 0;
-    if (const char* e = getenv("PASN_NO_SE_FUSE"))
+    if (const char* e = tune("PASN_NO_SE_FUSE"))
         if (e[0] == '1') return 0;
     if (dw_mfma_geom(*d, dtype).ok) return 0;    // the matrix-core stencil + the stand-alone gate beat the fused VALU launch (8669 vs 8623 clips/s)
     const DwMarchGeom m = dw_march_geom(*d, dtype);
@@ -1008,7 +1008,7 @@ extern "C" int pasn_dwconv3d_se_supported(const pasn_conv_desc* d, int dtype, in
     // 216: +4..9 us) against ~9 us for the stand-alone gate launch it replaces.  Measured end to end (32 x 16 x 224 x 224, one box): fused
     // everywhere 8084 clips/s, fused up to 256 channels 8218, up to 128 channels 8250, nowhere 8193.  A version of the tail with every
     // load batched up front (fc rows in registers) moved 432 channels to +16 us and the narrow stages to +6..9 us: no better.
-    const int max_c = getenv("PASN_SE_FUSE_MAXC") ? atoi(getenv("PASN_SE_FUSE_MAXC")) : 128;
+    const int max_c = tune("PASN_SE_FUSE_MAXC") ? atoi(tune("PASN_SE_FUSE_MAXC")) : 128;
     return m.WT != 0 && d->Cout_p <= max_c && m.R * d->Cout_p >= d->Cout_p + Cse + 8;  // the gate's LDS scratch is the pool scratch
 }
 

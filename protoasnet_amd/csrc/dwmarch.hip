@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_march_kernel(const __bf16* __
 DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
     DwMarchGeom g = {0, 0, 0, 0, 0, 0};
     if (dtype != PASN_BF16) return g;
-    if (const char* e = getenv("PASN_NO_DWMARCH"))
+    if (const char* e = tune("PASN_NO_DWMARCH"))
         if (e[0] == '1') return g;
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == d.sw && (d.sw == 1 || d.sw == 2) && d.pt == 1 &&
                        d.ph == 1 && d.pw == 1 && d.To == d.Ti && d.Cin_p == d.Cout_p && d.Cout_p % 8 == 0 && d.Cout_p / 8 <= DWM_CGS;
@@ -358,8 +358,8 @@ DwMarchGeom dw_march_geom(const pasn_conv_desc& d, int dtype) {
     // Pick (WT, Tc) with a small cost model.  One work item per thread makes the grid a fixed number of blocks; at 2
     // resident blocks per CU the kernel runs in ceil(blocks / 512) "rounds", and a half-empty last round is pure loss
     // (measured: 704 blocks = 2 rounds for 1.4 rounds of work).  Per-thread cost = frames x instructions per frame.
-    const int force_wt = getenv("PASN_DWM_WT") ? atoi(getenv("PASN_DWM_WT")) : 0;
-    const int force_tc = getenv("PASN_DWM_TC") ? atoi(getenv("PASN_DWM_TC")) : 0;
+    const int force_wt = tune("PASN_DWM_WT") ? atoi(tune("PASN_DWM_WT")) : 0;
+    const int force_tc = tune("PASN_DWM_TC") ? atoi(tune("PASN_DWM_TC")) : 0;
     double best = 1e30;
     for (int wt = 2; wt <= 3; ++wt) {
         if (force_wt && wt != force_wt) continue;

@@ -402,9 +402,9 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     // 68 vs 79 at 28 x 28, 35 vs 41 / 40 vs 44 at 14 x 14, 25 vs 35 / 27 vs 37 at 7 x 7; end to end, three alternating runs each
     // without event bracketing: planes <= 14 wide 8582 clips/s, <= 28 wide 8611, all 8633 -- profiles/README entry 45).
     // PASN_DWMFMA=0: none; PASN_DWMFMA_MAXW: only planes up to this width.
-    const char* on = getenv("PASN_DWMFMA");
+    const char* on = tune("PASN_DWMFMA");
     if (on && on[0] == '0') return g;
-    const int maxw = getenv("PASN_DWMFMA_MAXW") ? atoi(getenv("PASN_DWMFMA_MAXW")) : (1 << 30);
+    const int maxw = tune("PASN_DWMFMA_MAXW") ? atoi(tune("PASN_DWMFMA_MAXW")) : (1 << 30);
     if (d.Wo > maxw) return g;
     const int ss = 1;
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 &&
@@ -425,8 +425,8 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
     g.NI = dwf_ni(g.RPT, ss);  // the instance's constant
     // (Tc, upb): blocks run two per CU, a block costs a setup (weight operands, pipeline fill) plus upb units of Tc + 2 frames; at most
     // 64 chunks per clip where it costs nothing (the chunk count is the number of SE partial rows the gate has to sum)
-    const int force_tc = getenv("PASN_DWMFMA_TC") ? atoi(getenv("PASN_DWMFMA_TC")) : 0;
-    const int force_upb = getenv("PASN_DWMFMA_UPB") ? atoi(getenv("PASN_DWMFMA_UPB")) : 0;
+    const int force_tc = tune("PASN_DWMFMA_TC") ? atoi(tune("PASN_DWMFMA_TC")) : 0;
+    const int force_upb = tune("PASN_DWMFMA_UPB") ? atoi(tune("PASN_DWMFMA_UPB")) : 0;
     const int regions = g.RTH * g.RTW;
     double best = 1e30;
     for (int tc = d.To;; tc = (tc + 1) / 2) {
@@ -449,7 +449,7 @@ DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype) {
         if (force_tc || tc <= 4) break;
     }
     g.bpc = g.CQ * g.chunks;
-    g.abl = getenv("PASN_DWMFMA_ABL") ? atoi(getenv("PASN_DWMFMA_ABL")) : 0;  // timing ablations (wrong results)
+    g.abl = tune_dev("PASN_DWMFMA_ABL") ? atoi(tune_dev("PASN_DWMFMA_ABL")) : 0;  // timing ablations (wrong results)
     g.ok = 1;
     return g;
 }

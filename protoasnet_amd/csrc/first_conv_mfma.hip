@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void first_conv_mfma_kernel(const TIN* __re
 // Slot of tap 0 inside the 8-wide window, or -1 when this layer is not covered: (1,kh,kw) stride (1,2,2), slot + kw <= 8 with the window
 // start on a multiple of 4 input columns (slot = (4 - pw) mod 4), Wi % 4 == 0, bf16 output, Cout_p <= 64, C*kh <= 22.
 int first_conv_mfma_slot(const pasn_conv_desc& d, int out_dtype) {
-    if (const char* e = getenv("PASN_NO_FC_MFMA"))
+    if (const char* e = tune("PASN_NO_FC_MFMA"))
         if (e[0] == '1') return -1;
     if (out_dtype != PASN_BF16 || d.kt != 1 || d.st != 1 || d.pt != 0 || d.sh != 2 || d.sw != 2) return -1;
     if (d.Cin != 1 && d.Cin != 3) return -1;

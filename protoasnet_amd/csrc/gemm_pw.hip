@@ -289,7 +289,7 @@ static bool is_pointwise(const pasn_conv_desc& d) {
 }
 
 bool gemm_pw_applicable(const pasn_conv_desc& d, int dtype) {
-    if (const char* e = getenv("PASN_NO_GEMM"))
+    if (const char* e = tune("PASN_NO_GEMM"))
         if (e[0] == '1') return false;
     (void)dtype;
     if (d.w_rows % 128 != 0 || d.w_kc % 8 != 0) return false;
@@ -306,7 +306,7 @@ int launch_gemm_pw(const void* x, const void* w, const float* scale, const float
     // narrow tile only when ALL the output channels fit it (Cout <= 64: 216 -> 199 us on R(2+1)D's 144 -> 64 layers).  Splitting
     // 144 / 288 / 576 channels into 64-wide tiles instead of a half-empty last 128-wide one was measured 10-19 % SLOWER: the kernel
     // is bound by staging the activation tile (re-read once per channel tile), not by the MFMAs spent on zero rows.
-    static const bool no_narrow = getenv("PASN_NO_GEMM_BN64") != nullptr;
+    const bool no_narrow = tune("PASN_NO_GEMM_BN64") != nullptr;
     const bool narrow = !no_narrow && d.Cout_p <= 64;
     const int BN = narrow ? 64 : 128, BM = narrow ? 256 : 128;
     const size_t tiles = (size_t)2 * (BM + BN) * (G_BK + CH) * sizeof(T);

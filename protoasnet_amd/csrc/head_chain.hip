@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512) void xproto_chain_kernel(HcArgs a) {
 static int hc_rows(const pasn_xproto_desc& d) { return d.Cbp <= 192 ? 104 : 96; }
 
 bool xproto_chain_supported(const pasn_xproto_desc& d, int dtype) {
-    if (const char* e = getenv("PASN_HEAD_CHAIN"))
+    if (const char* e = tune("PASN_HEAD_CHAIN"))
         if (e[0] == '0') return false;
     if (dtype != PASN_BF16) return false;
     if (d.D != 256 || d.Dp != 256 || d.Hd != 128 || d.Hp != 128) return false;

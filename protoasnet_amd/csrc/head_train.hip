@@ -243,7 +243,7 @@ int xproto_tail_pool_finish(const void* z, const void* r, const float* protos, c
 // the inference head) instead of N x P/8 blocks that each walk all S positions (R(2+1)D-18, 8 clips: 32 blocks, 438 us per step).
 extern "C" size_t pasn_xproto_tail_workspace_bytes(const pasn_xproto_desc* d) {
     if (!d || d->N <= 0 || d->S <= 0 || d->P <= 0 || d->D <= 0) return 0;
-    if (const char* e = getenv("PASN_NO_TAIL_MFMA"))
+    if (const char* e = tune("PASN_NO_TAIL_MFMA"))
         if (e[0] == '1') return 0;
     if (d->D % 4 != 0 || d->D > 1024) return 0;
     return (size_t)d->N * xproto_tail_splits(*d) * d->P * d->D * sizeof(float);

@@ -299,7 +299,7 @@ static bool xp_desc_ok(const pasn_xproto_desc* d) {
 }
 
 static bool xp_pool_mfma() {
-    const char* e = getenv("PASN_POOL_VALU");
+    const char* e = tune("PASN_POOL_VALU");
     return !(e && e[0] == '1');
 }
 

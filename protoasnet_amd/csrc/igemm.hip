@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const __bf16* __rest
 // Instance for this layer: NT channel tiles per block in the low decimal digit, MT position tiles per wave in the next; 0 = not this kernel.
 int igemm_nt(const pasn_conv_desc& d, int dtype) {
     if (dtype != PASN_BF16) return 0;
-    if (const char* e = getenv("PASN_NO_IGEMM"))
+    if (const char* e = tune("PASN_NO_IGEMM"))
         if (e[0] == '1') return 0;
     const bool pointwise = d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1;
     if (pointwise || d.in_swish) return 0;                 // the pointwise kernels keep those
@@ -203,7 +203,7 @@ int igemm_nt(const pasn_conv_desc& d, int dtype) {
     if (taps == 1) return 0;                               // strided 1x1x1 shortcuts stay on the x-tile kernel
     if (taps > 32 || d.w_kc % 16 != 0 || d.w_kc < d.Cin_p || d.Cin_p * taps < 64) return 0;
     if ((long)d.N * d.Ti * d.Hi * d.Wi * d.Cin_p >= (1L << 31) || (long)d.w_rows * taps * d.w_kc >= (1L << 31)) return 0;  // 32-bit offsets
-    if (const char* e = getenv("PASN_IGEMM_NT")) return atoi(e);
+    if (const char* e = tune_dev("PASN_IGEMM_NT")) return atoi(e);
     // cover the channels with as few, as full blocks as possible: 144 -> one block of 160, 288 -> two of 160, 576 -> four of 160 (640);
     // 64 -> 64; everything else in 128s
     const int c = d.Cout_p;
@@ -233,7 +233,7 @@ int launch_igemm(const void* x, const void* w, const float* scale, const float* 
     const long M = (long)d.N * d.To * d.Ho * d.Wo;
     const dim3 grid(ceil_div(M, 128L * mt), ceil_div(d.Cout_p, nt * 32)), block(256);
     pasn_conv_desc dk = d;
-    if (const char* e = getenv("PASN_IGEMM_RR"))
+    if (const char* e = tune_dev("PASN_IGEMM_RR"))
         if (e[0] == '1') dk.w_frag = 7;  // A/B switch: round-robin tile placement
 #define PASN_IG(NT_, MT_)                                                                                                     \
     if (nt == NT_ && mt == MT_) {                                                                                             \

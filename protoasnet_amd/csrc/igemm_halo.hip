@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
 // Geometry of the halo tile for this layer: tile rows (padded to 16) or 0 when the layer is not a stride-1 "same" (1,k,k) / (3,1,1) conv
 // or the tile does not fit two blocks per CU.
 int igemm_halo_mode(const pasn_conv_desc& d) {
-    if (const char* e = getenv("PASN_NO_HALO"))
+    if (const char* e = tune("PASN_NO_HALO"))
         if (e[0] == '1') return 0;
     if (d.st != 1 || d.sh != 1 || d.sw != 1 || d.To != d.Ti || d.Ho != d.Hi || d.Wo != d.Wi) return 0;
     if (d.kt == 1 && d.pt == 0 && d.kh == 3 && d.kw == 3 && d.ph == 1 && d.pw == 1) return 1;
@@ -335,7 +335,7 @@ static int halo_rows16(const pasn_conv_desc& d, int mode, int mt) {
 // (3,1,1) layers: slice-granular pipeline (six weight stages) where it fits two blocks per CU; PASN_HALO_SP=0: the per-tap schedule everywhere
 static bool halo_sp(int mode, int r16, int nt) {
     if (mode != 2) return false;
-    if (const char* e = getenv("PASN_HALO_SP"))
+    if (const char* e = tune_dev("PASN_HALO_SP"))
         if (e[0] == '0') return false;
     return (size_t)2 * r16 * 64 + (size_t)6 * nt * 32 * 64 + (size_t)nt * 32 * 8 <= 80 * 1024;
 }
@@ -365,7 +365,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
                            bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                                               \
         return check_launch("igemm_halo_kernel");                                                                                 \
     }
-    if (const char* e = getenv("PASN_HALO_ABL")) {  // timing-only builds of the 160-channel spatial instance
+    if (const char* e = tune_dev("PASN_HALO_ABL")) {  // timing-only builds of the 160-channel spatial instance
         const int abl = atoi(e);
 #define PASN_IHA(A_)                                                                                                              \
         if (abl == A_ && nt == 5 && mt == 2 && mode == 1) {                                                                       \

@@ -378,7 +378,7 @@ PwGeom pw_geom(const pasn_conv_desc& d, int dtype) {
     const bool pointwise = d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 &&
                            d.ph == 0 && d.pw == 0;
     if (!pointwise) return g;
-    if (const char* e = getenv("PASN_NO_PWCONV"))
+    if (const char* e = tune("PASN_NO_PWCONV"))
         if (e[0] == '1') return g;
     const int kstep = dtype == PASN_BF16 ? 16 : 8;
     const int ks = d.w_kc / kstep;
@@ -397,7 +397,7 @@ PwGeom pw_geom(const pasn_conv_desc& d, int dtype) {
 // (8, 2, 4): 108 -> 48 + 48 -> 48 stride 2.  0 = not covered.
 int pw_short_ks2(const pasn_conv_desc& d, const pasn_conv_desc& d2, int dtype) {
     if (dtype != PASN_BF16) return 0;
-    if (const char* e = getenv("PASN_NO_SHORTFUSE"))
+    if (const char* e = tune("PASN_NO_SHORTFUSE"))
         if (e[0] == '1') return 0;
     const PwGeom g = pw_geom(d, dtype);
     if (!g.TM) return 0;

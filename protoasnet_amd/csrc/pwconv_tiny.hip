@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void pwconv_tiny_kernel(const T* __restrict__ x
 
 // pointwise conv (stride 1, plain [rows][kc] weights, no input transform) on few positions
 bool pw_tiny_applicable(const pasn_conv_desc& d, int dtype, bool has_gate) {
-    if (const char* e = getenv("PASN_NO_PWTINY"))
+    if (const char* e = tune("PASN_NO_PWTINY"))
         if (e[0] == '1') return false;
     if ((dtype != PASN_F32 && dtype != PASN_BF16) || has_gate || d.in_swish || d.w_frag != 0) return false;
     if (d.kt != 1 || d.kh != 1 || d.kw != 1 || d.pt || d.ph || d.pw || d.st != 1 || d.sh != 1 || d.sw != 1) return false;

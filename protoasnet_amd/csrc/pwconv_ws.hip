@@ -444,7 +444,7 @@ static int ws_ks(int nks) {
 WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_res, bool se_prologue, const pasn_conv_desc* d2) {
     WsGeom g{};
     if (d2) {  // chained pair: the second conv must be a plain stride-1 pointwise conv on the first one's output
-        if (const char* e = getenv("PASN_WSPAIR"))
+        if (const char* e = tune("PASN_WSPAIR"))
             if (e[0] == '0') return g;
         const bool ok2 = d2->kt == 1 && d2->kh == 1 && d2->kw == 1 && !d2->pt && !d2->ph && !d2->pw && d2->st == 1 && d2->sh == 1 && d2->sw == 1 &&
                          d2->N == d.N && d2->To == d.To && d2->Ho == d.Ho && d2->Wo == d.Wo && d2->Cin == d.Cout && d2->Cin_p == d.Cout_p &&
@@ -452,11 +452,11 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
                          d2->w_rows >= ((d2->Cout_p + 31) / 32) * 32 && (long)d.N * d.To * d.Ho * d.Wo * d2->Cout_p * 2 < (1L << 30);
         if (!ok2) return g;
     }
-    if (const char* e = getenv("PASN_WS"))
+    if (const char* e = tune("PASN_WS"))
         if (e[0] == '0') return g;
     if (dtype != PASN_BF16 || d.w_frag != 1) return g;
     if (d.kt != 1 || d.kh != 1 || d.kw != 1 || d.pt || d.ph || d.pw || d.st != 1 || d.sh != 1 || d.sw != 1) return g;
-    const int mink = getenv("PASN_WS_MINK") ? atoi(getenv("PASN_WS_MINK")) : 48;  // stage-2 layers (Cin_p 24 / 56): the register-resident kernel is faster (48: lets the 48 -> 216 expand conv in, 10.57 -> 10.60 k clips/s)
+    const int mink = tune("PASN_WS_MINK") ? atoi(tune("PASN_WS_MINK")) : 48;  // stage-2 layers (Cin_p 24 / 56): the register-resident kernel is faster (48: lets the 48 -> 216 expand conv in, 10.57 -> 10.60 k clips/s)
     if (d.Cin_p < mink || d.w_kc % 16 != 0 || d.w_kc < d.Cin_p) return g;
     const int nks = d.w_kc / 16, ks = ws_ks(nks);
     if (!ks) return g;
@@ -466,13 +466,13 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     const int ctiles = (d.Cout_p + 31) / 32;
     if (d.w_rows < ctiles * 32) return g;
     const bool xf = has_gate || d.in_swish;
-    if (xf && getenv("PASN_WS_GATED") && getenv("PASN_WS_GATED")[0] == '0') return g;
+    if (xf && tune("PASN_WS_GATED") && tune("PASN_WS_GATED")[0] == '0') return g;
     // Routing by measurement (X3D-S at 32 x 16 x 224^2, in the pipeline, us per launch old -> new; profiles/README round-3 entry 59):
     //   project + residual, plain:  108->48 37.5 -> 32, 432->192 22.7 -> 18.8            (216->96 rides the chained pair launch)
     //   project + residual, gated:  432->192 33 -> 27;   108->48 45 -> 54, 216->96 31 -> 34: the in-place transform pass costs more there
     //   expand:                     96->432 38 -> 30.5, 48->216 48 -> 45;   48->108 28 -> 29.5, 192->432 20 -> 21.5, head convs 10.6 -> 12.8
     // PASN_WS=2 takes every layer the kernel covers (the parity tests do).
-    const char* mode = getenv("PASN_WS");
+    const char* mode = tune("PASN_WS");
     if (!(mode && mode[0] == '2') && !d2) {
         bool take;
         if (xf) take = ks == 28 || (se_prologue && ks == 14);  // (with the gate in the prologue the stand-alone gate launch is saved as well)
@@ -484,9 +484,9 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     g.gy = (ctiles + 7) / 8;
     g.CT = (ctiles + g.gy - 1) / g.gy;
     g.PT = g.CT >= 5 ? 1 : g.CT >= 3 ? 2 : g.CT == 2 ? 4 : 8;
-    if (const char* e = getenv("PASN_WS_PT")) g.PT = max(1, min(8 / g.CT, atoi(e)));
+    if (const char* e = tune("PASN_WS_PT")) g.PT = max(1, min(8 / g.CT, atoi(e)));
     g.MT = (ks <= 16 && g.PT < 4) ? 2 : 1;
-    if (const char* e = getenv("PASN_WS_MT")) g.MT = ks <= 16 ? max(1, min(2, atoi(e))) : 1;
+    if (const char* e = tune("PASN_WS_MT")) g.MT = ks <= 16 ? max(1, min(2, atoi(e))) : 1;
     int ks2 = 0, y1bytes = 0;
     if (d2) {  // pair mode: 64-position tiles, (channel tile, position half) per wave in the first conv, channel tile = wave in the second
         const int nks2 = d2->w_kc / 16, ct2 = (d2->Cout_p + 31) / 32;
@@ -494,7 +494,7 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
         if (!ks2 || !((ks == 14 && ks2 == 6) || (ks == 8 && ks2 == 4)) || g.gy != 1 || g.CT * 2 > 8 || ct2 > 8) return WsGeom{};
         // measured in the pipeline (profiles/README entry 61): 216 -> 96 -> 216 plain 34.6 us vs 36.4 (pwconv_xpair), gated 46 vs 43 -- but 39 vs 53 once
         // the gate is computed in the prologue and its launch is gone; 108 -> 48 -> 108: 70 / 92 us against 61 / 73 for the two separate launches
-        const char* pm = getenv("PASN_WSPAIR");
+        const char* pm = tune("PASN_WSPAIR");
         const bool all = pm && pm[0] == '2';
         if (!all && (ks != 14 || (xf && !se_prologue))) return WsGeom{};
         g.PT = 2;
@@ -518,22 +518,22 @@ WsGeom pw_ws_geom(const pasn_conv_desc& d, int dtype, bool has_gate, bool has_re
     const int BM = 32 * g.PT * g.MT;
     if (S < BM) return g;  // a tile may touch at most two clips (two staged gate rows)
     g.NS = (xf || 3 * g.stage_bytes + y1bytes <= 150 * 1024) ? 3 : 2;
-    if (const char* e = getenv("PASN_WS_NS")) g.NS = xf ? 3 : max(2, min(4, atoi(e)));
+    if (const char* e = tune("PASN_WS_NS")) g.NS = xf ? 3 : max(2, min(4, atoi(e)));
     while (g.NS > 2 && g.NS * g.stage_bytes + y1bytes > 160 * 1024) --g.NS;
     g.lds_bytes = g.NS * g.stage_bytes + y1bytes;
     g.KS2 = ks2;
     int bpc = g.lds_bytes <= 78 * 1024 ? 2 : 1;
-    if (const char* e = getenv("PASN_WS_BPC")) bpc = max(1, atoi(e));
+    if (const char* e = tune("PASN_WS_BPC")) bpc = max(1, atoi(e));
     const long max_slots = max(1, 256 * bpc / g.gy);
     long rpb = (M + max_slots - 1) / max_slots;             // equal row shares ...
-    if (const char* e = getenv("PASN_WS_ROWS")) rpb = max(rpb, (long)atoi(e));
+    if (const char* e = tune_dev("PASN_WS_ROWS")) rpb = max(rpb, (long)atoi(e));
     if (rpb >= 16L * BM) rpb = (rpb + BM - 1) / BM * BM;     // ... whole tiles where the ragged last tile would not matter anyway
     g.rpb = (int)rpb;
     g.nslots = (int)((M + rpb - 1) / rpb);
     if (se_prologue && (rpb > S || 3 * g.stage_bytes > 160 * 1024 || d.Cin_p > 512 || GPR_fits(ks, d.Cin_p) == 0)) return WsGeom{};  // a block touches <= 2 clips; scratch in stage 2
-    g.abl = getenv("PASN_WS_ABL") ? atoi(getenv("PASN_WS_ABL")) : 0;
+    g.abl = tune_dev("PASN_WS_ABL") ? atoi(tune_dev("PASN_WS_ABL")) : 0;
     g.NW = g.CT * g.PT;
-    if (xf && !(getenv("PASN_WS_HELP") && getenv("PASN_WS_HELP")[0] == '0')) g.NW = 8;
+    if (xf && !(tune_dev("PASN_WS_HELP") && tune_dev("PASN_WS_HELP")[0] == '0')) g.NW = 8;
     if (d2) g.NW = 8;  // covers the second conv's channel tiles (<= 8) and the first conv's (channel tile, half) grid  // helper waves: the input transform spread evenly over the four SIMDs
     g.ok = 1;
     return g;

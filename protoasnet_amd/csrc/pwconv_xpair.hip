@@ -279,7 +279,7 @@ static size_t xp_lds(int ks1, int w1_kc) {
 int pw_xpair_ks(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, int* ks2_out) {
     if (dtype != PASN_BF16) return 0;
     {
-        const char* e = getenv("PASN_NO_XPAIR");
+        const char* e = tune("PASN_NO_XPAIR");
         if (e && e[0] == '1') return 0;
     }
     if (!xp_pointwise(d1) || !xp_pointwise(d2) || d2.in_swish) return 0;
@@ -293,7 +293,7 @@ int pw_xpair_ks(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, i
     // measured on X3D-S: the 216 -> 96 -> 216 pairs (stage 4) save ~5 us each (37 vs 21 + 21 us; gated 50 vs 34 + 21); the
     // 108 -> 48 -> 108 pairs (stage 3) are even with the separate launches, so only K1 > 128 takes the chained kernel
     // (PASN_XPAIR_ALL=1 enables the narrower instances, which the tests exercise)
-    const bool all = getenv("PASN_XPAIR_ALL") && getenv("PASN_XPAIR_ALL")[0] == '1';
+    const bool all = tune("PASN_XPAIR_ALL") && tune("PASN_XPAIR_ALL")[0] == '1';
     const int ks1 = nks1 <= 8 ? (all ? 8 : 0) : nks1 <= 14 ? 14 : 0;
     const int ks2 = nks2 <= 4 ? 4 : nks2 <= 6 ? 6 : 0;
     if (!ks1 || !ks2 || ks2 * 16 != t1 * 32) return 0;  // stage 1's tiles must fill stage 2's K extent exactly

@@ -261,10 +261,10 @@ static size_t xt_lds(const pasn_conv_desc& d, int dtype) {
 int pw_xtile_ks(const pasn_conv_desc& d, int dtype) { return xt_ks(d, dtype); }
 
 bool pw_xtile_applicable(const pasn_conv_desc& d, int dtype) {
-    if (const char* e = getenv("PASN_NO_XTILE"))
+    if (const char* e = tune("PASN_NO_XTILE"))
         if (e[0] == '1') return false;
     // narrow stride-1 layers belong to pwconv.hip (weights for ALL channels in registers); strided ones have no such kernel
-    const int mink = xt_strided(d) ? 16 : (getenv("PASN_XT_MINK") ? atoi(getenv("PASN_XT_MINK")) : 32);
+    const int mink = xt_strided(d) ? 16 : (tune_dev("PASN_XT_MINK") ? atoi(tune_dev("PASN_XT_MINK")) : 32);
     if (!xt_pointwise(d) || d.Cin_p < mink) return false;
     if (xt_strided(d) && d.in_swish) return false;  // narrower layers: pwconv.hip (weights for ALL channels in registers)
     const int ch = dtype == PASN_BF16 ? 8 : 4;

@@ -140,7 +140,7 @@ using namespace pasn;
 
 extern "C" int pasn_x3d_stem_supported(const pasn_conv_desc* d) {
     if (!d) return 0;
-    if (const char* e = getenv("PASN_NO_STEM"))
+    if (const char* e = tune("PASN_NO_STEM"))
         if (e[0] == '1') return 0;
     return (d->Cin == 3 || d->Cin == 1) && d->kt == 1 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 0 &&
            d->ph == 1 && d->pw == 1 && d->To == d->Ti && d->Cout_p == 24 && d->Cout <= 24;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void x3d_stem_mfma_kernel(const TIN* __rest
 }
 
 int x3d_stem_mfma_supported(const pasn_conv_desc& d, int out_dtype) {
-    if (const char* e = getenv("PASN_NO_STEM_MFMA"))
+    if (const char* e = tune("PASN_NO_STEM_MFMA"))
         if (e[0] == '1') return 0;
     if (out_dtype != PASN_BF16 || (d.Cin != 1 && d.Cin != 3) || d.Cout_p > 32) return 0;
     if (d.kt != 1 || d.kh != 3 || d.kw != 3 || d.st != 1 || d.sh != 2 || d.sw != 2 || d.pt != 0 || d.ph != 1 || d.pw != 1) return 0;

@@ -622,11 +622,11 @@ extern "C" int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, c
 // per-block fp32 partials -- a conv output without bias has |mean| ~ std.
 extern "C" int pasn_dwconv3d_stats_rows(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0 || d->Cout_p > 2048) return 0;
-    if (const char* e = getenv("PASN_NO_DW_STATS"))
+    if (const char* e = tune("PASN_NO_DW_STATS"))
         if (e[0] == '1') return 0;
     // stride-1 layers: the matrix-core stencil with the statistics epilogue (one partial row pair per (clip, chunk)); PASN_DW_STATS_MFMA=0: the
     // VALU stencil everywhere, as before round 3
-    if (!(getenv("PASN_DW_STATS_MFMA") && getenv("PASN_DW_STATS_MFMA")[0] == '0'))
+    if (!(tune("PASN_DW_STATS_MFMA") && tune("PASN_DW_STATS_MFMA")[0] == '0'))
         if (const DwMfmaGeom mf = dw_mfma_geom(*d, dtype); mf.ok && !mf.abl) return mf.chunks;
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     return m.WT ? m.bpc : 0;
@@ -644,7 +644,7 @@ extern "C" int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const floa
     const int Cp = d->Cout_p, S = d->To * d->Ho * d->Wo;
     int rc;
     const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
-    if (mf.ok && !mf.abl && mf.chunks == rows && !(getenv("PASN_DW_STATS_MFMA") && getenv("PASN_DW_STATS_MFMA")[0] == '0')) {
+    if (mf.ok && !mf.abl && mf.chunks == rows && !(tune("PASN_DW_STATS_MFMA") && tune("PASN_DW_STATS_MFMA")[0] == '0')) {
         rc = launch_dw_mfma(x, w, scale, bias, y, ws, *d, mf, s, 1, running_mean);  // moments shifted by the running mean (as it stands now:
     } else {                                                                           // the finalize kernel reads it before updating it)
         const DwMarchGeom m = dw_march_geom(*d, dtype);
@@ -662,7 +662,7 @@ extern "C" int pasn_dwconv3d_dgrad_reduce_rows(const pasn_conv_desc* d, int dtyp
     if (!d || d->sw != 1 || d->sh != 1) return 0;
     // OPT-IN (PASN_DW_DGRAD_REDUCE=1): measured, the fusion does not pay -- the stencil is bound by vector-instruction issue, and the ~25
     // extra instructions per output vector cost what the separate pass did (X3D-S: 22 launches 2.31 ms fused vs 1.37 + 0.87 ms)
-    const char* on = getenv("PASN_DW_DGRAD_REDUCE");
+    const char* on = tune("PASN_DW_DGRAD_REDUCE");
     if (!on || on[0] != '1') return 0;
     if (pasn_dwconv3d_stats_rows(d, dtype) == 0) return 0;
     const DwMarchGeom m = dw_march_geom(*d, dtype);

@@ -281,7 +281,7 @@ extern "C" int pasn_conv3d_wgrad(const void* x, const void* dy, float* dw, const
     PASN_REQUIRE(x && dy && dw && d, "null pointer");
     PASN_REQUIRE(d->Cin_p % 8 == 0 && d->Cout_p % 8 == 0 && d->Cin <= d->Cin_p && d->Cout <= d->Cout_p, "bad channel extents");
     const int taps = d->kt * d->kh * d->kw;
-    if (dtype == PASN_BF16 && !getenv("PASN_NO_WGRAD_LDS") && pw_wgrad_bf16(x, dy, dw, *d, (hipStream_t)stream))
+    if (dtype == PASN_BF16 && !tune("PASN_NO_WGRAD_LDS") && pw_wgrad_bf16(x, dy, dw, *d, (hipStream_t)stream))
         return check_launch("conv3d_wgrad");
     const int co_tiles = ceil_div(d->Cout, 32), ci_tiles = ceil_div(d->Cin, 32);
     const long tiles = (long)co_tiles * ci_tiles * taps;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void first_conv_im2col_kernel(const TIN* __res
 }
 
 extern "C" size_t pasn_first_conv_wgrad_workspace_bytes(const pasn_conv_desc* d, int dtype) {
-    if (!d || dtype != PASN_BF16 || getenv("PASN_NO_FIRST_IM2COL")) return 0;
+    if (!d || dtype != PASN_BF16 || tune("PASN_NO_FIRST_IM2COL")) return 0;
     const int colp = (3 * d->kh * d->kw + 7) / 8 * 8;
     if (colp > 512) return 0;
     return (size_t)d->N * d->To * d->Ho * d->Wo * colp * sizeof(__bf16);
@@ -465,7 +465,7 @@ extern "C" int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, con
     PASN_REQUIRE(dy && w && dx && d, "null pointer");
     PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0, "depthwise conv keeps the channel stride");
     if (d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 1 && d->ph == 1 && d->pw == 1 &&
-        d->Cout_p <= 512 && !getenv("PASN_NO_DGRAD_S2")) {
+        d->Cout_p <= 512 && !tune("PASN_NO_DGRAD_S2")) {
         const size_t items = (size_t)d->N * d->Ti * ((d->Hi + 1) / 2) * ((d->Wi + 1) / 2) * (d->Cin_p / 4);
         const int nb = (int)std::min<size_t>((items + 255) / 256, 4096);  // grid-stride: the weight staging amortises over many patches
         const size_t wlds = (size_t)27 * d->Cout_p * sizeof(float);  // <= 55 KB (Cout_p <= 512 checked above)
@@ -485,7 +485,7 @@ extern "C" int pasn_dwconv3d_dgrad(const void* dy, const float* w, void* dx, con
 
 extern "C" size_t pasn_dwconv3d_wgrad_workspace_floats(const pasn_conv_desc* d) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 || d->Cout_p > 2048) return 0;
-    const size_t fast = getenv("PASN_NO_DWWG_STRIP") ? 0 : dw_wgrad_strip_floats(*d);
+    const size_t fast = tune("PASN_NO_DWWG_STRIP") ? 0 : dw_wgrad_strip_floats(*d);
     if (fast) return fast;
     const long R = (long)d->N * d->To * d->Ho * d->Wo;
     const long rpc = dw_wgrad_rows_per_chunk(*d);
@@ -497,7 +497,7 @@ extern "C" int pasn_dwconv3d_wgrad(const void* x, const void* dy, float* ws, flo
     PASN_REQUIRE(x && dy && ws && dw && d, "null pointer");
     PASN_REQUIRE(d->Cin_p == d->Cout_p && d->Cin_p % 8 == 0 && d->Cout_p <= 2048, "depthwise conv keeps the channel stride (<= 2048)");
     PASN_REQUIRE(d->kh * d->kw <= 9, "spatial window above 3x3 is not covered");
-    if (!getenv("PASN_NO_DWWG_STRIP") && dw_wgrad_strip(x, dy, ws, dw, *d, dtype, (hipStream_t)stream)) return check_launch("dwconv3d_wgrad");
+    if (!tune("PASN_NO_DWWG_STRIP") && dw_wgrad_strip(x, dy, ws, dw, *d, dtype, (hipStream_t)stream)) return check_launch("dwconv3d_wgrad");
     const long R = (long)d->N * d->To * d->Ho * d->Wo;
     const long rpc = dw_wgrad_rows_per_chunk(*d);
     const int chunks = (int)((R + rpc - 1) / rpc);
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __rest
 }
 
 static bool pw_wgrad_tile(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s) {
-    if (const char* e = getenv("PASN_NO_WGRAD_TILE"))
+    if (const char* e = tune("PASN_NO_WGRAD_TILE"))
         if (e[0] == '1') return false;
     const bool pointwise = d.kt * d.kh * d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
     const int co_tiles = ceil_div(d.Cout_p, 32), ci_tiles = ceil_div(d.Cin_p, 32);
@@ -771,7 +771,7 @@ static bool pw_wgrad_tile(const void* x, const void* dy, float* dw, const pasn_c
     const long R = (long)d.N * d.To * d.Ho * d.Wo;
     const int gy = co_pairs * ci_pairs;
     // row partitions: about four blocks per CU in flight, at least two 128-row steps each
-    const long target = getenv("PASN_WGT_BLOCKS") ? atol(getenv("PASN_WGT_BLOCKS")) : 1024;
+    const long target = tune_dev("PASN_WGT_BLOCKS") ? atol(tune_dev("PASN_WGT_BLOCKS")) : 1024;
     long parts = std::max<long>(1, std::min<long>(target / gy + 1, R / (2 * WT_KT)));
     long rpb = (ceil_div(R, parts) + WT_KT - 1) / WT_KT * WT_KT;
     const dim3 grid((unsigned)ceil_div(R, rpb), gy);
@@ -792,7 +792,7 @@ bool pw_wgrad_bf16(const void* x, const void* dy, float* dw, const pasn_conv_des
     if ((KT / 8) * (d.Cout_p / 8 + d.Cin_p / 8) > 512) return false;  // the kernel's register pipeline holds 2 patches per thread
     int tpw = ceil_div(ntiles, 4);
     tpw = tpw <= 1 ? 1 : tpw <= 2 ? 2 : tpw <= 4 ? 4 : 8;
-    static const int tpw_cap = getenv("PASN_WG_TPW") ? atoi(getenv("PASN_WG_TPW")) : 4;  // 8 tiles per wave (occupancy 1) measured 7 % slower
+    const int tpw_cap = tune_dev("PASN_WG_TPW") ? atoi(tune_dev("PASN_WG_TPW")) : 4;  // 8 tiles per wave (occupancy 1) measured 7 % slower
     tpw = std::min(tpw, std::max(1, tpw_cap));
     const int gy = ceil_div(ntiles, 4 * tpw);
 #define PW(K, T) launch_pw_wgrad_bf16<K, T>(x, dy, dw, d, co_tiles, ci_tiles, gy, s)
@@ -1183,7 +1183,7 @@ namespace pasn {
 
 // T-marching form: 3x3x3, temporal stride 1 and pad 1, frames kept (To == Ti)
 static bool dw_wgrad_march_ok(const pasn_conv_desc& d) {
-    if (const char* e = getenv("PASN_NO_DWWG_MARCH"))
+    if (const char* e = tune("PASN_NO_DWWG_MARCH"))
         if (e[0] == '1') return false;
     return d.kt == 3 && d.st == 1 && d.pt == 1 && d.To == d.Ti && d.kh == 3 && d.kw == 3 && d.ph == 1 && d.pw == 1;
 }
@@ -1227,7 +1227,7 @@ bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const p
         hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div((long)27 * d.Cout_p, 64)), dim3(256), 0, s, ws, dw, (int)blocks, 27, d.Cout, d.Cout_p);
         return true;
     }
-    static const bool fuse3 = getenv("PASN_DWWG_FUSED") ? atoi(getenv("PASN_DWWG_FUSED")) != 0 : false;
+    const bool fuse3 = tune("PASN_DWWG_FUSED") ? atoi(tune("PASN_DWWG_FUSED")) != 0 : false;
     const bool na3 = fuse3 && d.kt == 3;
     const dim3 grid((unsigned)g.blocks, 1, na3 ? 1 : d.kt);
 #define DWS(T, SWv, WTv)                                                                                                              \

@@ -394,12 +394,12 @@ struct WgGather {
 };
 
 static bool wgrad_gather_geom(const pasn_conv_desc& d, int dtype, WgGather& g) {
-    if (const char* e = getenv("PASN_NO_WGRAD_GATHER"))
+    if (const char* e = tune("PASN_NO_WGRAD_GATHER"))
         if (e[0] == '1') return false;
     if (dtype != PASN_BF16 || d.Cin_p % 8 || d.Cout_p % 8) return false;
     g.taps = d.kt * d.kh * d.kw;
     const bool strided = d.st != 1 || d.sh != 1 || d.sw != 1;
-    static const bool det = getenv("PASN_WGRAD_DET") ? atoi(getenv("PASN_WGRAD_DET")) != 0 : false;
+    const bool det = tune("PASN_WGRAD_DET") ? atoi(tune("PASN_WGRAD_DET")) != 0 : false;
     if (g.taps == 1 && !strided && !det) return false;  // plain pointwise layers keep their (atomic) kernels unless asked
     if (g.taps > 27) return false;
     const long R = (long)d.N * d.To * d.Ho * d.Wo, Rin = (long)d.N * d.Ti * d.Hi * d.Wi;
@@ -420,7 +420,7 @@ static bool wgrad_gather_geom(const pasn_conv_desc& d, int dtype, WgGather& g) {
 }
 
 bool wgrad_halo_geom(const pasn_conv_desc& d, int dtype, WhGeom& g) {
-    if (const char* e = getenv("PASN_NO_WGRAD_HALO"))
+    if (const char* e = tune("PASN_NO_WGRAD_HALO"))
         if (e[0] == '1') return false;
     if (dtype != PASN_BF16) return false;
     if (d.st != 1 || d.sh != 1 || d.sw != 1 || d.To != d.Ti || d.Ho != d.Hi || d.Wo != d.Wi) return false;

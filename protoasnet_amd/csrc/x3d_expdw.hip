@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
 // de = the expand conv (1x1x1, stride 1, + BN + ReLU), d = the depthwise conv (3x3x3, stride (1,s,s), s = 1 or 2, pad 1) on its output.
 XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     XeGeom g{};
-    const char* mode = getenv("PASN_EXPDW");  // 0: off
+    const char* mode = tune("PASN_EXPDW");  // 0: off
     if (mode && mode[0] == '0') return g;
     if (dtype != PASN_BF16) return g;
     const int ss = d.sh;
@@ -522,7 +522,7 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     // One exception: the SE blocks of the widest stride-1 stage (no Swish in the stencil epilogue, planes >= 56 wide): 148 vs 55 + 107 us,
     // 10.56 -> 10.67 k clips/s end to end (entry 80).  PASN_EXPDW_S1=0: off.
     // With the ReLU-only expand epilogue (entry 81) the Swish (non-SE) blocks of those planes win too, narrowly (10 845 -> 10 875 clips/s).
-    const char* s1m = getenv("PASN_EXPDW_S1");  // 0: off; 1: the SE blocks only
+    const char* s1m = tune("PASN_EXPDW_S1");  // 0: off; 1: the SE blocks only
     const bool s1 = ss == 1 && d.Wo >= 56 && !(s1m && s1m[0] == '0') && (d.act == PASN_ACT_NONE || (d.act == PASN_ACT_SWISH && !(s1m && s1m[0] == '1')));
     if (ss != 2 && !s1) return g;
     const bool dw = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sw == ss && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
@@ -541,7 +541,7 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     g.KS = 2;
     g.XS = (de.Cin_p / 8) | 1;
     g.xtb = ((POS + 3) * g.XS * 16 + 1023) / 1024 * 1024;  // + 3 positions: lanes 29 .. 31 of the last staged row read past it (stride 2)
-    g.fuse = !(getenv("PASN_EXPDW_FUSE") && getenv("PASN_EXPDW_FUSE")[0] == '0');
+    g.fuse = !(tune("PASN_EXPDW_FUSE") && tune("PASN_EXPDW_FUSE")[0] == '0');
     g.lds = 2 * FRB + 2 * g.xtb + 512 + 1088;
     // two blocks per CU: block width 24 takes 78.5 KB.  (48 channels -- stage 4's first block -- need 107 KB = one block per CU: built,
     // correct, and slower end to end, 10.37 k vs 10.58 k clips/s: not taken.)
@@ -550,8 +550,8 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     g.RTH = ceil_div(d.Ho, NT);
     g.RTW = ceil_div(d.Wo, XeR<1>::BW);
     const int regions = g.RTH * g.RTW;
-    const int force_tc = getenv("PASN_EXPDW_TC") ? atoi(getenv("PASN_EXPDW_TC")) : 0;
-    const int force_upb = getenv("PASN_EXPDW_UPB") ? atoi(getenv("PASN_EXPDW_UPB")) : 0;
+    const int force_tc = tune("PASN_EXPDW_TC") ? atoi(tune("PASN_EXPDW_TC")) : 0;
+    const int force_upb = tune("PASN_EXPDW_UPB") ? atoi(tune("PASN_EXPDW_UPB")) : 0;
     double best = 1e30;
     for (int tc = d.To;; tc = (tc + 1) / 2) {
         const int tcu = force_tc ? std::min(force_tc, d.To) : tc;
@@ -573,7 +573,7 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
         if (force_tc || tc <= 4) break;
     }
     g.bpc = g.CQ * g.chunks;
-    g.abl = getenv("PASN_EXPDW_ABL") ? atoi(getenv("PASN_EXPDW_ABL")) : 0;
+    g.abl = tune_dev("PASN_EXPDW_ABL") ? atoi(tune_dev("PASN_EXPDW_ABL")) : 0;
     g.ok = 1;
     return g;
 }

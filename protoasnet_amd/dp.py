@@ -4,7 +4,9 @@ The reference trains on one GPU (no DistributedDataParallel anywhere in src/agen
 8-GPU data-parallel step.  Clips shard across ranks (one process per GPU), every rank runs the compiled forward + backward
 launch lists on its micro-batch, and the only exchange is this all-reduce of the parameter gradients (X3D-S + head B:
 about 3.8 M floats = 15 MB, one bucket: on the xGMI full mesh a ring all-reduce of M bytes moves 2*(n-1)/n*M per link
-direction, ~0.2 ms at 8 GPUs -- far below the step, so it is not overlapped with the backward in this round).
+direction, ~0.2 ms at 8 GPUs -- far below the step, so it is not overlapped with the backward).  The compiled backward pass
+already lands every gradient in one flat fp32 buffer (train.TrainPlan.backward), so the all-reduce runs IN PLACE on that buffer
+(``flat_gradient_view``): no flatten / unflatten / copy-back passes around the one collective this workload has.
 Norm-layer running statistics stay per rank, as they would under the reference's plain BatchNorm (no SyncBN).
 """
 from __future__ import annotations
@@ -69,6 +71,32 @@ class NativeComm:
             NativeComm._instance = None
 
 
+def flat_gradient_view(grads) -> Optional[torch.Tensor]:
+    """The ONE flat tensor the gradients already live in, or None.
+
+    ``train.TrainPlan.backward`` writes every parameter gradient of a pass into one zero-initialised fp32 buffer (64-float aligned slots)
+    and returns views of it; autograd's AccumulateGrad keeps those views as ``p.grad`` (later micro-batches accumulate into them in
+    place).  When every gradient is a dense view of one storage, the span from the first to the last is the bucket as it lies: the
+    all-reduce runs on it in place -- no flatten, no unflatten, no copy back.  (The alignment gaps inside the span are zeros on every
+    rank and stay zeros under a sum.)  Anything else -- gradients from torch autograd, mixed dtypes, a span more than 25 % larger than
+    the gradients it holds -- returns None and takes the bucketed path."""
+    if not grads:
+        return None
+    g0 = grads[0]
+    base = g0.untyped_storage().data_ptr()
+    lo, hi, total = None, 0, 0
+    for g in grads:
+        if g.dtype != g0.dtype or g.device != g0.device or not g.is_contiguous() or g.untyped_storage().data_ptr() != base:
+            return None
+        o = g.storage_offset()
+        lo = o if lo is None else min(lo, o)
+        hi = max(hi, o + g.numel())
+        total += g.numel()
+    if hi - lo > total + total // 4 + 64 * len(grads):
+        return None
+    return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), lo, (hi - lo,))
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None, average: bool = True,
                         native: Optional[bool] = None) -> int:
     """Sum (or average) ``p.grad`` of every parameter that has one across the ranks of ``group``; returns the bucket size in
@@ -83,7 +111,10 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[di
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return 0
-    flat = _flatten_dense_tensors(grads)
+    flat = flat_gradient_view(grads)  # the training arena's gradient buffer as it lies (in place), else a fresh bucket
+    in_place = flat is not None
+    if not in_place:
+        flat = _flatten_dense_tensors(grads)
     if native and flat.is_cuda and group is None:
         NativeComm.get(flat.device).all_reduce_(flat)
     elif flat.is_cuda and dist.get_backend(group) == "gloo":
@@ -95,6 +126,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[di
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # RCCL over xGMI on a real node
     if average:
         flat /= dist.get_world_size(group)
-    for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
-        g.copy_(f)
+    if not in_place:
+        for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
+            g.copy_(f)
     return flat.numel() * flat.element_size()

@@ -370,7 +370,7 @@ class _XProtoHeadMixin:
         lib = _lib.lib()
         code = _lib.dtype_code(dtype)
         # the chained head (one launch for the five convs and the pooling, intermediates in LDS) where the shape allows: bf16, D = 256,
-        # trunk channel stride <= 192 -- the X3D heads; everything else takes the seven-launch path
+        # trunk channel stride <= 256 -- the X3D heads and R(2+1)D-18[:-3]; everything else takes the seven-launch path
         chain = bool(lib.pasn_xproto_chain_supported(ctypes.byref(d), code))
         (a1, a1b), (a2, a2b) = self.add_on_layers.packed(cbp, dtype, frag=chain)
         (o1, o1b), (o2, o2b), (o3, _) = self.occurrence_module.packed(cbp, dtype, frag=chain)

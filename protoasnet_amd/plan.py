@@ -551,7 +551,7 @@ class PlanBuilder:
         # norm_a's scale goes INTO the expand weights (W * scale, rounded to bf16 once) and its bias becomes the accumulator's initial
         # value: the fused kernel's expand epilogue is then swap + ReLU + rounding (PASN_EXPDW_FOLD=0: scale and bias applied in fp32
         # after the MFMAs, the rounding points of the two separate launches)
-        fold = os.environ.get("PASN_EXPDW_FOLD", "1") != "0"
+        fold = (_lib.tuning_get("PASN_EXPDW_FOLD") or "1") != "0"
         sa_full, _ = fold_norm(norm_a, conv_a.bias, cm, cm, self.device)
         w_src = conv_a.weight.detach().float() * sa_full.to(conv_a.weight.device).view(-1, 1, 1, 1, 1) if fold else conv_a.weight
         wa, kca, rowsa = pack_conv_weight(w_src, x.Cp, self.dtype)

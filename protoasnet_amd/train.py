@@ -46,7 +46,7 @@ class TrainBuilder(PlanBuilder):
         # weights packed by the native one-launch packer (pasn_pack_weights): (parameter, destination, mode, cout, cin, taps, rows, kc,
         # frag, kstep, ch) -- source dims as the PARAMETER has them.  PASN_NO_PACK=1: torch expressions per parameter (the old path)
         self.pack_jobs: List[tuple] = []
-        self.native_pack = os.environ.get("PASN_NO_PACK") != "1"
+        self.native_pack = _lib.tuning_get("PASN_NO_PACK") != "1"
         self.pslots: List[Tuple[torch.Tensor, int, int]] = []
         self._slot_of: Dict[int, int] = {}
         self.gsize = 0
@@ -324,7 +324,7 @@ class TrainBuilder(PlanBuilder):
                 elif se is None:
                     self._use(g.buf, y.buf, rb, stat_buf, ws, coef)
                     self._op(red, 3 if lazy else 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
-                elif residual is None and not os.environ.get("PASN_NO_SE_ANALYTIC"):
+                elif residual is None and not _lib.tuning_get("PASN_NO_SE_ANALYTIC"):
                     # squeeze-excite unit, ONE pass over (d, y): mode 4 leaves d' = d act'(.) and per-clip (sum d', sum d' yhat, sum yhat);
                     # the gate's gradient, the norm's coefficients and dgamma / dbeta follow from those per clip (d'' = d' gate + add is
                     # affine in d'), and the apply pass forms d'' on the fly -- the second pass over the tensor (mode 2) is gone

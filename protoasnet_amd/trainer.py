@@ -99,19 +99,26 @@ class DPTrainer:
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 buf = push_mod._for_collective(t.detach())
                 dist.broadcast(buf, src=0)
-                if buf is not t:
+                if buf.data_ptr() != t.data_ptr():  # staged through the host (gloo rehearsal): bring it back; RCCL wrote t itself
                     t.copy_(buf.to(t.device))
         if hasattr(self.model, "cnn_backbone") and hasattr(self.model.cnn_backbone, "invalidate_plans"):
-            self.model.cnn_backbone.invalidate_plans()  # copy_ bumps the version counters too; this is belt and braces
+            self.model.cnn_backbone.invalidate_plans()  # a broadcast straight into the storage bumps no version counter
+        self._norm_dirty = False
 
     def sync_norm_buffers(self) -> None:
-        """Average the floating-point buffers (norm running means / variances) over the ranks and take the largest batch counter:
-        each rank's estimates saw only its own micro-batches; evaluation, push and the checkpoint must use ONE model."""
-        if self.world_size <= 1:
+        """Average the norm layers' running means / variances over the ranks and take the largest batch counter: each rank's estimates
+        saw only its own micro-batches; evaluation, push and the checkpoint must use ONE model.
+
+        Only when a training epoch ran since the last sync (``_norm_dirty``; every rank runs the same epochs, so the flag agrees
+        across ranks and the collective stays matched): a sync of already-equal buffers would still ``copy_`` into every buffer, bump
+        its version counter and make the next eval forward re-plan and re-pack every weight -- and for world sizes that are not powers
+        of two ``(a + a + a) / 3`` need not be ``a``, so the statistics would drift by an ulp per call.  Only norm statistics are
+        exchanged: ``prototype_class_identity``-like constants and ``ones`` are equal by construction."""
+        if self.world_size <= 1 or not getattr(self, "_norm_dirty", True):
             return
-        bufs = [b for b in self.model.buffers()]
-        fl = [b for b in bufs if b.is_floating_point()]
-        it = [b for b in bufs if not b.is_floating_point()]
+        norms = [m for m in self.model.modules() if isinstance(m, torch.nn.modules.batchnorm._NormBase) and m.running_mean is not None]
+        fl = [b for m in norms for b in (m.running_mean, m.running_var)]
+        it = [m.num_batches_tracked for m in norms if m.num_batches_tracked is not None]
         with torch.no_grad():
             if fl:
                 flat = push_mod._for_collective(torch.cat([b.detach().float().flatten() for b in fl]))
@@ -129,6 +136,7 @@ class DPTrainer:
                 for b in it:
                     b.copy_(flat[o:o + b.numel()].view_as(b).to(b.dtype))
                     o += b.numel()
+        self._norm_dirty = False
 
     # ---- reference surface: XProtoNet_Base.py:54-81 ---------------------------------------------------------------------------
     def get_criterion(self) -> None:
@@ -257,6 +265,7 @@ class DPTrainer:
                 loss_sum += terms
                 n_batches += 1
                 if mode == "train":
+                    self._norm_dirty = True  # this rank's running statistics moved on their own
                     loss.backward()  # undivided, as the reference accumulates it
                     if (i + 1) % self.local_accumulation == 0:
                         dp.allreduce_gradients(self.params, average=False)  # ONE exchange per optimizer step: SUM over ranks

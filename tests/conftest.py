@@ -43,6 +43,30 @@ def _built_library():
     yield
 
 
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """The library reads the PASN_* tuning switches from ONE snapshot of the environment (csrc/tuning.h), not at every call: a test that
+    sets or clears one must have the snapshot retaken -- after each change, and again when the patch is undone at teardown."""
+    from protoasnet_amd import _lib
+
+    real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        real_set(name, value, *a, **k)
+        if name.startswith("PASN_"):
+            _lib.tuning_reload()
+
+    def delenv(name, *a, **k):
+        real_del(name, *a, **k)
+        if name.startswith("PASN_"):
+            _lib.tuning_reload()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield monkeypatch
+    monkeypatch.undo()
+    _lib.tuning_reload()
+
+
 # Tolerances of the comparisons with the REFERENCE'S golden outputs (fp32 HIP path).  Round 1 asserted 1e-3 where the two golden
 # samples differ by only 4e-4 ... 2e-3 (the check could not tell the samples apart); observed errors are ~1e-7 ... 1e-6, so the
 # gates sit two orders above the noise and one to two below the sample-to-sample differences (assert_discriminates proves it).

@@ -150,6 +150,61 @@ def test_gradient_bucket_allreduce_world2(tmp_path):
             assert torch.allclose(got, ref, atol=1e-6)
 
 
+def _dp_inplace_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from protoasnet_amd import dp
+
+    # gradients laid out the way train.TrainPlan.backward returns them: views of ONE zero-initialised flat buffer, 64-float slots
+    shapes = ((7, 3, 1, 1, 1), (5,), (2, 9))
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    G = torch.zeros(64 * 3)
+    g = torch.Generator().manual_seed(100 + rank)
+    for i, p in enumerate(params):
+        v = G[64 * i: 64 * i + p.numel()].view_as(p)
+        v.copy_(torch.randn(p.shape, generator=g))
+        p.grad = v
+    flat = dp.flat_gradient_view([p.grad for p in params])
+    assert flat is not None and flat.data_ptr() == G.data_ptr() and flat.numel() == 128 + 18
+    ptrs = [p.grad.data_ptr() for p in params]
+    nbytes = dp.allreduce_gradients(params)
+    assert [p.grad.data_ptr() for p in params] == ptrs  # reduced where they lie
+    assert float(G[21:64].abs().max()) == 0.0 and float(G[69:128].abs().max()) == 0.0  # the alignment gaps stay zero
+    torch.save({"grads": [p.grad.clone() for p in params], "nbytes": nbytes}, os.path.join(out_dir, f"ip{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gradient_allreduce_in_place_on_the_flat_training_buffer(tmp_path):
+    """When every gradient is a view of one flat buffer (what the compiled backward pass produces) the exchange runs in place on that
+    buffer -- no flatten / unflatten / copy back -- and gives the same means; anything else falls back to a fresh bucket."""
+    from protoasnet_amd import dp
+
+    world, port = 2, _free_port()
+    mp.spawn(_dp_inplace_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    shapes = ((7, 3, 1, 1, 1), (5,), (2, 9))
+    per_rank = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        per_rank.append([torch.randn(s, generator=g) for s in shapes])
+    for r in range(world):
+        o = torch.load(os.path.join(tmp_path, f"ip{r}.pt"))
+        assert o["nbytes"] == (128 + 18) * 4
+        for i, got in enumerate(o["grads"]):
+            assert torch.allclose(got, (per_rank[0][i] + per_rank[1][i]) / 2, atol=1e-6)
+    # not one storage / not dense / a sparse span: no in-place view
+    a, b = torch.zeros(8), torch.zeros(8)
+    assert dp.flat_gradient_view([a, b]) is None
+    big = torch.zeros(4096)
+    assert dp.flat_gradient_view([big[:8], big[4000:4008]]) is None
+    assert dp.flat_gradient_view([big[:16].view(4, 4).t()]) is None
+    assert dp.flat_gradient_view([big[:8], big[8:16].double()]) is None
+    assert dp.flat_gradient_view([]) is None
+    v = dp.flat_gradient_view([big[64:72], big[0:8]])
+    assert v is not None and v.data_ptr() == big.data_ptr() and v.numel() == 72
+
+
 def _run_bench(args, env_extra=None, timeout=300):
     import json
     import subprocess

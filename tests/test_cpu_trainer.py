@@ -130,8 +130,11 @@ def _sync_worker(rank, world, port, out_dir):
     t.run_epoch(0, "train")
     before_sync = {k: v.clone() for k, v in t.model.state_dict().items() if "running" in k}
     t.run_epoch(0, "val")  # averages the norm buffers first
+    versions = [b._version for b in t.model.buffers()]
     t.save_checkpoint()
-    torch.save({"init": after_init, "before": before_sync, "final": t.model.state_dict()}, os.path.join(out_dir, f"sync{rank}.pt"))
+    t.run_epoch(0, "val")  # nothing trained since the last sync: no collective, no copy_, no version bump (cached HIP plans stay valid)
+    clean = versions == [b._version for b in t.model.buffers()] and not t._norm_dirty
+    torch.save({"init": after_init, "before": before_sync, "final": t.model.state_dict(), "clean": clean}, os.path.join(out_dir, f"sync{rank}.pt"))
     # a rank with a shorter loader must be refused, not hang: both ranks take part in the length check
     t.data_loaders["train"] = all_b[: 2 if rank == 0 else 4]
     try:
@@ -162,6 +165,7 @@ def test_ranks_built_from_different_seeds_train_one_model(tmp_path):
         if "running" in k and v.is_floating_point():
             assert torch.allclose(v, (a["before"][k] + b["before"][k]) / 2, atol=1e-6), f"{k}: not the mean of the ranks' estimates"
     assert os.path.exists(os.path.join(tmp_path, "ck", "last.pth"))
+    assert a["clean"] and b["clean"], "a sync with nothing trained in between must not touch the buffers"
     assert all(torch.load(os.path.join(tmp_path, f"raised{r}.pt")) for r in range(world))
 
 

@@ -1,4 +1,6 @@
 """GPU: whole models behind the reference's nn.Module surface vs the oracle / the reference's golden vectors."""
+import os
+
 import pytest
 import torch
 
@@ -121,6 +123,35 @@ def test_x3d_production_routes_vs_oracle(dtype):
         assert_close(occ, ref["occurrence_map"], 1e-3 * max(1.0, float(ref["occurrence_map"].max())), 1e-3, "occurrence_map")
         assert_close(sim, ref["similarity"], 1e-3, 0, "similarity")
         assert_close(logits, ref["logits"], 1e-3, 0, "logits")
+
+
+@pytest.mark.timeout(1200)
+def test_headline_batch_of_32_vs_oracle():
+    """BASELINE config 2 at the batch the metric is quoted on: ONE forward of 32 x 3 x 16 x 224 x 224 clips, bf16, as bench.py runs it
+    (default routing: this is the launch list of tests/golden/routing_x3d_s_cfg2.json, persistent kernels sized by the 32-clip grid) --
+    every clip against the fp32 oracle with the bf16 gates, in chunks of 8 on the host (the broadcast-product pooling bounds N); and the
+    hipGraph replay of the same batch is bit-identical to the launch-by-launch forward."""
+    from protoasnet_amd.graph import GraphedForward
+
+    m = _gpu(CFG_VIDEO_X3D).set_compute_dtype(torch.bfloat16)
+    x = synth.echo_clips((32, 3, 16, 224, 224))
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    xd = x.to(DEV).bfloat16()
+    with torch.no_grad():
+        logits, sim, occ = [t.clone() for t in m(xd)]
+    assert len(m.cnn_backbone.plan_for(xd).ops) <= 72
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    worst = {"sim": 0.0, "logits": 0.0, "occ": 0.0}
+    for lo in range(0, 32, 8):
+        ref = oracle.nets.xprotonet_forward(sd, x[lo:lo + 8], arch="x3d_s")
+        worst["sim"] = max(worst["sim"], float((sim[lo:lo + 8].cpu() - ref["similarity"]).abs().max()))
+        worst["logits"] = max(worst["logits"], float((logits[lo:lo + 8].cpu() - ref["logits"]).abs().max()))
+        worst["occ"] = max(worst["occ"], float((occ[lo:lo + 8].cpu() - ref["occurrence_map"]).abs().mean() / ref["occurrence_map"].abs().mean()))
+    print("headline batch vs oracle:", worst)
+    assert worst["sim"] <= BF16_SIM and worst["logits"] <= BF16_LOGITS and worst["occ"] <= BF16_OCC_REL, worst
+    got = GraphedForward(m)(xd)
+    for a, b in zip(got, (logits, sim, occ)):
+        assert torch.equal(a, b)
 
 
 CFG_VIDEO_X3D_M = dict(CFG_VIDEO_X3D, base_architecture="x3d_m", prototype_shape="(60, 256, 1, 1, 1)", img_size=312)

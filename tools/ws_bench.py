@@ -9,6 +9,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
+from protoasnet_amd import _lib  # noqa: E402
 import torch.nn as nn
 
 from protoasnet_amd.plan import Act, PlanBuilder, round_up
@@ -28,6 +30,7 @@ LAYERS = [
 
 def build(cin, cout, T, H, W, use_res, gate, ws, N=32, dtype=torch.bfloat16):
     os.environ["PASN_WS"] = "1" if ws else "0"
+    _lib.tuning_reload()  # the library routes on one snapshot of the switches
     torch.manual_seed(1)
     pb = PlanBuilder(DEV, dtype, dtype)
     cp, cop = round_up(cin, 8), round_up(cout, 8)
@@ -71,6 +74,7 @@ def main():
         for ws in (False, True):
             plan, x, _ = arms[ws]
             os.environ["PASN_WS"] = "1" if ws else "0"
+            _lib.tuning_reload()  # the library routes on one snapshot of the switches
             for _ in range(3):
                 outs[ws] = plan.run(x)
         torch.cuda.synchronize()
@@ -78,6 +82,7 @@ def main():
             for ws in (False, True):
                 plan, x, _ = arms[ws]
                 os.environ["PASN_WS"] = "1" if ws else "0"
+                _lib.tuning_reload()  # the library routes on one snapshot of the switches
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
