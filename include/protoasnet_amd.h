@@ -280,7 +280,11 @@ typedef struct pasn_xproto_desc {
     int32_t D, Dp;     /* prototype depth, round_up(D, 8)          */
     int32_t Hd, Hp;    /* D / 2 (hidden width of the occurrence module), round_up(Hd, 8) */
     int32_t P, Pp;     /* prototypes, round_up(P, 8)               */
-    int32_t K;         /*
+    int32_t K;         /* classes                                   */
+    int32_t mode;
+} pasn_xproto_desc;
+
+/*
  * Front half of an X3D stage's first block in ONE launch (bf16): conv_a (1x1x1) + norm_a + ReLU -> conv_b (depthwise 3x3x3, stride
  * (1,2,2), pad 1) + norm_b (+ the descriptor's activation, + squeeze-excite pool partial rows), pytorchvideo's BottleneckTransform as
  * instantiated by the reference's x3d trunks; replaces pasn_conv3d_fwd + pasn_dwconv3d_fwd for that pair -- the expanded activation (2.25x
@@ -299,9 +303,27 @@ int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, cons
                        const float* bias, void* y, float* pool_partial, const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype,
                        void* stream);
 
-/* classes                                   */
-    int32_t mode;
-} pasn_xproto_desc;
+/*
+ * The body of an X3D residual block WITHOUT squeeze-excite in ONE launch (bf16): conv_b (depthwise 3x3x3, stride 1, pad 1) + norm_b +
+ * Swish -> conv_c (1x1x1) + norm_c + residual + ReLU -> the NEXT block's conv_a (1x1x1) + norm_a + ReLU (pytorchvideo's
+ * BottleneckTransform / ResBlock as instantiated by the x3d trunks BASELINE.json names; the reference itself ships no X3D -- SURVEY 8a row
+ * 5).  Replaces pasn_dwconv3d_fwd + pasn_conv3d_pair_fwd (or + two pasn_conv3d_fwd): the stencil's output (2.25x the block width) only
+ * ever exists as a tile in LDS; results are bit-identical to those launches (same rounding points, same accumulation order).
+ *   e        : this block's expanded activation, channels-last [N][T][H][W][d_dw->Cin_p] (what the previous launch's expand conv wrote)
+ *   w_dw     : conv_b weights fp32 [27][Cp]; scale_dw / bias_dw: folded norm_b [Cp]                       (d_dw->act = PASN_ACT_SWISH)
+ *   w_c      : conv_c weights FRAGMENT-MAJOR (w_frag = 1) with K zero-padded to an EVEN number of 16-wide steps (d_c->w_kc = 32 *
+ *              ceil(Cin_p / 32)); scale_c / bias_c: folded norm_c [d_c->w_rows]; residual: the block input [N][T][H][W][d_c->Cout_p]
+ *   y        : the block output [N][T][H][W][d_c->Cout_p]                                                  (d_c->act = PASN_ACT_RELU)
+ *   w_a ...  : the next block's conv_a in the same form (d_a->w_kc = 32 * ceil(d_c->Cout_p / 32)), its folded norm and its output
+ *              e_next [N][T][H][W][d_a->Cout_p]; all NULL (with d_a == NULL) for the last block of a stage
+ * _supported() == 0: issue the separate launches.
+ */
+int pasn_x3d_block_supported(const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_a, int dtype);
+int pasn_x3d_block_fwd(const void* e, const float* w_dw, const float* scale_dw, const float* bias_dw, const void* w_c, const float* scale_c,
+                       const float* bias_c, const void* residual, void* y, const void* w_a, const float* scale_a, const float* bias_a,
+                       void* e_next, const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_a, int dtype,
+                       void* stream);
+
 
 int pasn_xproto_head_splits(const pasn_xproto_desc* d);
 size_t pasn_xproto_head_workspace_bytes(const pasn_xproto_desc* d, int dtype);

@@ -340,6 +340,16 @@ class X3DFeatures(_plan.HipTrunk):
                     # the pool partial rows are produced here (gate = ("pooled", ...))
                     y, gate = pb.dwconv_se(e, blk.conv_b, blk.bn_b, blk.se.fc1, blk.se.fc2, consumer=(blk.conv_c, True))
                 else:
+                    # a block without squeeze-excite: stencil -> project conv (+ residual) -> the next block's expand conv in ONE launch where
+                    # that is covered (stride 1, no shortcut conv: every such block of an X3D stage); the stencil's output stays in LDS
+                    nxt_b = blocks[i + 1] if i + 1 < len(blocks) else None
+                    if blk.shortcut is None:
+                        chain_a = nxt_b is not None and nxt_b.shortcut is None
+                        fused_b = pb.x3d_block(e, blk.conv_b, blk.bn_b, blk.conv_c, blk.bn_c, x,
+                                               nxt_b.conv_a if chain_a else None, nxt_b.bn_a if chain_a else None)
+                        if fused_b is not None:
+                            x, pre = fused_b
+                            continue
                     y = pb.dwconv(e, blk.conv_b, blk.bn_b, act=act_b)
                 # project conv; where the geometry allows, chained in ONE launch with the next block's expand conv
                 nxt = blocks[i + 1] if i + 1 < len(blocks) else None

@@ -533,6 +533,69 @@ class PlanBuilder:
             return y, (pool_buf, pool_blocks, y)
         return y
 
+    def x3d_block(self, e: Act, conv_b: nn.Module, norm_b: Optional[nn.Module], conv_c: nn.Module, norm_c: Optional[nn.Module], residual: Act,
+                  conv_a: Optional[nn.Module] = None, norm_a: Optional[nn.Module] = None):
+        """The body of an X3D block without squeeze-excite in ONE launch (``pasn_x3d_block_fwd``): depthwise 3x3x3 conv + BN + Swish ->
+        project conv + BN + residual + ReLU -> (``conv_a``: the NEXT block's expand conv + BN + ReLU).  ``e`` = this block's expanded
+        activation.  Returns (y, e_next or None), or None when the launch does not cover the block (the caller emits the separate ones)."""
+        one, zero = (1, 1, 1), (0, 0, 0)
+        if e.planar or self.dtype != torch.bfloat16 or conv_b.groups != conv_b.in_channels or conv_b.in_channels != e.C or conv_c.groups != 1:
+            return None
+        k, s, p = _triple(conv_b.kernel_size, 1), _triple(conv_b.stride, 1), _triple(conv_b.padding, 0)
+        if k != (3, 3, 3) or s != one or p != (1, 1, 1) or conv_b.bias is not None:
+            return None
+        for cv in (conv_c, conv_a):
+            if cv is not None and (_triple(cv.kernel_size, 1) != one or _triple(cv.stride, 1) != one or _triple(cv.padding, 0) != zero or cv.groups != 1):
+                return None
+        if conv_c.in_channels != e.C or (conv_a is not None and conv_a.in_channels != conv_c.out_channels):
+            return None
+
+        def frag32(conv, cin_p):  # fragment-major weights with K zero-padded to an EVEN number of 16-wide steps
+            wp, kc, rows = pack_conv_weight(conv.weight, round_up(cin_p, 32), self.dtype)
+            return wp.view(rows // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous(), kc, rows
+
+        mid = Act(e.N, e.T, e.H, e.W, e.C, e.Cp, -1)  # the stencil's output: never materialised
+        dd = self._desc(e, mid, k, s, p, "swish")
+        y = self._out_act(mid, conv_c.out_channels, one, one, zero)
+        wc, kcc, rowsc = frag32(conv_c, e.Cp)
+        dc = self._desc(mid, y, one, one, zero, "relu", False, kcc, rowsc)
+        dc.w_frag = 1
+        en = da = None
+        if conv_a is not None:
+            ymid = Act(y.N, y.T, y.H, y.W, y.C, y.Cp, -1)
+            en = self._out_act(ymid, conv_a.out_channels, one, one, zero)
+            wa, kca, rowsa = frag32(conv_a, y.Cp)
+            da = self._desc(ymid, en, one, one, zero, "relu", False, kca, rowsa)
+            da.w_frag = 1
+        if (residual.N, residual.T, residual.H, residual.W, residual.Cp) != (y.N, y.T, y.H, y.W, y.Cp) or \
+                not int(self.lib.pasn_x3d_block_supported(ctypes.byref(dd), ctypes.byref(dc), ctypes.byref(da) if da is not None else None, self.code)):
+            self.bufs[y.buf].nbytes = ALIGN  # never used
+            if en is not None:
+                self.bufs[en.buf].nbytes = ALIGN
+            return None
+        wd = torch.zeros(27, e.Cp, dtype=torch.float32, device=self.device)
+        wd[:, : e.C] = conv_b.weight.detach().float().reshape(e.C, 27).t()
+        sd, bd = fold_norm(norm_b, None, e.C, e.Cp, self.device)
+        sc, bc = fold_norm(norm_c, conv_c.bias, y.C, rowsc, self.device)
+        keep = [wd, sd, bd, wc, sc, bc]
+        if conv_a is not None:
+            sa, ba = fold_norm(norm_a, conv_a.bias, en.C, rowsa, self.device)
+            keep += [wa, sa, ba]
+        self.keep += keep
+        a = tuple(t.data_ptr() for t in keep) + ((0, 0, 0) if conv_a is None else ())
+        eb, rb, yb, nb = e.buf, residual.buf, y.buf, (en.buf if en is not None else None)
+        rd, rc, ra = ctypes.byref(dd), ctypes.byref(dc), (ctypes.byref(da) if da is not None else None)
+        self._use(eb, rb, yb, nb)
+        pos = y.N * y.positions
+        cn = en.C if en is not None else 0
+        self._note("block" if en is None else "block+expand", f"x3d_block_kernel<{2 if e.W <= 8 else 1},{'true' if en is not None else 'false'},0>",
+                   (pos * (e.C + 2 * y.C + cn) + 27 * e.C + y.C * e.C + cn * y.C) * self.es, 2 * pos * (27 * e.C + y.C * e.C + cn * y.C))
+        self.meta[-1]["shape"] = f"dw{e.C} k333 -> {e.C}->{y.C}" + (f" -> {y.C}->{cn}" if cn else "") + f" k111 in{e.T}x{e.H}x{e.W}"
+        fn, code = self.lib.pasn_x3d_block_fwd, self.code
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[eb], a[0], a[1], a[2], a[3], a[4], a[5], ptrs[rb], ptrs[yb], a[6], a[7], a[8],
+                                                       ptrs[nb] if nb is not None else 0, rd, rc, ra, code, st)))
+        return y, en
+
     def expand_dw(self, x: Act, conv_a: nn.Module, norm_a: Optional[nn.Module], conv_b: nn.Module, norm_b: Optional[nn.Module], act_b: str,
                   pool: bool = False):
         """Front half of an X3D block in ONE launch (``pasn_x3d_expdw_fwd``): 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 conv,

@@ -32,6 +32,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.pasn_last_error() is not None
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/protoasnet_amd.h is the boundary a C / cgo / JNI binding would compile: it must be valid C (round 3 shipped a
+    declaration block inside a struct -- legal C++ member declarations, not C)."""
+    import subprocess
+
+    src = tmp_path / "t.c"
+    src.write_text('#include "protoasnet_amd.h"\nint main(void) { return sizeof(pasn_conv_desc) == 25 * 4 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"), str(src), "-o", str(tmp_path / "t")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([str(tmp_path / "t")]).returncode == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from protoasnet_amd import _lib
 
