@@ -384,7 +384,7 @@ def _tuning_in_force():
 
 
 _UNFUSED = {"PASN_EXPDW": "0", "PASN_NO_XPAIR": "1", "PASN_WSPAIR": "0", "PASN_NO_SHORTFUSE": "1", "PASN_NO_SE_PROLOGUE": "1",
-            "PASN_NO_SE_FUSE": "1", "PASN_NO_BLOCK": "1"}
+            "PASN_NO_SE_FUSE": "1", "PASN_BLOCK": "0"}
 
 
 def _layerwise_bytes(trunk, x, dtype):

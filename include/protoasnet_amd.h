@@ -310,7 +310,12 @@ int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, cons
  * 5).  Replaces pasn_dwconv3d_fwd + pasn_conv3d_pair_fwd (or + two pasn_conv3d_fwd): the stencil's output (2.25x the block width) only
  * ever exists as a tile in LDS; results are bit-identical to those launches (same rounding points, same accumulation order).
  *   e        : this block's expanded activation, channels-last [N][T][H][W][d_dw->Cin_p] (what the previous launch's expand conv wrote)
- *   w_dw     : conv_b weights fp32 [27][Cp]; scale_dw / bias_dw: folded norm_b [Cp]                       (d_dw->act = PASN_ACT_SWISH)
+ *   w_dw     : conv_b weights as the stencil's matrix-core operands: uint16 [ceil(Cp / 16)][2][64][8], row (16-channel tile, half, lane):
+ *              entry e = kt * 5 + j (half e >> 3, slot e & 7; entry 15 unused) = bf16 bits (round-to-nearest-even) of tap
+ *              kt * 9 + 2 j + (lane >> 5) of channel 16 tile + (lane & 15), for lanes with ((lane >> 3) & 1) == ((lane >> 4) & 1), a tap index
+ *              < 9 and a real channel; 0 otherwise -- the one possibly nonzero element per lane of the block-diagonal A operands that
+ *              pasn_dwconv3d_fwd's matrix-core kernel builds in its own prologue;
+ *              scale_dw / bias_dw: folded norm_b [Cp], zero beyond the channels                          (d_dw->act = PASN_ACT_SWISH)
  *   w_c      : conv_c weights FRAGMENT-MAJOR (w_frag = 1) with K zero-padded to an EVEN number of 16-wide steps (d_c->w_kc = 32 *
  *              ceil(Cin_p / 32)); scale_c / bias_c: folded norm_c [d_c->w_rows]; residual: the block input [N][T][H][W][d_c->Cout_p]
  *   y        : the block output [N][T][H][W][d_c->Cout_p]                                                  (d_c->act = PASN_ACT_RELU)
@@ -319,7 +324,7 @@ int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, cons
  * _supported() == 0: issue the separate launches.
  */
 int pasn_x3d_block_supported(const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_a, int dtype);
-int pasn_x3d_block_fwd(const void* e, const float* w_dw, const float* scale_dw, const float* bias_dw, const void* w_c, const float* scale_c,
+int pasn_x3d_block_fwd(const void* e, const void* w_dw, const float* scale_dw, const float* bias_dw, const void* w_c, const float* scale_c,
                        const float* bias_c, const void* residual, void* y, const void* w_a, const float* scale_a, const float* bias_a,
                        void* e_next, const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_a, int dtype,
                        void* stream);

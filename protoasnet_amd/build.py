@@ -14,8 +14,8 @@ SOURCES = ("api.hip", "tuning.hip", "comm.hip", "conv.hip", "pwconv.hip", "gemm_
 ARCH = "gfx950"
 
 
-def lib_path() -> str:
-    return os.path.join(OUT_DIR, "libprotoasnet_amd.so")
+def lib_path(variant: str = "") -> str:
+    return os.path.join(OUT_DIR, f"libprotoasnet_amd{'_' + variant if variant else ''}.so")
 
 
 def _hipcc() -> str:
@@ -32,18 +32,27 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_extension(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link the shared library; returns its path."""
+def build_extension(force: bool = False, verbose: bool = False, variant: str = "") -> str:
+    """Compile every HIP source for gfx950 and link the shared library; returns its path.
+
+    ``variant="tuning"``: a second library, ``libprotoasnet_amd_tuning.so`` (own object directory), built with ``-DPASN_TUNING
+    -DPASN_WS_ABLATE``: the dev-class switches of csrc/tuning.h (timing ablations, unswept geometry) are compiled in.  Never the product:
+    select it per process with ``PASN_LIB_PATH`` (tools/*.sh)."""
     hipcc = _hipcc()
+    obj_dir = OBJ_DIR + ("_" + variant if variant else "")
     os.makedirs(OUT_DIR, exist_ok=True)
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     # every header of csrc/ (igemm_epilogue.h is shared by three kernels' files: an edit there must rebuild them) + the C-ABI header
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(os.path.dirname(HERE), "include", "protoasnet_amd.h")]
     flags_extra = os.environ.get("PASN_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPASN_WS_ABLATE for tools/ws_abl.sh (use with force=True / a clean obj dir)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + flags_extra
+    if variant == "tuning":
+        flags += ["-DPASN_TUNING", "-DPASN_WS_ABLATE"]
+    elif variant:
+        raise ValueError(f"unknown build variant {variant!r}")
 
     def compile_one(src: str) -> str:
-        s, o = os.path.join(CSRC, src), os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        s, o = os.path.join(CSRC, src), os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
             cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
@@ -55,7 +64,7 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    target = lib_path()
+    target = lib_path(variant)
     if force or _stale(target, objs):
         r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs + ["-ldl"], capture_output=True, text=True)
         if r.returncode != 0:

@@ -161,7 +161,8 @@ struct XbGeom {
     int R, RTn, NQ;                     // rows per tile, 32-row tiles, 64-channel quads of the inner width
     int KSC, KSA, CTC, CTA;             // (even) k-steps of the project / expand conv, 32-channel output tiles of each
     int DPL, XPL;                       // 16-byte slots per row of the stencil-output image / the block-output image (odd)
-    int dw_off, tab_off, lds_bytes;     // LDS layout: [ring | block-output image] [stencil-output image] [row table]
+    int NS;                             // frame images in the ring (2-4: what fits next to the operand images)
+    int dw_off, tab_off, cst_off, wop_off, lds_bytes;  // LDS layout: [ring | block-output image] [stencil-output image] [row table] [scale / bias tables] [stencil weight operands]
     int tiles, tpb, grid, abl;          // work split; timing ablations (PASN_BLOCK_ABL, -DPASN_TUNING builds only)
 };
 XbGeom xb_geom(const pasn_conv_desc& d_dw, const pasn_conv_desc& d_c, const pasn_conv_desc* d_a, int dtype);

@@ -60,7 +60,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_NO_WGRAD_TILE",    "route", "windowed weight gradient without the tiled kernel"},
     {"PASN_NO_XPAIR",         "route", "project conv never chained with the next expand conv (pwconv_xpair.hip)"},
     {"PASN_NO_XTILE",         "route", "no X-stationary pointwise conv (pwconv_xtile.hip)"},
-    {"PASN_NO_BLOCK",         "route", "no fused residual-block launch (x3d_block.hip)"},
+    {"PASN_BLOCK",            "route", "fused residual-block launch (x3d_block.hip): 0 / unset off (it loses at the benchmark shapes), 1 every covered block, 5 the 432-channel blocks only"},
     {"PASN_POOL_VALU",        "route", "1: head-B pooling on the VALU kernel"},
     {"PASN_SE_FUSE_MAXC",     "route", "largest channel count whose squeeze-excite gate rides in the stencil launch (default 128)"},
     {"PASN_WGRAD_DET",        "route", "1: windowed weight gradient through fixed-order partial buffers only"},
@@ -82,6 +82,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_WS_PT",            "geom",  "weight-stationary conv: forced waves along positions"},
     {"PASN_WS_MINK",          "geom",  "weight-stationary conv: smallest padded K it takes (default 48)"},
     {"PASN_BLOCK_TF",         "geom",  "fused residual block: forced frames per tile"},
+    {"PASN_BLOCK_NS",         "geom",  "fused residual block: forced frame images in the ring (2-4)"},
     // ---- dev: only with -DPASN_TUNING (timing ablations give WRONG results) ----------------------------------------------------------
     {"PASN_DWMFMA_ABL",       "dev",   "matrix-core stencil timing ablations (bit mask)"},
     {"PASN_EXPDW_ABL",        "dev",   "fused expand + stencil timing ablations (bit mask)"},

@@ -24,6 +24,8 @@
 //   E  the next block's expand conv from `xt` (same unit shape), scale / bias + ReLU -> 16-byte stores of the expanded activation.
 // Rounding points are exactly those of the separate launches (stencil output, block output, expanded activation in bf16; fp32 accumulation
 // in the same k order): the fused launch is BIT-IDENTICAL to dwconv3d_mfma_kernel + pwconv_ws_kernel (pair), which the tests assert.
+#include <type_traits>
+
 #include "common.h"
 
 namespace pasn {
@@ -34,10 +36,22 @@ typedef __attribute__((address_space(3))) void* xb_lds_ptr_t;
 
 constexpr unsigned XB_OOB = 0x80000000u;
 
-// staged frame image of one quad (dwmfma.hip's layout): region rows x 16 positions x 10 slots of 16 bytes (8 used: 64 channels)
+// staged frame image of one quad (dwmfma.hip's layout, tighter on narrow planes): region rows x RW positions x 10 slots of 16 bytes (8 used:
+// 64 channels).  RW = 16 for regions up to 14 wide; 10 for the two-rows-per-tile regions (<= 8 wide): 16 KiB instead of 25 per frame, which
+// is what lets the ring hold four frames next to the 87 KB stencil-output image of the 432-channel blocks
 constexpr int xb_tiles(int rpt) { return rpt == 2 ? 4 : 7; }
 constexpr int xb_rows(int rpt) { return xb_tiles(rpt) * rpt - 1 + 3; }
-constexpr int xb_ni(int rpt) { return (xb_rows(rpt) * 16 * 10 + 63) / 64; }  // 1-KiB DMA instructions per frame: 23 / 25
+constexpr int xb_rw(int rpt) { return rpt == 2 ? 10 : 16; }
+constexpr int xb_ni(int rpt) { return (xb_rows(rpt) * xb_rw(rpt) * 10 + 63) / 64; }  // 1-KiB DMA instructions per frame: 23 / 16
+
+__device__ __forceinline__ void xb_wait_all_but(int n) {  // n wave-uniform: all but this wave's n most recent vector-memory ops are done
+    switch (n) {
+#define XB_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        XB_W(0) XB_W(1) XB_W(2) XB_W(3) XB_W(4) XB_W(5) XB_W(6) XB_W(7) XB_W(8) XB_W(9) XB_W(10) XB_W(11) XB_W(12)
+#undef XB_W
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;  // never weaker than asked: at most (NS - 2) x 3 DMA instructions are younger
+    }
+}
 
 __device__ __forceinline__ void xb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ unsigned xb_bf16_bits(float f) {
@@ -45,11 +59,23 @@ __device__ __forceinline__ unsigned xb_bf16_bits(float f) {
     return (unsigned)__builtin_bit_cast(unsigned short, b);
 }
 
+#ifdef PASN_TUNING
+// cycle stamps of block 0 / wave 0 (PASN_BLOCK_ABL bit 64; tools/block_bench.py prints them): [0] start, [1] LDS cleared, then per tile
+// 8 entries: D start, D end, P end, E end, cycles inside the D-step waits + barriers, steps, -, -
+__device__ long long xb_stamps[8 + 8 * 16];
+#define XB_STAMP(i) do { if (ABL && (g.abl & 64) && blockIdx.x == 0 && threadIdx.x == 0 && (i) < 8 + 8 * 16) xb_stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define XB_STAMP(i) do { } while (0)
+#endif
+
 struct XbArgs {
     const __bf16* e;          // expanded activation of THIS block [N][T][H][W][Cmp]
-    const float* w_dw;        // stencil taps [27][Cmp] fp32
-    const float *s_dw, *b_dw; // [Cmp]
-    const __bf16* w_c;        // project weights, fragment-major [CTC][KSC][64][8], K zero-padded to KSC steps
+    const unsigned short* wq; // stencil weight operands [16-channel tile][2 halves][64 lanes][8]: entry e = kt * 5 + j (half e >> 3, slot e & 7) = bf16
+                              // bits of the lane's ONE possibly nonzero element of the block-diagonal operand A[kt][pair j], zero where the lane
+                              // holds none (host: plan.stencil_operands; the values dwmfma.hip builds in its prologue).  One half of a tile = 1 KiB
+                              // = one LDS-DMA instruction
+    const float *s_dw, *b_dw; // [Cmp], zero beyond the real channels
+    const __bf16* w_c;        // project weights, fragment-major [CTC][KSC][64][8], K zero-padded to KSC (even) steps
     const float *s_c, *b_c;   // [>= 32 CTC]
     const __bf16* res;        // block input [M][Cop]
     __bf16* y;                // block output [M][Cop]
@@ -59,29 +85,157 @@ struct XbArgs {
     int N, T, H, W, Cm, Cmp, Cop, Cnp;
 };
 
-template <int RPT, bool EXPAND, int ABL>
+// One pointwise conv of the tile: out[r][ch] = act(scale * sum_k W[ch][k] img[r][k] + bias (+ residual)), unit = (32 channels, two 32-row tiles).
+// scale / bias: the launch's tables in LDS (read where they are used: as registers held across the weight burst they were 32 of the 256).
+// The whole-K weight fragments of a unit are requested in one burst (one L2 round trip, then streaming); the NEXT unit's burst goes out right
+// after the MFMAs of this one, under its epilogue.  RES: + residual rows from global memory; TOLDS: the bf16 outputs also go to `xt`.
+template <int KS, bool RES, bool TOLDS>
+__device__ __forceinline__ void xb_pointwise(const __bf16* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ bias,
+                                             const char* img, int IPL, int ctiles, int RTn, const unsigned* rowtab,
+                                             const __amdgpu_buffer_rsrc_t& rrsrc, const __amdgpu_buffer_rsrc_t& orsrc, int Cout_p, char* xt, int XPL,
+                                             int wave, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    const int npairs = (RTn + 1) >> 1;
+    const int units = ctiles * npairs;
+    // Software pipeline with ONE load site for the weight burst (two sites -- a prologue and the loop tail -- made the compiler keep two copies
+    // of the 4 KS fragment registers around the back edge): iteration = [request the PREVIOUS unit's epilogue operands] [request this unit's
+    // weights] [previous unit's epilogue: waits for its own, older loads only] [this unit's MFMAs].
+    f32x16 acc0, acc1;
+    int pco = 0, ppp = 0;
+    bool have_prev = false;
+#pragma unroll 1
+    for (int u = wave;; u += 8) {
+        const bool cur = u < units;  // wave-uniform
+        unsigned off[2][2];
+        uint4 rraw[2][2];
+        if (have_prev) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const unsigned gp = rowtab[min(ppp * 2 + mt, RTn - 1) * 32 + c];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int ch = pco * 32 + 16 * pr + 8 * h;
+                    off[mt][pr] = (ppp * 2 + mt < RTn && gp != 0xffffffffu && ch < Cout_p) ? (gp * (unsigned)Cout_p + (unsigned)ch) * 2u : XB_OOB;
+                    if (RES) rraw[mt][pr] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)off[mt][pr], 0, 0));
+                }
+            }
+        }
+        bf16x8 A[KS];
+        constexpr int KH = KS > 16 ? KS / 2 : KS;  // K > 256: the burst goes out in two halves around the epilogue (all of it at once + the epilogue's operands
+                                                   // did not fit 256 registers: 50 spilled); the second half lands under the MFMAs of the first
+        const int co = cur ? u / npairs : 0, pp = cur ? u - co * npairs : 0;
+        const __bf16* ab = w + ((long)co * KS * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) A[ks] = load_frag<__bf16>(ab + ks * 512);  // (a finished wave re-reads tile 0: harmless, and no branch around the burst)
+        if (have_prev) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float v[8];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt ? acc1[8 * pr + qq] : acc0[8 * pr + qq]),
+                                                                         __float_as_uint(mt ? acc1[8 * pr + 4 + qq] : acc0[8 * pr + 4 + qq]), false, false);
+                        v[qq] = __uint_as_float(sw[0]);
+                        v[4 + qq] = __uint_as_float(sw[1]);
+                    }
+                    float scv[8], bsv[8];
+                    load8(scale + pco * 32 + 16 * pr + 8 * h, scv);
+                    load8(bias + pco * 32 + 16 * pr + 8 * h, bsv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * scv[e] + bsv[e];
+                    if (RES) {
+                        float r8[8];
+                        const uint4 rr1[1] = {rraw[mt][pr]};
+                        raw_to_f8<__bf16>(rr1, r8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)relu_f32(v[e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xb_u32x4, o), orsrc, (int)off[mt][pr], 0, 0);
+                    if (TOLDS) {
+                        const int ch = pco * 32 + 16 * pr + 8 * h;
+                        // (channels beyond the width would spill into the next row; a row tile beyond the tile's rows has no image rows)
+                        if (ch < Cout_p && ppp * 2 + mt < RTn) *reinterpret_cast<bf16x8*>(xt + (((ppp * 2 + mt) * 32 + c) * XPL + (ch >> 3)) * 16) = o;
+                    }
+                }
+            }
+        }
+        if (!cur) break;
+#pragma unroll
+        for (int ks = KH; ks < KS; ++ks) A[ks] = load_frag<__bf16>(ab + ks * 512);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.0f;
+        const char* b0 = img + ((pp * 64 + c) * IPL + h) * 16;
+        const char* b1 = b0 + 32 * IPL * 16;
+        // explicit two-deep operand pipeline (left to itself the scheduler hoists all 2 KS reads to the top: 8 KS registers, spilled)
+        bf16x8 Bq[2][2];
+        Bq[0][0] = *reinterpret_cast<const bf16x8*>(b0);
+        Bq[0][1] = *reinterpret_cast<const bf16x8*>(b1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                Bq[(ks + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(b0 + (ks + 1) * 32);
+                Bq[(ks + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(b1 + (ks + 1) * 32);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], Bq[ks & 1][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], Bq[ks & 1][1], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        pco = co;
+        ppp = pp;
+        have_prev = true;
+    }
+}
+
+// KSA = 0: no chained expand conv (the last block of a stage)
+template <int RPT, int KSC, int KSA, int ABL>
 __global__ __launch_bounds__(512) void x3d_block_kernel(XbArgs a, XbGeom g) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr bool EXPAND = KSA != 0;
     constexpr int NT = xb_tiles(RPT), NTW = (NT + 1) / 2;
-    constexpr int RW = 16, SLOTS = 10;
+    constexpr int RW = xb_rw(RPT), SLOTS = 10;
     constexpr int NI = xb_ni(RPT), NE = (NI + 7) / 8;
     constexpr int fbytes = NI * 1024;
     constexpr int lstep = RPT * RW * SLOTS * 16;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, q = lane >> 4;   // stencil roles
-    const int c = lane & 31, h = lane >> 5;   // pointwise roles
     const int ctw = wave & 3, ph = wave >> 2;
     const int abl = ABL ? g.abl : 0;
-    char* const ring = smem;                  // [2][fbytes]; dead after the D phase
+    char* const ring = smem;                  // [NS][fbytes]; dead after the D phase
     char* const xt = smem;                    // [RTn * 32][XPL] slots: aliases the ring
     char* const dwact = smem + g.dw_off;      // [R + 1][DPL] slots (row R: dump row of the lanes that hold no output)
     unsigned* const rowtab = reinterpret_cast<unsigned*>(smem + g.tab_off);  // [RTn * 32] global position of a tile row, ~0u: none
+    float* const cst = reinterpret_cast<float*>(smem + g.cst_off);           // scale / bias tables: stencil [2][Cmp], project [2][32 CTC], expand [2][32 CTA]
+    char* const wop = smem + g.wop_off;       // [4 channel tiles][2 halves][64 lanes][16 bytes]: the current quad's stencil weight operands
     const int Cmp = a.Cmp, Cop = a.Cop, T = a.T, H = a.H, W = a.W;
-    const int DPL = g.DPL, XPL = g.XPL, TF = g.TF, BW = g.BW, BHW = g.BH * g.BW, R = g.R, RTn = g.RTn;
+    const int DPL = g.DPL, XPL = g.XPL, TF = g.TF, BW = g.BW, BHW = g.BH * g.BW, R = g.R, RTn = g.RTn, NS = g.NS, LA = g.NS - 1;
     const int nsteps_q = TF + 2;
+    float* const sdw = cst, *const bdw = cst + Cmp, *const scp = cst + 2 * Cmp, *const bcp = scp + 32 * g.CTC, *const sap = bcp + 32 * g.CTC,
+                *const bap = sap + 32 * g.CTA;
 
+    XB_STAMP(0);
     // the pad slots of the two operand images (k beyond the real channels: the weights there are zero, the activations must be finite)
     for (int i = threadIdx.x; i < g.lds_bytes / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cmp; i += 512) {
+        sdw[i] = a.s_dw[i];
+        bdw[i] = a.b_dw[i];
+    }
+    for (int i = threadIdx.x; i < 32 * g.CTC; i += 512) {
+        scp[i] = a.s_c[i];
+        bcp[i] = a.b_c[i];
+    }
+    if (EXPAND)
+        for (int i = threadIdx.x; i < 32 * g.CTA; i += 512) {
+            sap[i] = a.s_a[i];
+            bap[i] = a.b_a[i];
+        }
 
     const long fstride = (long)H * W * Cmp;
     const unsigned fr_in_bytes = (unsigned)(fstride * 2);
@@ -89,6 +243,8 @@ __global__ __launch_bounds__(512) void x3d_block_kernel(XbArgs a, XbGeom g) {
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.res), 0, (unsigned)(M * Cop * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(M * Cop * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t ersrc = __builtin_amdgcn_make_buffer_rsrc(EXPAND ? a.e_next : a.y, 0, EXPAND ? (unsigned)(M * a.Cnp * 2) : 0u, 0x00020000);
+    const int CT16 = (Cmp + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wq), 0, (unsigned)CT16 * 2048u, 0x00020000);
 
     int tapoff[5];
 #pragma unroll
@@ -100,18 +256,31 @@ __global__ __launch_bounds__(512) void x3d_block_kernel(XbArgs a, XbGeom g) {
     const int regions = g.RTH * g.RTW;
     const int lbl = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_end = min(g.tiles, (lbl + 1) * g.tpb);
+    const int kdma = NI > wave ? (NI - wave + 7) >> 3 : 0;  // frame-DMA instructions of this wave per step
+    const int dwsel = (m & 7) >> 1, wsh = (m & 1) * 16;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 S0[NTW], S1[NTW], S2[NTW];
-#pragma unroll
-    for (int l = 0; l < NTW; ++l) S0[l] = S1[l] = S2[l] = zero4;
+    // the stencil weight operands of quad qd: wave (ctw, ph) fetches half ph of channel tile 4 qd + ctw -- ONE 1-KiB LDS-DMA instruction.  (As register
+    // loads, issued a quad ahead, hipcc guarded their use with vmcnt(0): the frame pipeline drained once per quad.)
+    auto issue_ops = [&](int qd) {
+        const int ct = min(qd * 4 + ctw, CT16 - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (xb_lds_ptr_t)(wop + (ctw * 2 + ph) * 1024), 16, (int)(((ct * 2 + ph) * 64 + lane) * 16), 0, 0, 0);
+    };
     __syncthreads();
+    XB_STAMP(1);
+    int tix = 0;
+    long long twait = 0;
 
 #pragma unroll 1
-    for (int tile = lbl * g.tpb; tile < tile_end; ++tile) {
+    for (int tile = lbl * g.tpb; tile < tile_end; ++tile, ++tix) {
+        // (all stencil state lives inside the tile: nothing of it is held across the pointwise phases, whose weight bursts need the registers)
+        f32x4 S0[NTW], S1[NTW], S2[NTW];
+#pragma unroll
+        for (int l = 0; l < NTW; ++l) S0[l] = S1[l] = S2[l] = zero4;
         const int tch = tile % g.nTch, nr = tile / g.nTch;
         const int reg = nr % regions, n = nr / regions;
         const int rth = reg / g.RTW, rtw = reg - rth * g.RTW;
         const int t0 = tch * TF, h0 = rth * g.BH, w0 = rtw * BW;
+        issue_ops(0);  // (older than every frame group: landed when the first group has)
         // ---- row table of this tile: row r = (frame, region row, region column) -> global position ------------------------------------
         if ((int)threadIdx.x < RTn * 32) {
             const int r = threadIdx.x;
@@ -133,7 +302,8 @@ __global__ __launch_bounds__(512) void x3d_block_kernel(XbArgs a, XbGeom g) {
         }
         const __bf16* eclip = a.e + (long)n * T * fstride;
         const int total = g.NQ * nsteps_q;
-        auto issue = [&](int s) {
+        // the DMA group of step s (quad s / (TF + 2), frame t0 - 1 + s % (TF + 2)) into ring slot `slot`
+        auto issue = [&](int s, int slot) {
             if (s >= total || (abl & 2)) return;
             const int qd = s / nsteps_q, f = s - qd * nsteps_q;
             const int ti = t0 - 1 + f;
@@ -141,7 +311,7 @@ __global__ __launch_bounds__(512) void x3d_block_kernel(XbArgs a, XbGeom g) {
             const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(eclip + qd * 64), 0,
                                                                                (unsigned)T * fr_in_bytes - (unsigned)(qd * 128), 0x00020000);
             const unsigned foff = inclip ? (unsigned)ti * fr_in_bytes : 0u;
-            char* dst = ring + (s & 1) * fbytes;
+            char* dst = ring + slot * fbytes;
 #pragma unroll
             for (int e = 0; e < NE; ++e)
                 if (wave + 8 * e < NI)
@@ -154,69 +324,117 @@ __global__ __launch_bounds__(512) void x3d_block_kernel(XbArgs a, XbGeom g) {
         float sc[4], bs[4];
         bool wave_live = false;
         int ce = 0;
-        issue(0);
+        for (int j = 0; j < LA; ++j) issue(j, j);
+        XB_STAMP(8 + 8 * tix);
+        twait = 0;
+        long long tparts[3] = {0, 0, 0};
+        int slot = 0, islot = LA, qd = 0, f = 0;  // ring slot of step s; ring slot the next group goes to; (quad, frame) of step s
 #pragma unroll 1
         for (int s = 0; s < total; ++s) {
-            const int qd = s / nsteps_q, f = s - qd * nsteps_q;
-            if (f == 0) {  // this quad's weight operands and epilogue constants (dwmfma.hip: block-diagonal, built once per quad)
+#ifdef PASN_TUNING
+            long long tw0 = 0;
+            if (ABL && (g.abl & 64)) tw0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+            // Group s has landed for this wave -- counted: vmcnt retires in order, everything this wave issued AFTER group s may still fly: the
+            // groups of the look-ahead steps that exist and, while it is younger than group s, the operand fetch of the next quad (issued at
+            // f == 1).  At f == 0 the operands themselves must have landed: they are older than group s when TF + 1 >= LA, else only the
+            // groups issued since then may be outstanding.  Then everyone's have; nobody still reads the slot of step s - 1.
+            {
+                const int ahead = min(LA - 1, total - 1 - s);
+                int n = ahead * kdma;
+                if (f == 0) n = min(ahead, nsteps_q - 1) * kdma;
+                else if (f - 1 >= 1 && f - 1 <= LA - 1 && qd + 1 < g.NQ) n += 1;
+                xb_wait_all_but((abl & 2) ? 0 : n);
+            }
+            xb_barrier();
+#ifdef PASN_TUNING
+            if (ABL && (g.abl & 64)) twait += (long long)__builtin_amdgcn_s_memrealtime() - tw0;
+#endif
+#ifdef PASN_TUNING
+            long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+            if (ABL && (g.abl & 64)) tq0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+            if (f == 1 && qd + 1 < g.NQ) issue_ops(qd + 1);  // everyone built quad qd's operands before this step's barrier: the buffer is free
+            issue(s + LA, islot);
+            if (f == 0) {  // this quad's weight operands and epilogue constants
                 const int c0 = (qd * 4 + ctw) * 16;
                 wave_live = c0 < Cmp;
-                const int cch = c0 + m;
-                const bool mine = ((m >> 3) == (q & 1)) && cch < Cmp;
-                const int dwsel = (m & 7) >> 1, sh = (m & 1) * 16;
-                const int ccl = min(cch, Cmp - 1);
-                float wv[3][5];
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) wv[kt][j] = a.w_dw[(kt * 9 + min(2 * j + (q >> 1), 8)) * Cmp + ccl];
                 ce = c0 + 4 * q;
                 const bool cev = ce < Cmp;
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sdw + min(ce, Cmp - 4)), b4 = *reinterpret_cast<const f32x4*>(bdw + min(ce, Cmp - 4));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    sc[i] = (cev && ce + i < a.Cm) ? a.s_dw[ce + i] : 0.0f;
-                    bs[i] = (cev && ce + i < a.Cm) ? a.b_dw[ce + i] : 0.0f;
+                    sc[i] = cev ? s4[i] : 0.0f;
+                    bs[i] = cev ? b4[i] : 0.0f;
                 }
+                const uint4 w0v = *reinterpret_cast<const uint4*>(wop + ((ctw * 2 + 0) * 64 + lane) * 16);
+                const uint4 w1v = *reinterpret_cast<const uint4*>(wop + ((ctw * 2 + 1) * 64 + lane) * 16);
+                const unsigned wd[8] = {w0v.x, w0v.y, w0v.z, w0v.w, w1v.x, w1v.y, w1v.z, w1v.w};
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
-                        const bool livew = mine && 2 * j + (q >> 1) < 9;
-                        const unsigned bits = livew ? (xb_bf16_bits(wv[kt][j]) << sh) : 0u;
+                        const int e = kt * 5 + j;
+                        const unsigned u16v = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffffu);
+                        const unsigned bits = wave_live ? (u16v << wsh) : 0u;
                         A[kt][j] = xb_u32x4{dwsel == 0 ? bits : 0u, dwsel == 1 ? bits : 0u, dwsel == 2 ? bits : 0u, dwsel == 3 ? bits : 0u};
                     }
             }
-            // frame s has landed for this wave (nothing younger is in flight), then for everyone; nobody still reads the other slot
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            xb_barrier();
-            issue(s + 1);
+#ifdef PASN_TUNING
+            if (ABL && (g.abl & 64)) tq1 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
             if (wave_live && !(abl & 1)) {
-                int fbo = (s & 1) * fbytes + lbase0 + ph * NTW * lstep;
+                int fbo = slot * fbytes + lbase0 + ph * NTW * lstep;
                 asm volatile("" : "+v"(fbo));
                 const char* ta[5];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) ta[j] = ring + fbo + tapoff[j];
-                bf16x8 Bq[2][5];
+                // Only the chains whose output frame lies in this tile run: frame f feeds output t0 + f - 2 through kt = 2 (set S0), t0 + f - 1
+                // through kt = 1 (S1), t0 + f through kt = 0 (S2).  With all three chains on every staged frame -- what dwmfma.hip does, at T chunks
+                // of 8-16 -- a 2-frame tile did 60 MFMAs per position tile for the 30 it needs.  The sets still rotate through the chains' first
+                // MFMA; a skipped chain's set is never read before it is restarted.
+                auto frame = [&](auto dop, auto doc, auto don) {
+                    constexpr bool DOP = decltype(dop)::value, DOC = decltype(doc)::value, DON = decltype(don)::value;
+                    constexpr int NCH = (DOP ? 1 : 0) + (DOC ? 1 : 0) + (DON ? 1 : 0);
+                    bf16x8 Bq[2][5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
 #pragma unroll
-                for (int l = 0; l < NTW; ++l) {
-                    if (l + 1 < NTW) {
+                    for (int l = 0; l < NTW; ++l) {
+                        if (l + 1 < NTW) {
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) Bq[(l + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ta[j] + (l + 1) * lstep);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                            for (int j = 0; j < 5; ++j) Bq[(l + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ta[j] + (l + 1) * lstep);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            const bf16x8 B = Bq[l & 1][j];
+                            if (DOP) S0[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, j == 0 ? S1[l] : S0[l], 0, 0, 0);
+                            if (DOC) S1[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, j == 0 ? S2[l] : S1[l], 0, 0, 0);
+                            if (DON) S2[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : S2[l], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 5 * NCH, 0);
                     }
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const bf16x8 B = Bq[l & 1][j];
-                        S0[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, j == 0 ? S1[l] : S0[l], 0, 0, 0);
-                        S1[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, j == 0 ? S2[l] : S1[l], 0, 0, 0);
-                        S2[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : S2[l], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
+                };
+                using T1 = std::true_type;
+                using T0 = std::false_type;
+                const int mask = ((f >= 2 && f <= TF + 1) ? 4 : 0) | ((f >= 1 && f <= TF) ? 2 : 0) | (f <= TF - 1 ? 1 : 0);  // wave-uniform
+                switch (mask) {
+                    case 1: frame(T0{}, T0{}, T1{}); break;
+                    case 2: frame(T0{}, T1{}, T0{}); break;
+                    case 3: frame(T0{}, T1{}, T1{}); break;
+                    case 4: frame(T1{}, T0{}, T0{}); break;
+                    case 6: frame(T1{}, T1{}, T0{}); break;
+                    default: frame(T1{}, T1{}, T1{}); break;
                 }
             }
+#ifdef PASN_TUNING
+            if (ABL && (g.abl & 64)) {
+                asm volatile("s_nop 0" ::: "memory");
+                tq2 = (long long)__builtin_amdgcn_s_memrealtime();
+            }
+#endif
             // S0 now holds output frame t0 + f - 2 of this quad: complete once f >= 2
             if (wave_live && f >= 2 && t0 + f - 2 < T) {
                 const int tfo = f - 2;
@@ -238,146 +456,48 @@ __global__ __launch_bounds__(512) void x3d_block_kernel(XbArgs a, XbGeom g) {
                     *reinterpret_cast<bf16x4*>(dwact + (r * DPL) * 16 + (ok ? ce : 0) * 2) = o;
                 }
             }
-        }
-        __syncthreads();  // dwact and the row table are complete; the ring is dead (xt may overwrite it)
-
-        // ================================ P: project conv + residual + ReLU ==============================================================
-        const int npairs = (RTn + 1) >> 1;
-        if (!(abl & 4)) {
-#pragma unroll 1
-            for (int u = wave; u < g.CTC * npairs; u += 8) {
-                const int co = u / npairs, pp = u - co * npairs;
-                f32x16 acc0, acc1;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.0f;
-                const __bf16* ab = a.w_c + ((long)co * g.KSC * 64 + lane) * 8;
-                const char* b0 = dwact + ((pp * 64 + c) * DPL + h) * 16;
-                const char* b1 = b0 + 32 * DPL * 16;
-                bf16x8 A0 = load_frag<__bf16>(ab), A1 = load_frag<__bf16>(ab + 512);
-#pragma unroll 1
-                for (int ks = 0; ks < g.KSC; ks += 2) {  // KSC is even (host pads K with zero weights)
-                    const bf16x8 a0 = A0, a1 = A1;
-                    A0 = load_frag<__bf16>(ab + (size_t)min(ks + 2, g.KSC - 2) * 512);
-                    A1 = load_frag<__bf16>(ab + (size_t)min(ks + 3, g.KSC - 1) * 512);
-                    const bf16x8 B00 = *reinterpret_cast<const bf16x8*>(b0 + ks * 32), B10 = *reinterpret_cast<const bf16x8*>(b1 + ks * 32);
-                    const bf16x8 B01 = *reinterpret_cast<const bf16x8*>(b0 + ks * 32 + 32), B11 = *reinterpret_cast<const bf16x8*>(b1 + ks * 32 + 32);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B00, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B10, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B01, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B11, acc1, 0, 0, 0);
-                }
-                float scv[2][8], bsv[2][8];
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    load8(a.s_c + co * 32 + 16 * pr + 8 * h, scv[pr]);
-                    load8(a.b_c + co * 32 + 16 * pr + 8 * h, bsv[pr]);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int rt = pp * 2 + mt;
-                    if (rt < RTn) {  // wave-uniform
-                        const int r = rt * 32 + c;
-                        const unsigned gp = rowtab[r];
-                        uint4 rraw[2];
-                        unsigned off[2];
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const int ch = co * 32 + 16 * pr + 8 * h;
-                            off[pr] = (gp != 0xffffffffu && ch < Cop) ? (gp * (unsigned)Cop + (unsigned)ch) * 2u : XB_OOB;
-                            rraw[pr] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)off[pr], 0, 0));
-                        }
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            float v[8], r8[8];
-#pragma unroll
-                            for (int qq = 0; qq < 4; ++qq) {
-                                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt ? acc1[8 * pr + qq] : acc0[8 * pr + qq]),
-                                                                                 __float_as_uint(mt ? acc1[8 * pr + 4 + qq] : acc0[8 * pr + 4 + qq]), false, false);
-                                v[qq] = __uint_as_float(sw[0]);
-                                v[4 + qq] = __uint_as_float(sw[1]);
-                            }
-                            const uint4 rr1[1] = {rraw[pr]};
-                            raw_to_f8<__bf16>(rr1, r8);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = relu_f32(v[e] * scv[pr][e] + bsv[pr][e] + r8[e]);
-                            bf16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xb_u32x4, o), yrsrc, (int)off[pr], 0, 0);
-                            const int ch = co * 32 + 16 * pr + 8 * h;
-                            if (EXPAND && ch < Cop) *reinterpret_cast<bf16x8*>(xt + (r * XPL + (ch >> 3)) * 16) = o;
-                        }
-                    }
-                }
+#ifdef PASN_TUNING
+            if (ABL && (g.abl & 64)) {
+                tq3 = (long long)__builtin_amdgcn_s_memrealtime();
+                tparts[0] += tq1 - tq0;
+                tparts[1] += tq2 - tq1;
+                tparts[2] += tq3 - tq2;
+            }
+#endif
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            islot = islot + 1 == NS ? 0 : islot + 1;
+            if (++f == nsteps_q) {
+                f = 0;
+                ++qd;
             }
         }
+        __syncthreads();  // dwact and the row table are complete; the ring is dead (xt may overwrite it)
+        XB_STAMP(8 + 8 * tix + 1);
+#ifdef PASN_TUNING
+        if (ABL && (g.abl & 64) && blockIdx.x == 0 && threadIdx.x == 0 && tix < 16) {
+            xb_stamps[8 + 8 * tix + 4] = twait;
+            xb_stamps[8 + 8 * tix + 5] = total;
+            xb_stamps[8 + 8 * tix + 6] = tparts[0] | (tparts[1] << 20) | (tparts[2] << 40);
+        }
+#endif
+
+        // ================================ P: project conv + residual + ReLU ==============================================================
+        if (!(abl & 4))
+            xb_pointwise<KSC, true, EXPAND>(a.w_c, scp, bcp, dwact, DPL, g.CTC, RTn, rowtab, rrsrc, yrsrc, Cop, xt, XPL, wave, lane);
+        XB_STAMP(8 + 8 * tix + 2);
         if (EXPAND) {
             __syncthreads();  // the block-output tile is complete in xt
             // ================================ E: the next block's expand conv + ReLU =====================================================
-            if (!(abl & 8)) {
-#pragma unroll 1
-                for (int u = wave; u < g.CTA * npairs; u += 8) {
-                    const int co = u / npairs, pp = u - co * npairs;
-                    f32x16 acc0, acc1;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.0f;
-                    const __bf16* ab = a.w_a + ((long)co * g.KSA * 64 + lane) * 8;
-                    const char* b0 = xt + ((pp * 64 + c) * XPL + h) * 16;
-                    const char* b1 = b0 + 32 * XPL * 16;
-                    bf16x8 A0 = load_frag<__bf16>(ab), A1 = load_frag<__bf16>(ab + 512);
-#pragma unroll 1
-                    for (int ks = 0; ks < g.KSA; ks += 2) {
-                        const bf16x8 a0 = A0, a1 = A1;
-                        A0 = load_frag<__bf16>(ab + (size_t)min(ks + 2, g.KSA - 2) * 512);
-                        A1 = load_frag<__bf16>(ab + (size_t)min(ks + 3, g.KSA - 1) * 512);
-                        const bf16x8 B00 = *reinterpret_cast<const bf16x8*>(b0 + ks * 32), B10 = *reinterpret_cast<const bf16x8*>(b1 + ks * 32);
-                        const bf16x8 B01 = *reinterpret_cast<const bf16x8*>(b0 + ks * 32 + 32), B11 = *reinterpret_cast<const bf16x8*>(b1 + ks * 32 + 32);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B00, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B10, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B01, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B11, acc1, 0, 0, 0);
-                    }
-                    float scv[2][8], bsv[2][8];
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        load8(a.s_a + co * 32 + 16 * pr + 8 * h, scv[pr]);
-                        load8(a.b_a + co * 32 + 16 * pr + 8 * h, bsv[pr]);
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const int rt = pp * 2 + mt;
-                        if (rt < RTn) {
-                            const unsigned gp = rowtab[rt * 32 + c];
-#pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {
-                                float v[8];
-#pragma unroll
-                                for (int qq = 0; qq < 4; ++qq) {
-                                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt ? acc1[8 * pr + qq] : acc0[8 * pr + qq]),
-                                                                                     __float_as_uint(mt ? acc1[8 * pr + 4 + qq] : acc0[8 * pr + 4 + qq]), false, false);
-                                    v[qq] = __uint_as_float(sw[0]);
-                                    v[4 + qq] = __uint_as_float(sw[1]);
-                                }
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] = relu_f32(v[e] * scv[pr][e] + bsv[pr][e]);
-                                bf16x8 o;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-                                const int ch = co * 32 + 16 * pr + 8 * h;
-                                const unsigned off = (gp != 0xffffffffu && ch < a.Cnp) ? (gp * (unsigned)a.Cnp + (unsigned)ch) * 2u : XB_OOB;
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xb_u32x4, o), ersrc, (int)off, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
+            if (!(abl & 8))
+                xb_pointwise<EXPAND ? KSA : 2, false, false>(a.w_a, sap, bap, xt, XPL, g.CTA, RTn, rowtab, ersrc, ersrc, a.Cnp, nullptr, 0, wave, lane);
         }
-        __syncthreads();  // nobody reads xt / dwact / the row table any more: the next tile's first frame may land
+        __syncthreads();  // nobody reads xt / dwact / the row table any more: the next tile's first frames may land
+        XB_STAMP(8 + 8 * tix + 3);
     }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
-static bool xb_pointwise(const pasn_conv_desc& d) {
+static bool xb_is_pointwise(const pasn_conv_desc& d) {
     return d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && !d.pt && !d.ph && !d.pw;
 }
 
@@ -385,11 +505,17 @@ static bool xb_pointwise(const pasn_conv_desc& d) {
 XbGeom xb_geom(const pasn_conv_desc& dd, const pasn_conv_desc& dc, const pasn_conv_desc* da, int dtype) {
     XbGeom g{};
     if (dtype != PASN_BF16) return g;
-    if (const char* e = tune("PASN_NO_BLOCK"))
-        if (e[0] == '1') return g;
+    // Routing by measurement (profiles/README.md round-4 entries 3-6): at the X3D-S benchmark shapes the fused launch LOSES to the separate
+    // launches on every stage (28 x 28: 171 vs 109 us, 14 x 14: 84 vs 63, 7 x 7: 65 vs 55 in isolation) -- its stencil steps serialise wait,
+    // DMA issue, MFMAs and the Swish epilogue in eight lock-step waves where dwmfma.hip runs two independent blocks per CU, and the 85-90 KB
+    // stencil-output image leaves no LDS for a deeper ring or a second block.  OFF by default; PASN_BLOCK=1: every covered block (what the
+    // parity tests run), PASN_BLOCK=5: the 432-channel blocks only.
+    const char* mode = tune("PASN_BLOCK");
+    if (!mode || mode[0] == '0') return g;
+    if (mode[0] == '5' && dd.Cout_p < 432) return g;
     const bool stencil = dd.kt == 3 && dd.kh == 3 && dd.kw == 3 && dd.st == 1 && dd.sh == 1 && dd.sw == 1 && dd.pt == 1 && dd.ph == 1 && dd.pw == 1 &&
                          dd.To == dd.Ti && dd.Ho == dd.Hi && dd.Wo == dd.Wi && dd.Cin_p == dd.Cout_p && dd.Cout_p % 8 == 0 && dd.act == PASN_ACT_SWISH;
-    if (!stencil || !xb_pointwise(dc) || dc.in_swish || dc.act != PASN_ACT_RELU) return g;
+    if (!stencil || !xb_is_pointwise(dc) || dc.in_swish || dc.act != PASN_ACT_RELU) return g;
     if (dc.N != dd.N || dc.To != dd.To || dc.Ho != dd.Ho || dc.Wo != dd.Wo || dc.Cin != dd.Cout || dc.Cin_p != dd.Cout_p || dc.w_frag != 1) return g;
     if (dc.Cout_p % 16 != 0 || dc.Cout_p < 48 || dc.Cout_p > 256 || dd.Cout_p > 512) return g;  // (narrower blocks: byte-bound on big planes, the separate launches win)
     g.KSC = (dd.Cout_p + 31) / 32 * 2;
@@ -397,7 +523,7 @@ XbGeom xb_geom(const pasn_conv_desc& dd, const pasn_conv_desc& dc, const pasn_co
     g.CTC = (dc.Cout_p + 31) / 32;
     if (dc.w_rows < g.CTC * 32) return g;
     if (da) {
-        if (!xb_pointwise(*da) || da->in_swish || da->act != PASN_ACT_RELU || da->w_frag != 1) return g;
+        if (!xb_is_pointwise(*da) || da->in_swish || da->act != PASN_ACT_RELU || da->w_frag != 1) return g;
         if (da->N != dc.N || da->To != dc.To || da->Ho != dc.Ho || da->Wo != dc.Wo || da->Cin != dc.Cout || da->Cin_p != dc.Cout_p) return g;
         g.KSA = (dc.Cout_p + 31) / 32 * 2;
         g.CTA = (da->Cout_p + 31) / 32;
@@ -405,10 +531,11 @@ XbGeom xb_geom(const pasn_conv_desc& dd, const pasn_conv_desc& dc, const pasn_co
     }
     const long M = (long)dd.N * dd.To * dd.Ho * dd.Wo;
     if (M * dd.Cout_p * 2 >= (1L << 30) || (da && M * da->Cout_p * 2 >= (1L << 30)) || (long)dd.Ti * dd.Hi * dd.Wi * dd.Cin_p * 2 >= (1L << 31)) return g;
+    if (g.KSC != 8 && g.KSC != 14 && g.KSC != 28) return XbGeom{};                // the instantiated widths: inner 112 / 216 / 432 (X3D stages 3-5)
+    if (da && !((g.KSC == 8 && g.KSA == 4) || (g.KSC == 14 && g.KSA == 6) || (g.KSC == 28 && g.KSA == 12))) return XbGeom{};
     g.BW = std::min(dd.Wo, 14);
     g.RPT = g.BW <= 8 ? 2 : 1;
-    g.BH = std::min(dd.Ho, xb_tiles(g.RPT) * g.RPT);
-    if (g.RPT == 1) g.BH = std::min(g.BH, 7);
+    g.BH = std::min(dd.Ho, g.RPT == 2 ? 8 : 7);
     g.RTH = ceil_div(dd.Ho, g.BH);
     g.RTW = ceil_div(dd.Wo, g.BW);
     g.TF = 2;
@@ -419,14 +546,23 @@ XbGeom xb_geom(const pasn_conv_desc& dd, const pasn_conv_desc& dc, const pasn_co
     g.R = g.TF * g.BH * g.BW;
     g.RTn = ceil_div(g.R, 32);
     g.NQ = ceil_div(dd.Cout_p, 64);
-    g.DPL = (2 * g.KSC) | 1;
-    g.XPL = da ? ((2 * g.KSA) | 1) : 1;
+    // operand images: every real 8-channel slot + an odd row stride.  A k-step beyond the real channels reads the row's (zeroed) pad slot or the
+    // next row's first slots -- finite values under zero weights; the image is followed by a zeroed gap for the last row's sake
+    g.DPL = (dd.Cout_p / 8) | 1;
+    g.XPL = da ? ((dc.Cout_p / 8) | 1) : 1;
     auto kib = [](int b) { return (b + 1023) / 1024 * 1024; };
-    const int ring = 2 * xb_ni(g.RPT) * 1024;
-    const int xtb = da ? g.RTn * 32 * g.XPL * 16 : 0;
-    g.dw_off = kib(std::max(ring, xtb));
-    g.tab_off = g.dw_off + kib((g.R + 1) * g.DPL * 16);
-    g.lds_bytes = g.tab_off + kib(g.RTn * 32 * 4);
+    const int fb = xb_ni(g.RPT) * 1024;
+    const int xtb = da ? g.RTn * 32 * g.XPL * 16 + 64 : 0;
+    const int dwb = kib((g.R + 1) * g.DPL * 16 + 64), tabb = kib(g.RTn * 32 * 4);
+    const int cstb = kib((2 * dd.Cout_p + 64 * g.CTC + 64 * g.CTA) * 4), wopb = 8 * 1024;
+    g.NS = 4;
+    if (const char* e = tune("PASN_BLOCK_NS")) g.NS = std::max(2, std::min(4, atoi(e)));
+    while (g.NS > 2 && kib(std::max(g.NS * fb, xtb)) + dwb + tabb + cstb + wopb > 160 * 1024) --g.NS;
+    g.dw_off = kib(std::max(g.NS * fb, xtb));
+    g.tab_off = g.dw_off + dwb;
+    g.cst_off = g.tab_off + tabb;
+    g.wop_off = g.cst_off + cstb;
+    g.lds_bytes = g.wop_off + wopb;
     if (g.lds_bytes > 160 * 1024) return XbGeom{};
     g.tiles = dd.N * g.RTH * g.RTW * g.nTch;
     const int grid = std::min(g.tiles, 256);
@@ -437,31 +573,40 @@ XbGeom xb_geom(const pasn_conv_desc& dd, const pasn_conv_desc& dc, const pasn_co
     return g;
 }
 
-int launch_x3d_block(const void* e, const float* w_dw, const float* s_dw, const float* b_dw, const void* w_c, const float* s_c, const float* b_c,
+int launch_x3d_block(const void* e, const unsigned short* wq, const float* s_dw, const float* b_dw, const void* w_c, const float* s_c, const float* b_c,
                      const void* res, void* y, const void* w_a, const float* s_a, const float* b_a, void* e_next, const pasn_conv_desc& dd,
                      const pasn_conv_desc& dc, const pasn_conv_desc* da, const XbGeom& g, hipStream_t s) {
-    XbArgs a{(const __bf16*)e, w_dw, s_dw, b_dw, (const __bf16*)w_c, s_c, b_c, (const __bf16*)res, (__bf16*)y, (const __bf16*)w_a, s_a, b_a,
+    XbArgs a{(const __bf16*)e, wq, s_dw, b_dw, (const __bf16*)w_c, s_c, b_c, (const __bf16*)res, (__bf16*)y, (const __bf16*)w_a, s_a, b_a,
              (__bf16*)e_next, dd.N, dd.To, dd.Ho, dd.Wo, dd.Cout, dd.Cout_p, dc.Cout_p, da ? da->Cout_p : 0};
     const dim3 grid(g.grid), block(512);
-#define PASN_XB(RPT_, EXP_, ABL_)                                                                                      \
-    do {                                                                                                               \
-        PASN_MAX_LDS(160 * 1024, x3d_block_kernel<RPT_, EXP_, ABL_>);                                                 \
-        hipLaunchKernelGGL((x3d_block_kernel<RPT_, EXP_, ABL_>), grid, block, (size_t)g.lds_bytes, s, a, g);          \
+#define PASN_XB(RPT_, KSC_, KSA_, ABL_)                                                                                         \
+    do {                                                                                                                        \
+        PASN_MAX_LDS(160 * 1024, x3d_block_kernel<RPT_, KSC_, KSA_, ABL_>);                                                    \
+        hipLaunchKernelGGL((x3d_block_kernel<RPT_, KSC_, KSA_, ABL_>), grid, block, (size_t)g.lds_bytes, s, a, g);             \
+    } while (0)
+#define PASN_XB_K(RPT_, ABL_)                                         \
+    do {                                                              \
+        if (g.KSC == 8) {                                             \
+            if (da) PASN_XB(RPT_, 8, 4, ABL_);                        \
+            else PASN_XB(RPT_, 8, 0, ABL_);                           \
+        } else if (g.KSC == 14) {                                     \
+            if (da) PASN_XB(RPT_, 14, 6, ABL_);                       \
+            else PASN_XB(RPT_, 14, 0, ABL_);                          \
+        } else {                                                      \
+            if (da) PASN_XB(RPT_, 28, 12, ABL_);                      \
+            else PASN_XB(RPT_, 28, 0, ABL_);                          \
+        }                                                             \
     } while (0)
 #ifdef PASN_TUNING
     if (g.abl) {
-        if (g.RPT == 2) PASN_XB(2, true, 1);
-        else PASN_XB(1, true, 1);
+        if (g.RPT == 2) PASN_XB_K(2, 1);
+        else PASN_XB_K(1, 1);
         return check_launch("x3d_block_kernel (ablation)");
     }
 #endif
-    if (g.RPT == 2) {
-        if (da) PASN_XB(2, true, 0);
-        else PASN_XB(2, false, 0);
-    } else {
-        if (da) PASN_XB(1, true, 0);
-        else PASN_XB(1, false, 0);
-    }
+    if (g.RPT == 2) PASN_XB_K(2, 0);
+    else PASN_XB_K(1, 0);
+#undef PASN_XB_K
 #undef PASN_XB
     return check_launch("x3d_block_kernel");
 }
@@ -472,12 +617,18 @@ using namespace pasn;
 
 static bool xb_desc_ok(const pasn_conv_desc* d) { return d && d->N > 0 && d->To > 0 && d->Ho > 0 && d->Wo > 0 && d->Cin > 0 && d->Cout > 0; }
 
+#ifdef PASN_TUNING
+extern "C" int pasn_debug_block_stamps(long long* host_out, int n) {  // tuning builds only; not part of the product C-ABI
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pasn::xb_stamps), sizeof(long long) * (size_t)std::min(n, 8 + 8 * 16));
+}
+#endif
+
 extern "C" int pasn_x3d_block_supported(const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_a, int dtype) {
     if (!xb_desc_ok(d_dw) || !xb_desc_ok(d_c) || (d_a && !xb_desc_ok(d_a))) return 0;
     return xb_geom(*d_dw, *d_c, d_a, dtype).ok;
 }
 
-extern "C" int pasn_x3d_block_fwd(const void* e, const float* w_dw, const float* scale_dw, const float* bias_dw, const void* w_c,
+extern "C" int pasn_x3d_block_fwd(const void* e, const void* w_dw, const float* scale_dw, const float* bias_dw, const void* w_c,
                                   const float* scale_c, const float* bias_c, const void* residual, void* y, const void* w_a,
                                   const float* scale_a, const float* bias_a, void* e_next, const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c,
                                   const pasn_conv_desc* d_a, int dtype, void* stream) {
@@ -486,6 +637,6 @@ extern "C" int pasn_x3d_block_fwd(const void* e, const float* w_dw, const float*
     PASN_REQUIRE(xb_desc_ok(d_dw) && xb_desc_ok(d_c) && (!d_a || xb_desc_ok(d_a)), "bad geometry");
     const XbGeom g = xb_geom(*d_dw, *d_c, d_a, dtype);
     PASN_REQUIRE(g.ok, "block not covered (pasn_x3d_block_supported returns 0)");
-    return launch_x3d_block(e, w_dw, scale_dw, bias_dw, w_c, scale_c, bias_c, residual, y, w_a, scale_a, bias_a, e_next, *d_dw, *d_c, d_a, g,
+    return launch_x3d_block(e, (const unsigned short*)w_dw, scale_dw, bias_dw, w_c, scale_c, bias_c, residual, y, w_a, scale_a, bias_a, e_next, *d_dw, *d_c, d_a, g,
                             (hipStream_t)stream);
 }

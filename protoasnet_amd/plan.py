@@ -94,6 +94,30 @@ def pack_conv_weight(w: torch.Tensor, cin_p: int, dtype: torch.dtype) -> Tuple[t
     return packed.to(dtype).contiguous(), kc, rows
 
 
+def stencil_operands(w: torch.Tensor, c: int, cp: int) -> torch.Tensor:
+    """Depthwise 3x3x3 weights (C,1,3,3,3) as the matrix-core stencil's block-diagonal A operands (``pasn_x3d_block_fwd``'s ``w_dw``):
+    int16 [ceil(cp / 16)][2][64 lanes][8], entry e = kt * 5 + j (half e >> 3, slot e & 7) = bf16 bits of the lane's one possibly nonzero
+    element of A[kt][pair j] -- lane (m = lane & 15, q = lane >> 4) supplies k = 8 q .. 8 q + 7 = tap 2 j + (q >> 1) of the pair, channels
+    8 (q & 1) ..: only channel m can be nonzero, and only when m's half matches.  Same values (round-to-nearest-even) as the prologue of
+    ``dwconv3d_mfma_kernel`` builds (csrc/dwmfma.hip)."""
+    dev = w.device
+    w27 = w.detach().float().reshape(c, 27)
+    ct = (cp + 15) // 16
+    lane = torch.arange(64, device=dev)
+    m, q = lane & 15, lane >> 4
+    ch = torch.arange(ct, device=dev)[:, None] * 16 + m[None, :]                         # [ct][64]
+    tap = 2 * torch.arange(5, device=dev)[None, :] + (q >> 1)[:, None]                   # [64][5]
+    live = (tap < 9)[None, :, None, :] & ((m >> 3) == (q & 1))[None, :, None, None] & (ch < c)[:, :, None, None]
+    idx = torch.arange(3, device=dev)[None, :, None] * 9 + tap.clamp(max=8)[:, None, :]  # [64][3][5]
+    vals = w27[ch.clamp(max=c - 1)[:, :, None, None], idx[None]]                         # [ct][64][3][5]
+    bits = vals.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+    bits = torch.where(live, bits, torch.zeros_like(bits))
+    out = torch.zeros(ct, 64, 16, dtype=torch.int32, device=dev)
+    out[:, :, :15] = bits.reshape(ct, 64, 15)
+    # [tile][half][lane][8]: one half of a tile = 1 KiB = one LDS-DMA instruction of the kernel
+    return out.view(ct, 64, 2, 8).permute(0, 2, 1, 3).to(torch.int16).contiguous()
+
+
 def _igemm_name(inst: int) -> str:
     """Kernel instance of ``pasn_conv3d_variant`` - 6000 (igemm.hip / igemm_halo.hip): mode*100 + MT*10 + NT."""
     mode, mt, nt = inst // 100, (inst // 10) % 10, inst % 10
@@ -573,8 +597,7 @@ class PlanBuilder:
             if en is not None:
                 self.bufs[en.buf].nbytes = ALIGN
             return None
-        wd = torch.zeros(27, e.Cp, dtype=torch.float32, device=self.device)
-        wd[:, : e.C] = conv_b.weight.detach().float().reshape(e.C, 27).t()
+        wd = stencil_operands(conv_b.weight.to(self.device), e.C, e.Cp)
         sd, bd = fold_norm(norm_b, None, e.C, e.Cp, self.device)
         sc, bc = fold_norm(norm_c, conv_c.bias, y.C, rowsc, self.device)
         keep = [wd, sd, bd, wc, sc, bc]
@@ -588,7 +611,7 @@ class PlanBuilder:
         self._use(eb, rb, yb, nb)
         pos = y.N * y.positions
         cn = en.C if en is not None else 0
-        self._note("block" if en is None else "block+expand", f"x3d_block_kernel<{2 if e.W <= 8 else 1},{'true' if en is not None else 'false'},0>",
+        self._note("block" if en is None else "block+expand", f"x3d_block_kernel<{2 if e.W <= 8 else 1},{kcc // 16},{kca // 16 if en is not None else 0},0>",
                    (pos * (e.C + 2 * y.C + cn) + 27 * e.C + y.C * e.C + cn * y.C) * self.es, 2 * pos * (27 * e.C + y.C * e.C + cn * y.C))
         self.meta[-1]["shape"] = f"dw{e.C} k333 -> {e.C}->{y.C}" + (f" -> {y.C}->{cn}" if cn else "") + f" k111 in{e.T}x{e.H}x{e.W}"
         fn, code = self.lib.pasn_x3d_block_fwd, self.code

@@ -335,7 +335,7 @@ def test_x3d_block_one_launch(cm, c, cn, n, thw, tf, monkeypatch):
     en = F.relu(bn_a(F.conv3d(y, _rt(conv_a.weight.data, dtype)))).detach() if cn else None
 
     def run(fused):
-        with _lib_env(PASN_NO_BLOCK=None if fused else "1"):
+        with _lib_env(PASN_BLOCK="1" if fused else "0"):
             pb = _pb(dtype)
             ea, es = _cl_input(pb, e, dtype)
             ra, rs = _cl_input(pb, res, dtype)
