@@ -304,6 +304,21 @@ int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, cons
                        void* stream);
 
 /*
+ * An X3D block's conv_c (1x1x1) + norm_c + residual + ReLU chained with the NEXT block's conv_a (1x1x1) + norm_a + ReLU in ONE launch for the
+ * 432-channel stage (bf16; inner width 432 -> block width 192 -> 432), with the block's squeeze-excite gate -- when it has one -- computed in the
+ * launch's prologue from the stencil's pool partial rows: same contract and results (bit-identical) as pasn_conv3d_pair_se_fwd /
+ * pasn_conv3d_pair_fwd, which do not cover this width (both weight sets do not fit a wave's registers); the weights are streamed per row tile
+ * instead.  Differences in the operands: w1 is fragment-major with K zero-padded to an EVEN number of 16-wide steps (d1->w_kc = 32 *
+ * ceil(Cin_p / 32)); pool_partial == NULL (with Cse = 0): no gate, x is the block's final stencil output (d1->in_swish = 0).
+ * _supported() == 0: issue the separate launches.
+ */
+int pasn_x3d_pe_supported(const pasn_conv_desc* d1, const pasn_conv_desc* d2, int dtype, int Cse);
+int pasn_x3d_pe_fwd(const void* x, const void* w1, const float* scale1, const float* bias1, const void* residual, const float* pool_partial,
+                    int pool_blocks, int positions, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int Cse,
+                    void* y1, const pasn_conv_desc* d1, const void* w2, const float* scale2, const float* bias2, void* y2,
+                    const pasn_conv_desc* d2, int dtype, void* stream);
+
+/*
  * The body of an X3D residual block WITHOUT squeeze-excite in ONE launch (bf16): conv_b (depthwise 3x3x3, stride 1, pad 1) + norm_b +
  * Swish -> conv_c (1x1x1) + norm_c + residual + ReLU -> the NEXT block's conv_a (1x1x1) + norm_a + ReLU (pytorchvideo's
  * BottleneckTransform / ResBlock as instantiated by the x3d trunks BASELINE.json names; the reference itself ships no X3D -- SURVEY 8a row

@@ -166,6 +166,15 @@ struct XbGeom {
     int tiles, tpb, grid, abl;          // work split; timing ablations (PASN_BLOCK_ABL, -DPASN_TUNING builds only)
 };
 XbGeom xb_geom(const pasn_conv_desc& d_dw, const pasn_conv_desc& d_c, const pasn_conv_desc* d_a, int dtype);
+// x3d_pe.hip: project conv (+ squeeze-excite gate in the prologue) chained with the next block's expand conv for the 432-channel X3D stage,
+// weights streamed per tile (nothing stationary); ok = 0: not covered
+struct PeGeom {
+    int ok, KSC, KSA, CTC, CTA;                               // (even) k-steps and 32-channel output tiles of the two convs
+    int R, RTn, DPL, XPL;                                     // rows per tile, 32-row tiles, 16-byte slots per row of the two images
+    int xt_off, gate_off, tab_off, cst_off, lds_bytes;        // LDS layout
+    int tiles, tpb, grid, se;
+};
+PeGeom pe_geom(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, bool se, int cse);
 // pwconv_tiny.hip: fp32 / bf16 pointwise conv on few positions (the image heads): one wave per 32 x 32 output tile, operands straight from global
 bool pw_tiny_applicable(const pasn_conv_desc& d, int dtype, bool has_gate);
 int launch_pw_tiny(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y, const pasn_conv_desc& d,

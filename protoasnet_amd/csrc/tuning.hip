@@ -45,6 +45,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_NO_HALO",          "route", "no halo-tile implicit GEMM (igemm_halo.hip)"},
     {"PASN_NO_IGEMM",         "route", "no direct-to-LDS implicit GEMM (igemm.hip)"},
     {"PASN_NO_PACK",          "route", "1: training weights packed by torch ops instead of the one-launch pack kernel (host side, train.py)"},
+    {"PASN_NO_PE",            "route", "1: no streamed project + expand pair launch for the 432-channel stage (x3d_pe.hip)"},
     {"PASN_NO_PWCONV",        "route", "no register-resident persistent pointwise conv (pwconv.hip)"},
     {"PASN_NO_PWTINY",        "route", "no one-wave-per-tile pointwise conv for small maps (pwconv_tiny.hip)"},
     {"PASN_NO_SE_ANALYTIC",   "route", "training: squeeze-excite backward without the analytic pooled-gradient path (host side, train.py)"},
@@ -81,6 +82,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_WS_NS",            "geom",  "weight-stationary conv: forced stage count"},
     {"PASN_WS_PT",            "geom",  "weight-stationary conv: forced waves along positions"},
     {"PASN_WS_MINK",          "geom",  "weight-stationary conv: smallest padded K it takes (default 48)"},
+    {"PASN_PE_MT",            "geom",  "streamed project + expand pair: 32-row tiles per unit (2 or 4, default 4)"},
     {"PASN_BLOCK_TF",         "geom",  "fused residual block: forced frames per tile"},
     {"PASN_BLOCK_NS",         "geom",  "fused residual block: forced frame images in the ring (2-4)"},
     // ---- dev: only with -DPASN_TUNING (timing ablations give WRONG results) ----------------------------------------------------------

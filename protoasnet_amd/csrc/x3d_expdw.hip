@@ -117,17 +117,20 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     }
     const int ce = c0 + 4 * q;
     const bool cev = ce < Cp;
-    // The stencil's epilogue constants of this quad live in LDS ([2][64] behind the dummy region) and are read where they are used: as eight
+    // FOLD instances (the plan's form): the stencil's epilogue constants of this quad live in LDS and are read where they are used -- as eight
     // registers held across the march they were what pushed the squeeze-excite instance <2, none, 2, fold> over 256 (8 spilled VGPRs, scratch
-    // traffic inside the pinned schedule: round-3 verdict).  (zero for the padded channels: act(0 * P + 0) = 0 for none / ReLU / Swish -- the
-    // epilogue stores without a tail mask)
-    float* const scd = reinterpret_cast<float*>(reinterpret_cast<char*>(scb) + 512 + 1088);
-    if (threadIdx.x < 64) {
-        const int ch = cq * 64 + threadIdx.x;
-        scd[threadIdx.x] = ch < d.Cout ? scale[ch] : 0.0f;
-        scd[64 + threadIdx.x] = ch < d.Cout ? bias[ch] : 0.0f;
+    // traffic inside the pinned schedule: round-3 verdict).  They take the place of the expand conv's scale | bias table, which a FOLD instance
+    // reads only once, into biasC, before the march (the launch sits at 79.6 KB of LDS: two blocks per CU leave no room for another table).
+    // (zero for the padded channels: act(0 * P + 0) = 0 for none / ReLU / Swish -- the epilogue stores without a tail mask)
+    float sc_r[4], bs_r[4];
+    if (!FOLD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc_r[i] = (cev && ce + i < d.Cout) ? scale[ce + i] : 0.0f;
+            bs_r[i] = (cev && ce + i < d.Cout) ? bias[ce + i] : 0.0f;
+        }
     }
-    const float* const scl = scd + wave * 16 + 4 * q;  // this lane's four channels (always inside the [2][64] table)
+    const float* const scl = scb + wave * 16 + 4 * q;  // FOLD: this lane's four channels of the [2][64] table
     float psum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     // ---- expand conv: this wave's 32-channel tile (ct = wave & 1 of the quad) for the expand tiles (wave >> 1) + 2 i of every frame ----
@@ -156,6 +159,15 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
     f32x16 biasC;
 #pragma unroll
     for (int r = 0; r < 16; ++r) biasC[r] = folded ? scb[64 + 32 * ect + acc_row(r, h32)] : 0.0f;
+    if (FOLD) {
+        __syncthreads();  // everyone holds its biasC: the table's place takes the stencil's scale | bias
+        if (threadIdx.x < 64) {
+            const int ch = cq * 64 + threadIdx.x;
+            scb[threadIdx.x] = ch < d.Cout ? scale[ch] : 0.0f;
+            scb[64 + threadIdx.x] = ch < d.Cout ? bias[ch] : 0.0f;
+        }
+        __syncthreads();
+    }
     const int Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     const long fx = (long)Hi * Wi * Cin_p;  // elements per x frame
     const unsigned fx_bytes = (unsigned)(fx * 2);
@@ -354,7 +366,14 @@ __global__ __launch_bounds__(256, 2) void x3d_expdw_kernel(const __bf16* __restr
                 const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yclip + (long)to * ofs, 0, fr_bytes, 0x00020000);
                 // straight-line over ALL tiles, as in dwmfma.hip: a row below the plane stores out of the descriptor's range and counts nothing,
                 // the pool sums are formed whether or not the launch has a row for them, padded channels carry zero scale and bias
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(scl), bs = *reinterpret_cast<const f32x4*>(scl + 64);
+                f32x4 sc, bs;
+                if (FOLD) {
+                    sc = *reinterpret_cast<const f32x4*>(scl);
+                    bs = *reinterpret_cast<const f32x4*>(scl + 64);
+                } else {
+                    sc = f32x4{sc_r[0], sc_r[1], sc_r[2], sc_r[3]};
+                    bs = f32x4{bs_r[0], bs_r[1], bs_r[2], bs_r[3]};
+                }
 #pragma unroll
                 for (int l = 0; l < XE_NT; ++l)
                     {
@@ -547,7 +566,7 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     g.XS = (de.Cin_p / 8) | 1;
     g.xtb = ((POS + 3) * g.XS * 16 + 1023) / 1024 * 1024;  // + 3 positions: lanes 29 .. 31 of the last staged row read past it (stride 2)
     g.fuse = !(tune("PASN_EXPDW_FUSE") && tune("PASN_EXPDW_FUSE")[0] == '0');
-    g.lds = 2 * FRB + 2 * g.xtb + 512 + 1088 + 512;  // ring | x tiles | expand scale / bias | dummy stores | stencil scale / bias
+    g.lds = 2 * FRB + 2 * g.xtb + 512 + 1088;
     // two blocks per CU: block width 24 takes 78.5 KB.  (48 channels -- stage 4's first block -- need 107 KB = one block per CU: built,
     // correct, and slower end to end, 10.37 k vs 10.58 k clips/s: not taken.)
     if (g.lds > 80 * 1024 || (POS * g.XS + 63) / 64 > 4 * XE_NE) return XeGeom{};

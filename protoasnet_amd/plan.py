@@ -474,12 +474,49 @@ class PlanBuilder:
                 int(self.lib.pasn_conv3d_pair_se_supported(ctypes.byref(d1), ctypes.byref(d2), self.code, se[1].out_channels))
         else:
             supported = int(self.lib.pasn_conv3d_pair_supported(ctypes.byref(d1), ctypes.byref(d2), self.code))
-        if not supported:
-            self.bufs[y1.buf].nbytes = ALIGN  # never used
-            self.bufs[y2.buf].nbytes = ALIGN
-            return None
-        assert (residual.N, residual.T, residual.H, residual.W, residual.Cp) == (y1.N, y1.T, y1.H, y1.W, y1.Cp)
         frag = lambda wp, rows, kc: wp.view(rows // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+        if not supported:
+            # the 432-channel stage: both weight sets do not fit a wave's registers; x3d_pe.hip streams them per row tile instead (same contract,
+            # bit-identical results).  Its weights are fragment-major with K zero-padded to an EVEN number of 16-wide steps
+            cse = se[1].out_channels if se is not None else 0
+            w1, kc1, rows1 = pack_conv_weight(conv1.weight, round_up(x.Cp, 32), self.dtype)
+            w2, kc2, rows2 = pack_conv_weight(conv2.weight, round_up(y1.Cp, 32), self.dtype)
+            d1.w_kc, d1.w_rows, d2.w_kc, d2.w_rows = kc1, rows1, kc2, rows2
+            d1.w_frag = d2.w_frag = 1
+            pe_ok = in_gate is None and (se is None or (se[0][2].N, se[0][2].positions, se[0][2].Cp) == (x.N, x.positions, x.Cp)) and \
+                (residual.N, residual.T, residual.H, residual.W, residual.Cp) == (y1.N, y1.T, y1.H, y1.W, y1.Cp) and \
+                int(self.lib.pasn_x3d_pe_supported(ctypes.byref(d1), ctypes.byref(d2), self.code, cse))
+            if not pe_ok:
+                self.bufs[y1.buf].nbytes = ALIGN  # never used
+                self.bufs[y2.buf].nbytes = ALIGN
+                return None
+            w1f, w2f = frag(w1, rows1, kc1), frag(w2, rows2, kc2)
+            s1, b1 = fold_norm(norm1, conv1.bias, y1.C, rows1, self.device)
+            s2, b2 = fold_norm(norm2, conv2.bias, y2.C, rows2, self.device)
+            keep = [w1f, w2f, s1, b1, s2, b2]
+            sa = (0, 0, 0, 0)
+            pool_buf, pool_blocks = None, 0
+            if se is not None:
+                (pool_buf, pool_blocks, _), fc1, fc2 = se
+                c = x.C
+                sw = [fc1.weight.detach().float().reshape(cse, c).contiguous(), fc1.bias.detach().float().contiguous(),
+                      fc2.weight.detach().float().reshape(c, cse).contiguous(), fc2.bias.detach().float().contiguous()]
+                keep += sw
+                sa = tuple(t.data_ptr() for t in sw)
+            self.keep += keep
+            a = tuple(t.data_ptr() for t in (w1f, s1, b1, w2f, s2, b2))
+            xb, rb, y1b, y2b = x.buf, residual.buf, y1.buf, y2.buf
+            r1, r2 = ctypes.byref(d1), ctypes.byref(d2)
+            self._use(xb, rb, y1b, y2b, pool_buf)
+            pos, npos = y1.N * y1.positions, x.positions
+            self._note("conv_pair+se" if se is not None else "conv_pair", f"x3d_pe_kernel<{kc1 // 16},{kc2 // 16},{'true' if se is not None else 'false'}>",
+                       (pos * (x.C + 2 * y1.C + y2.C) + y1.C * x.C + y2.C * y1.C) * self.es + ((x.N * pool_blocks * x.C + 2 * x.C * cse) * 4 if se is not None else 0),
+                       2 * pos * (y1.C * x.C + y2.C * y1.C))
+            fpe, code = self.lib.pasn_x3d_pe_fwd, self.code
+            self.ops.append(lambda ptrs, st: _lib.check(fpe(ptrs[xb], a[0], a[1], a[2], ptrs[rb], ptrs[pool_buf] if pool_buf is not None else 0, pool_blocks, npos,
+                                                            sa[0], sa[1], sa[2], sa[3], cse, ptrs[y1b], r1, a[3], a[4], a[5], ptrs[y2b], r2, code, st)))
+            return y1, y2
+        assert (residual.N, residual.T, residual.H, residual.W, residual.Cp) == (y1.N, y1.T, y1.H, y1.W, y1.Cp)
         w1f, w2f = frag(w1, rows1, kc1), frag(w2, rows2, kc2)
         d1.w_frag = d2.w_frag = 1
         s1, b1 = fold_norm(norm1, conv1.bias, y1.C, rows1, self.device)

@@ -664,6 +664,85 @@ def test_project_conv_with_se_gate_in_its_prologue(c, cout, cse, n, thw, stride,
     assert_close(_from_cl(out, cout), _from_cl(two, cout), 1.6e-2 * scale, 1e-2, "prologue gate vs stand-alone gate launch")  # one bf16 ulp of the output
 
 
+@pytest.mark.parametrize("se", [False, True])
+@pytest.mark.parametrize("n,thw", [(32, (4, 7, 7)), (3, (5, 7, 7)), (5, (2, 6, 5))])
+def test_streamed_project_expand_pair_432(n, thw, se, monkeypatch):
+    """pasn_x3d_pe_fwd (x3d_pe.hip): the 432 -> 192 -> 432 project + expand pair of X3D's last stage in ONE launch, weights streamed per row tile,
+    with the block's squeeze-excite gate computed in the launch's prologue (se) -- against torch, and BIT-IDENTICAL to the launches it replaces
+    (gate prologue + project conv on the weight-stationary kernel, expand conv on its own).  Shapes: tiles of 98 rows that never straddle a clip
+    (the benchmark's layout, 32 clips), tiles that straddle clips (two gate rows per tile), a ragged last tile."""
+    dtype = torch.bfloat16
+    c, c1, c2, cse = 432, 192, 432, 32
+    torch.manual_seed(n + thw[0] + se)
+    x = torch.randn(n, c, *thw)
+    res = torch.randn(n, c1, *thw)
+    conv_b = nn.Conv3d(c, c, 3, 1, 1, groups=c, bias=False)
+    conv_c, conv_a = nn.Conv3d(c, c1, 1, bias=False), nn.Conv3d(c1, c2, 1, bias=False)
+    bn_b, bn_c, bn_a = nn.BatchNorm3d(c), nn.BatchNorm3d(c1), nn.BatchNorm3d(c2)
+    fc1, fc2 = nn.Conv3d(c, cse, 1), nn.Conv3d(cse, c, 1)
+    with torch.no_grad():
+        conv_c.weight.normal_(0, 0.08)
+        conv_a.weight.normal_(0, 0.1)
+        for b in (bn_b, bn_c, bn_a):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+            b.running_mean.normal_(0, 0.3)
+            b.running_var.uniform_(0.5, 1.5)
+    for b in (bn_b, bn_c, bn_a):
+        b.eval()
+    conv_br = nn.Conv3d(c, c, 3, 1, 1, groups=c, bias=False)
+    conv_br.weight.data = _rt(conv_b.weight.data, dtype)
+    yb = bn_b(conv_br(_rt(x, dtype))).detach()
+    if se:
+        gate = torch.sigmoid(fc2(F.relu(fc1(yb.mean(dim=(2, 3, 4), keepdim=True))))).detach()
+        zin = _rt(yb, dtype) * gate
+        zin = _rt(zin * torch.sigmoid(zin), dtype)
+    else:
+        zin = _rt(yb * torch.sigmoid(yb), dtype)
+    y1 = F.relu(bn_c(F.conv3d(zin, _rt(conv_c.weight.data, dtype))) + _rt(res, dtype)).detach()
+    y2 = F.relu(bn_a(F.conv3d(_rt(y1, dtype), _rt(conv_a.weight.data, dtype)))).detach()
+    mods = [m_.to(DEV) for m_ in (conv_b, bn_b, conv_c, bn_c, conv_a, bn_a, fc1, fc2)]
+
+    def run(streamed: bool):
+        with _lib_env(PASN_NO_PE=None if streamed else "1"):
+            pb = _pb(dtype)
+            xa, xs = _cl_input(pb, x, dtype)
+            ra, rs = _cl_input(pb, res, dtype)
+            if se:
+                y, pooled = pb.dwconv(xa, mods[0], mods[1], act="none", pool=True)
+                pair = pb.conv_pair(y, mods[2], mods[3], "relu", ra, mods[4], mods[5], "relu", in_swish=True, se=(pooled, mods[6], mods[7]))
+            else:
+                y = pb.dwconv(xa, mods[0], mods[1], act="swish")
+                pair = pb.conv_pair(y, mods[2], mods[3], "relu", ra, mods[4], mods[5], "relu")
+            if streamed:
+                assert pair is not None and pb.meta[-1]["kernel"].startswith("x3d_pe_kernel"), "the streamed pair must cover this geometry"
+                o1, o2 = pair
+            else:
+                assert pair is None, "without the streamed kernel nothing chains this width"
+                o1 = pb.conv_se(y, mods[2], mods[3], "relu", ra, pooled, mods[6], mods[7]) if se else pb.conv(y, mods[2], mods[3], "relu", residual=ra)
+                assert o1 is not None
+                o2 = pb.conv(o1, mods[4], mods[5], "relu")
+            pb.bufs[o1.buf].external = True
+            plan = pb.finish(xa, o2)
+            out1 = torch.empty(n, *thw, o1.Cp, dtype=dtype, device=DEV)
+            plan.ptrs[o1.buf] = out1.data_ptr()
+            plan.ptrs[ra.buf] = rs.data_ptr()
+            out2 = plan.run(xs).clone()
+            torch.cuda.synchronize()
+            return out1, out2, len(plan.ops)
+
+    f1, f2, nf = run(True)
+    scale1, scale2 = max(1.0, float(y1.abs().max())), max(1.0, float(y2.abs().max()))
+    assert_close(_from_cl(f1, c1), y1, 4e-2 * scale1, 3e-2, "streamed pair: block output")
+    assert_close(_from_cl(f2, c2), y2, 4e-2 * scale2, 3e-2, "streamed pair: expand output")
+    u1, u2, nu = run(False)
+    assert (nf, nu) == (2, 3)
+    assert torch.equal(f1, u1), "block output must be bit-identical to the separate launches"
+    assert torch.equal(f2, u2), "expanded activation must be bit-identical to the separate launches"
+    g1, g2, _ = run(True)
+    assert torch.equal(f1, g1) and torch.equal(f2, g2), "bitwise reproducible"
+
+
 @pytest.mark.parametrize("n,thw", [(3, (4, 9, 9)), (2, (3, 14, 14))])
 def test_chained_pair_with_se_gate_in_its_prologue(n, thw, monkeypatch):
     """X3D stage-4 SE block followed by a block without shortcut: stencil (+ pool partial rows) -> ONE launch that computes the gate from
