@@ -174,6 +174,8 @@ def test_plan_shapes_and_arena(cfg, shape):
     # project conv of block i + expand conv of block i+1 chained in one launch (bf16): the 10 pairs of stage 4
     # (+ the 4 of stage 3 with PASN_XPAIR_ALL=1)
     paired = 0 if os.environ.get("PASN_NO_XPAIR") == "1" or fused else (14 if os.environ.get("PASN_XPAIR_ALL") == "1" else 10)
+    # round 4: the 6 project + expand pairs of the 432-channel stage in one launch each (x3d_pe.hip: weights streamed per row tile)
+    paired += 0 if os.environ.get("PASN_NO_PE") == "1" else 6
     max_c = int(os.environ.get("PASN_SE_FUSE_MAXC", "128"))
     mfma = os.environ.get("PASN_DWMFMA", "1") != "0" and "PASN_DWMFMA_MAXW" not in os.environ
     mfma_s2 = False
