@@ -172,7 +172,7 @@ struct PeGeom {
     int ok, KSC, KSA, CTC, CTA;                               // (even) k-steps and 32-channel output tiles of the two convs
     int R, RTn, DPL, XPL;                                     // rows per tile, 32-row tiles, 16-byte slots per row of the two images
     int xt_off, gate_off, tab_off, cst_off, lds_bytes;        // LDS layout
-    int tiles, tpb, grid, se;
+    int tiles, tpb, grid, se, stamps;
 };
 PeGeom pe_geom(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, bool se, int cse);
 // pwconv_tiny.hip: fp32 / bf16 pointwise conv on few positions (the image heads): one wave per 32 x 32 output tile, operands straight from global

@@ -90,6 +90,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_EXPDW_ABL",        "dev",   "fused expand + stencil timing ablations (bit mask)"},
     {"PASN_HALO_ABL",         "dev",   "halo implicit GEMM timing ablations"},
     {"PASN_WS_ABL",           "dev",   "weight-stationary conv timing ablations (needs -DPASN_WS_ABLATE too)"},
+    {"PASN_PE_STAMPS",        "dev",   "streamed project + expand pair: in-kernel phase stamps (tools/pe_bench.py)"},
     {"PASN_BLOCK_ABL",        "dev",   "fused residual block timing ablations (bit mask)"},
     {"PASN_DW_WT",            "dev",   "strip stencil: outputs per thread (4, 7, 8)"},
     {"PASN_HALO_SP",          "dev",   "halo implicit GEMM: slice pipeline on / off"},

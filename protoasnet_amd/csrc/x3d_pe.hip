@@ -34,6 +34,15 @@ struct PeArgs {
     int M, S, Cmp, Cop, Cnp;
 };
 
+#ifdef PASN_TUNING
+// 100 MHz stamps of block 0 / thread 0 (tuning builds, PASN_PE_STAMPS=1; tools/pe_bench.py prints them): start, tables written, rows landed (+ gate),
+// transformed, project done, expand done
+__device__ long long pe_stamps[8];
+#define PE_STAMP(i) do { if (g.se >= 0 && g.stamps && blockIdx.x == 0 && threadIdx.x == 0) pe_stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PE_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void pe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The squeeze-excite gate rows of clips n0 .. n0 + ncl - 1 into G ([2][GP] floats in LDS): pwconv_ws.hip's prologue, thread for thread (same
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(512) void x3d_pe_kernel(PeArgs a, PeGeom g) {
     float* const scp = cst, *const bcp = scp + 32 * g.CTC, *const sap = bcp + 32 * g.CTC, *const bap = sap + 32 * g.CTA;
     const int Cmp = a.Cmp, Cop = a.Cop, M = a.M, S = a.S, R = g.R, RTn = g.RTn, DPL = g.DPL, XPL = g.XPL;
 
+    PE_STAMP(0);
     // No clearing pass: the DMA zero-fills every pad slot of the rows image, the gate rows and tables are written in full, rows beyond the tile
     // only ever feed output rows that are never stored.  One exception: the 64-byte gap behind the image's last row, which that row's last
     // (zero-weight) k-step reads -- it must be finite.
@@ -155,6 +165,7 @@ __global__ __launch_bounds__(512) void x3d_pe_kernel(PeArgs a, PeGeom g) {
     const int tile_end = min(g.tiles, (lbl + 1) * g.tpb);
     int gate_clip = -1;  // the clip whose gate sits in G[0] (G[1]: the next clip's)
     __syncthreads();
+    PE_STAMP(1);
 
 #pragma unroll 1
     for (int tile = lbl * g.tpb; tile < tile_end; ++tile) {
@@ -177,6 +188,7 @@ __global__ __launch_bounds__(512) void x3d_pe_kernel(PeArgs a, PeGeom g) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the rows have landed, the gate rows and the row table are written
+        PE_STAMP(2);
         if (SE) {
             // x' = swish(x * gate[clip][k]) IN PLACE, each element once, rounded back to bf16 (pwconv_ws.hip's input transform)
             const int r0 = (int)(m0 - (unsigned)n0 * (unsigned)S);
@@ -198,10 +210,15 @@ __global__ __launch_bounds__(512) void x3d_pe_kernel(PeArgs a, PeGeom g) {
             }
             __syncthreads();
         }
+        PE_STAMP(3);
+        // (Requesting the project conv's first weight burst BEFORE this wait and the transform pass was tried -- a `pre` hook in xb_pointwise --
+        // and changed nothing: 9.9 us for the phase either way.  It is bound by its 6 units on 4 SIMDs and their epilogues, not by the burst.)
         xb_pointwise<KSC, MT, true, true>(a.w_c, scp, bcp, img, DPL, g.CTC, RTn, rowtab, rrsrc, yrsrc, Cop, xt, XPL, wave, lane);
         __syncthreads();  // the block-output tile is complete in xt
+        PE_STAMP(4);
         xb_pointwise<KSA, MT, false, false>(a.w_a, sap, bap, xt, XPL, g.CTA, RTn, rowtab, ersrc, ersrc, a.Cnp, nullptr, 0, wave, lane);
         __syncthreads();  // nobody reads the images / the row table any more
+        PE_STAMP(5);
     }
 }
 
@@ -255,6 +272,7 @@ PeGeom pe_geom(const pasn_conv_desc& d1, const pasn_conv_desc& d2, int dtype, bo
     g.tpb = ceil_div(g.tiles, grid);
     g.grid = ceil_div(g.tiles, g.tpb);
     g.se = se ? 1 : 0;
+    g.stamps = tune_dev("PASN_PE_STAMPS") ? 1 : 0;
     g.ok = 1;
     return g;
 }
@@ -288,6 +306,10 @@ int launch_x3d_pe(const void* x, const void* w1, const float* s1, const float* b
 }  // namespace pasn
 
 using namespace pasn;
+
+#ifdef PASN_TUNING
+extern "C" int pasn_debug_pe_stamps(long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pasn::pe_stamps), sizeof(long long) * 8); }
+#endif
 
 static bool pe_desc_ok(const pasn_conv_desc* d) { return d && d->N > 0 && d->To > 0 && d->Ho > 0 && d->Wo > 0 && d->Cin > 0 && d->Cout > 0; }
 
