@@ -33,6 +33,8 @@
 // fp32.  A zero weight times a non-finite activation of ANOTHER channel of the tile would leak (0 x inf); the trunk's activations are
 // finite.  Work split: block = 4 waves = the 4 channel tiles of a quad; unit = (T chunk, region); a block walks `upb` units; SE partial
 // sums: one row per (clip, chunk), every channel written by exactly one wave, fixed summation order.
+#include <type_traits>
+
 #include "common.h"
 
 namespace pasn {
@@ -240,42 +242,59 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         for (int l = 0; l < NT; ++l) S0[l] = S1[l] = S2[l] = zero4;
 
         // one input frame ti from ring slot `slot`: P = output ti-1 (kt = 2), C = output ti (kt = 1), N = output ti+1 (kt = 0)
+        // The MFMA chains of one staged frame.  Only the chains whose OUTPUT frame lies in this T chunk run (round 4): frame ti feeds output
+        // ti - 1 through kt = 2 (set P), ti through kt = 1 (C), ti + 1 through kt = 0 (N); the two halo frames of a chunk need one chain each,
+        // its first and last frame two -- with all three chains on every staged frame a chunk of 8 ran 30 chain-frames for the 24 it needs.
+        // The sets still rotate through the chains' first MFMA; a skipped chain's set is never read before it is restarted from zero.
+        auto chains = [&](int slot, f32x4 (&P)[NT], f32x4 (&C)[NT], f32x4 (&N)[NT], auto dop, auto doc, auto don) {
+            constexpr bool DOP = decltype(dop)::value, DOC = decltype(doc)::value, DON = decltype(don)::value;
+            constexpr int NCH = (DOP ? 1 : 0) + (DOC ? 1 : 0) + (DON ? 1 : 0);
+            // per-frame operand addresses (kept out of the loop-invariant hoisting: three slots x five taps of them otherwise stay live
+            // across the whole march)
+            int fbo = slot * fbytes + lbase0;
+            asm volatile("" : "+v"(fbo));
+            const char* ta[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ta[j] = ring + fbo + tapoff[j];
+            // explicit two-deep operand pipeline: the 5 reads of tile l + 1 are issued before the MFMAs of tile l (left to itself the
+            // scheduler serialises read -> lgkmcnt(0) -> 3 MFMAs, one LDS round trip per tap pair: ~2500 cycles per frame)
+            bf16x8 Bq[2][5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+            for (int l = 0; l < NT; ++l) {
+                if (l + 1 < NT) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) Bq[(l + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ta[j] + (l + 1) * lstep);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const bf16x8 B = Bq[l & 1][j];
+                    // The role rotation rides in the first MFMA of every chain (D and C are different registers there): the new P is
+                    // the old C plus this frame's kt = 2 taps, the new C the old N plus kt = 1, the new N starts from a constant zero.
+                    // No register moves (2 x NT x 4 per frame otherwise).  Order P, C, N: each reads a set before it is overwritten.
+                    if (DOP) P[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, j == 0 ? C[l] : P[l], 0, 0, 0);
+                    if (DOC) C[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, j == 0 ? N[l] : C[l], 0, 0, 0);
+                    if (DON) N[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : N[l], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 5 * NCH, 0);
+            }
+        };
+        // one input frame ti from ring slot `slot`: P = output ti-1 (kt = 2), C = output ti (kt = 1), N = output ti+1 (kt = 0)
         auto frame = [&](int ti, int slot, f32x4 (&P)[NT], f32x4 (&C)[NT], f32x4 (&N)[NT]) {
             if (wave_live && ti >= 0 && ti < Ti && !(abl & 1)) {  // wave-uniform
-                // All three kt taps of every staged frame are applied: a set that belongs to an output frame outside this T chunk is
-                // simply never emitted and restarts from zero when it becomes N again (at most 2 of Tc + 2 frames carry such work).
-                // per-frame operand addresses (kept out of the loop-invariant hoisting: three slots x five taps of them otherwise stay live
-                // across the whole march)
-                int fbo = slot * fbytes + lbase0;
-                asm volatile("" : "+v"(fbo));
-                const char* ta[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) ta[j] = ring + fbo + tapoff[j];
-                // explicit two-deep operand pipeline: the 5 reads of tile l + 1 are issued before the 15 MFMAs of tile l (left to itself the
-                // scheduler serialises read -> lgkmcnt(0) -> 3 MFMAs, one LDS round trip per tap pair: ~2500 cycles per frame)
-                bf16x8 Bq[2][5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) Bq[0][j] = *reinterpret_cast<const bf16x8*>(ta[j]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-#pragma unroll
-                for (int l = 0; l < NT; ++l) {
-                    if (l + 1 < NT) {
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) Bq[(l + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ta[j] + (l + 1) * lstep);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const bf16x8 B = Bq[l & 1][j];
-                        // The role rotation rides in the first MFMA of every chain (D and C are different registers there): the new P is
-                        // the old C plus this frame's kt = 2 taps, the new C the old N plus kt = 1, the new N starts from a constant zero.
-                        // No register moves (2 x NT x 4 per frame otherwise).  Order P, C, N: each reads a set before it is overwritten.
-                        P[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[2][j]), B, j == 0 ? C[l] : P[l], 0, 0, 0);
-                        C[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[1][j]), B, j == 0 ? N[l] : C[l], 0, 0, 0);
-                        N[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[0][j]), B, j == 0 ? zero4 : N[l], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
-                }
+                using T1 = std::true_type;
+                using T0 = std::false_type;
+                const bool np = ti - 1 >= t0 && ti - 1 < t1, nc = ti >= t0 && ti < t1, nn = ti + 1 >= t0 && ti + 1 < t1;
+                // Specialised bodies only for the 4-tile instance (planes <= 8 wide), and there only for the chunk's two halo frames (one chain each):
+                // every extra copy of the 7-tile body costs this compiler 60+ VGPRs (see the note at the step loop below) -- with a copy per
+                // mask the 7-tile instance spilled 56, with three copies 57.
+                const int mask = RPT == 2 ? ((np ? 4 : 0) | (nc ? 2 : 0) | (nn ? 1 : 0)) : 7;  // wave-uniform
+                if (RPT == 2 && mask == 1) chains(slot, P, C, N, T0{}, T0{}, T1{});
+                else if (RPT == 2 && mask == 4) chains(slot, P, C, N, T1{}, T0{}, T0{});
+                else chains(slot, P, C, N, T1{}, T1{}, T1{});
             } else {  // a frame outside the clip (zero padding in T), or an idle wave: only the roles move on
 #pragma unroll
                 for (int l = 0; l < NT; ++l) {
@@ -468,8 +487,13 @@ int launch_dw_mfma(const void* x, const float* w, const float* scale, const floa
     }
 #define PASN_DWF(RPT_, ABL_, ACT_) \
     hipLaunchKernelGGL((dwconv3d_mfma_kernel<RPT_, ABL_, ACT_>), grid, block, lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g, (const float*)nullptr)
-    if (g.abl) PASN_DWF(1, true, -1);
-    else if (g.RPT == 2) {
+#ifdef PASN_TUNING
+    if (g.abl) {  // timing-ablation instance: -DPASN_TUNING builds only, never in the product library
+        PASN_DWF(1, true, -1);
+        return check_launch("dwconv3d_mfma_kernel (ablation)");
+    }
+#endif
+    if (g.RPT == 2) {
         if (d.act == PASN_ACT_NONE) PASN_DWF(2, false, PASN_ACT_NONE);
         else if (d.act == PASN_ACT_SWISH) PASN_DWF(2, false, PASN_ACT_SWISH);
         else PASN_DWF(2, false, -1);
