@@ -1,11 +1,14 @@
 # pwconv_ws kernel time per step under its timing ablations (PASN_WS_ABL bits: 1 MFMAs, 2 output stores, 4 x DMA, 8 input transform, 16 residual DMA, 32 all DMA)
 #   bash tools/ws_abl.sh 0 1 2 3 8 16     (0 = the product path; results are wrong when a bit is set)
-# NEEDS a library built with -DPASN_WS_ABLATE (the product kernel compiles the flag tests out: they cost 0.5 % of the step, log entry 96)
+# Runs on the tuning build (protoasnet_amd.build_extension(variant="tuning"): -DPASN_TUNING -DPASN_WS_ABLATE; the product kernel compiles the flag
+# tests out: they cost 0.5 % of the step, log entry 96) and WITHOUT the hipGraph replay: every kernel then runs exactly warm-up + steps = 13 times,
+# which is the divisor below (with the graph-enabled bench each kernel ran 17 times and the reported us/step were 31 % high: ADVICE round 3).
 R=$GRAFT_REPO_ROOT
+export PASN_LIB_PATH=$R/protoasnet_amd/lib/libprotoasnet_amd_tuning.so
 cd /tmp && export TMPDIR=/tmp
 for A in "$@"; do
   if [ "$A" != "0" ]; then export PASN_WS_ABL=$A; else unset PASN_WS_ABL; fi
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ws -o p -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-clips 0 --no-secondary --no-roofline > $R/gpurun_out/prof_ws.log 2>&1 || true
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ws -o p -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-clips 0 --no-secondary --no-roofline --no-graph > $R/gpurun_out/prof_ws.log 2>&1 || true
   f=$(find $R/gpurun_out/prof_ws -name "*kernel_stats.csv" | head -1)
   echo "abl=$A $(python3 -c "
 import csv
