@@ -643,9 +643,44 @@ def secondary(dev) -> dict:
             return loss
 
         sec = timed(step, 2, 4)
-        return {"workload": "BASELINE config 3, per-GPU work: one training step (forward + the reference's loss recipe incl. the transform term's "
+        line = {"workload": "BASELINE config 3, per-GPU work: one training step (forward + the reference's loss recipe incl. the transform term's "
                             "second trunk pass + backward + Adam), X3D-S + prototype layer, 32x16x224x224", "value": round(32 / sec, 1),
                 "unit": "clips/s", "ms_per_step": round(sec * 1e3, 2)}
+        # roofline of the C-ABI entry point that takes the most device time: one more step with every launch of the first-pass plan bracketed by
+        # HIP events on the launch stream (tools/train_bench.py's accounting: bytes = the buffers a launch touches, each once)
+        runner = next(r for r in m._train_runners.values() if r.mode == 0)
+        plan, evs = runner.plan, []
+        orig = list(plan.ops)
+
+        def wrap(i, op):
+            def run(ptrs, st):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                op(ptrs, st)
+                b.record()
+                evs.append((i, a, b))
+            return run
+
+        plan.ops[:] = [wrap(i, op) for i, op in enumerate(orig)]
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            plan.ops[:] = orig
+        agg = {}
+        for i, a, b in evs:
+            k = ("fwd " if i < plan.n_fwd else "bwd ") + plan.op_names[i]
+            e = agg.setdefault(k, [0.0, 0, 0])
+            e[0] += a.elapsed_time(b)
+            e[1] += 1
+            e[2] += plan.op_bytes[i]
+        top, (ms, n, nb) = max(agg.items(), key=lambda kv: kv[1][0])
+        line["roofline"] = {"kernel": top, "bound": "hbm", "achieved": round(nb / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                            "algorithmic_bytes_per_launch": int(nb / n), "share_of_pass": round(ms / sum(v[0] for v in agg.values()), 3),
+                            "note": "first trunk pass of the step (launch list of forward(): forward + backward); bytes = buffers touched, each once"}
+        line["device_ms_by_entry_point"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}
+        return line
 
     guarded("r2plus1d_18_forward", r2p1d)
     guarded("config1_image_forward", cfg1)

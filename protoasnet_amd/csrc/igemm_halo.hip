@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const __bf16* __rest
                                                             int rows16, int scb_off) {
     constexpr int BN = NT * 32, BM = 128 * MT, BT = 4 * MT;
     constexpr bool PIPE = PASN_HALO_PIPE;
+    // (Round 4, tried and removed: a start-up delay for the first dispatch round's second-slot blocks, so that one block's epilogue -- 43 of the
+    // 64 -> 144 layer's ~185 event-timed us by the ablation builds, the main loop ~107 -- would run under its CU partner's MFMAs: +-0 at 3-14 us of
+    // delay, slower beyond; profiles/README.md entry 117.)
     constexpr int WBYTES = BN * 64, WGROUPS = BN / 16;
     constexpr int OROW = BN + 8;  // epilogue image row (elements)
     extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][rows16 * 64] halo tiles, [3][WBYTES] weight tiles; the epilogue aliases
@@ -365,6 +368,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
                            bias, (const __bf16*)res, (__bf16*)y, d, r16, (int)scb_off);                                               \
         return check_launch("igemm_halo_kernel");                                                                                 \
     }
+#ifdef PASN_TUNING  // (seven more instances of the 160-channel kernel: -DPASN_TUNING builds only, never in the product library)
     if (const char* e = tune_dev("PASN_HALO_ABL")) {  // timing-only builds of the 160-channel spatial instance
         const int abl = atoi(e);
 #define PASN_IHA(A_)                                                                                                              \
@@ -377,6 +381,7 @@ int launch_igemm_halo(const void* x, const void* w, const float* scale, const fl
         PASN_IHA(1) PASN_IHA(2) PASN_IHA(4) PASN_IHA(8) PASN_IHA(3) PASN_IHA(15) PASN_IHA(16)
 #undef PASN_IHA
     }
+#endif
 #define PASN_IHS(NT_, MT_)                                                                                                        \
     if (sp && nt == NT_ && mt == MT_) {                                                                                           \
         if (lds > 64 * 1024) PASN_MAX_LDS(96 * 1024, igemm_halo_kernel<NT_, MT_, 1, 0, true>);                                    \
