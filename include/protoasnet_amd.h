@@ -304,6 +304,24 @@ int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, cons
                        void* stream);
 
 /*
+ * A WHOLE X3D residual block without squeeze-excite on 7 x 7 planes (the last stage: block width 192, inner width 432) in ONE launch (bf16):
+ * conv_a (1x1x1) + norm_a + ReLU -> conv_b (depthwise 3x3x3, pad 1) + norm_b + Swish -> conv_c (1x1x1) + norm_c + x + ReLU, optionally followed by
+ * the NEXT block's conv_a + norm_a + ReLU (pytorchvideo's ResBlock / BottleneckTransform as the x3d trunks instantiate them).  Replaces
+ * pasn_conv3d_fwd + pasn_dwconv3d_fwd + pasn_conv3d_fwd (/ pasn_x3d_pe_fwd): the expanded activation and the stencil's output exist only as LDS
+ * images of a (clip, two frames) tile; results are bit-identical to those launches.
+ *   x        : block input = residual, channels-last [N][T][7][7][d_a->Cin_p];   y : block output, same shape
+ *   w_a, w_c : fragment-major (w_frag = 1); d_a->w_kc = Cin_p, d_c->w_kc = 32 * ceil(Cin_p / 32) (K zero-padded to an even number of steps)
+ *   w_dw     : conv_b as the stencil's matrix-core operands (the table pasn_x3d_block_fwd takes); scale / bias: the folded norms
+ *   w_n ...  : the next block's conv_a in w_a's form and its output e_next [N][T][7][7][d_n->Cout_p]; all NULL (with d_n == NULL): none
+ * _supported() == 0: issue the separate launches.
+ */
+int pasn_x3d_edp_supported(const pasn_conv_desc* d_a, const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_n, int dtype);
+int pasn_x3d_edp_fwd(const void* x, const void* w_a, const float* scale_a, const float* bias_a, const void* w_dw, const float* scale_dw,
+                     const float* bias_dw, const void* w_c, const float* scale_c, const float* bias_c, void* y, const void* w_n,
+                     const float* scale_n, const float* bias_n, void* e_next, const pasn_conv_desc* d_a, const pasn_conv_desc* d_dw,
+                     const pasn_conv_desc* d_c, const pasn_conv_desc* d_n, int dtype, void* stream);
+
+/*
  * An X3D block's conv_c (1x1x1) + norm_c + residual + ReLU chained with the NEXT block's conv_a (1x1x1) + norm_a + ReLU in ONE launch for the
  * 432-channel stage (bf16; inner width 432 -> block width 192 -> 432), with the block's squeeze-excite gate -- when it has one -- computed in the
  * launch's prologue from the stencil's pool partial rows: same contract and results (bit-identical) as pasn_conv3d_pair_se_fwd /

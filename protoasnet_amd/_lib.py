@@ -60,6 +60,8 @@ SIGNATURES = {
     "pasn_conv3d_se_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_conv3d_short_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int]),
     "pasn_conv3d_short_fwd": (c_int, [c_void_p] * 9 + [POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_void_p]),
+    "pasn_x3d_edp_supported": (c_int, [POINTER(ConvDesc)] * 4 + [c_int]),
+    "pasn_x3d_edp_fwd": (c_int, [c_void_p] * 15 + [POINTER(ConvDesc)] * 4 + [c_int, c_void_p]),
     "pasn_x3d_pe_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_int]),
     "pasn_x3d_pe_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, POINTER(ConvDesc)] + [c_void_p] * 4
                         + [POINTER(ConvDesc), c_int, c_void_p]),

@@ -317,8 +317,22 @@ class X3DFeatures(_plan.HipTrunk):
         for stage in self.stages:
             blocks = list(stage)
             pre = None  # this block's expand-conv output when the previous block's chained launch already made it
+            edp = [False] * len(blocks)  # blocks that run as ONE launch (expand -> stencil -> project [-> next expand]): 7 x 7 planes, no squeeze-excite
             for i, blk in enumerate(blocks):
                 sc = x
+                if i == 0:  # (behind the stage's first block the shape is fixed: decide for the whole stage before any pairing)
+                    sb = _plan._triple(blk.conv_b.stride, 1)
+                    co = blk.conv_c.out_channels
+                    xs = _plan.Act(x.N, x.T, (x.H - 1) // sb[1] + 1, (x.W - 1) // sb[2] + 1, co, _plan.round_up(co, 8), -1)
+                    edp = [j >= 1 and b.se is None and b.shortcut is None and bool(pb.x3d_edp(xs, b.conv_a, b.bn_a, b.conv_b, b.bn_b, b.conv_c, b.bn_c, probe=True))
+                           for j, b in enumerate(blocks)]
+                if edp[i] and pre is None:
+                    nb_ = blocks[i + 1] if i + 1 < len(blocks) else None
+                    chain = nb_ is not None and nb_.shortcut is None and not edp[i + 1]
+                    whole = pb.x3d_edp(x, blk.conv_a, blk.bn_a, blk.conv_b, blk.bn_b, blk.conv_c, blk.bn_c, nb_.conv_a if chain else None, nb_.bn_a if chain else None)
+                    if whole is not None:
+                        x, pre = whole
+                        continue
                 fuse_short = blk.shortcut is not None and pb.short_fusable(x, blk)  # the strided shortcut conv rides in the project conv's launch
                 if blk.shortcut is not None and not fuse_short:
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
@@ -358,7 +372,7 @@ class X3DFeatures(_plan.HipTrunk):
                     if fuse_short:  # (not combined with the fused shortcut: different kernels)
                         sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
                         fuse_short = False
-                    if nxt is not None and nxt.shortcut is None:  # ... chained with the next block's expand conv where that is covered
+                    if nxt is not None and nxt.shortcut is None and not edp[i + 1]:  # ... chained with the next block's expand conv where that is covered (a whole-block launch makes its own)
                         pair = pb.conv_pair(y, blk.conv_c, blk.bn_c, "relu", sc, nxt.conv_a, nxt.bn_a, "relu", in_swish=True,
                                             se=(gate[1], blk.se.fc1, blk.se.fc2))
                         if pair is not None:
@@ -377,7 +391,7 @@ class X3DFeatures(_plan.HipTrunk):
                     else:
                         x, pre = fused, None
                         continue
-                if nxt is not None and nxt.shortcut is None:
+                if nxt is not None and nxt.shortcut is None and not edp[i + 1]:
                     pair = pb.conv_pair(y, blk.conv_c, blk.bn_c, "relu", sc, nxt.conv_a, nxt.bn_a, "relu",
                                         in_gate=gate, in_swish=blk.se is not None)
                 if pair is not None:

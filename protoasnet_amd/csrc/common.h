@@ -166,6 +166,13 @@ struct XbGeom {
     int tiles, tpb, grid, abl;          // work split; timing ablations (PASN_BLOCK_ABL, -DPASN_TUNING builds only)
 };
 XbGeom xb_geom(const pasn_conv_desc& d_dw, const pasn_conv_desc& d_c, const pasn_conv_desc* d_a, int dtype);
+// x3d_edp.hip: a whole X3D block of the 7 x 7 stage (expand -> stencil -> project [-> next expand]) in one launch, both wide tensors in LDS; ok = 0: not covered
+struct EdpGeom {
+    int ok, KSA, KSC, CTA, CTC, CTN, NQ;                       // k-steps / 32-channel tiles of the expand, project and next expand convs; quads of the inner width
+    int fimg_off, dch_off, tab_off, cst_off, lds_bytes;       // LDS layout: [x image] [frame images | block-output image] [stencil-output chunk] [row table] [tables]
+    int tiles, tpb, grid, stamps;
+};
+EdpGeom edp_geom(const pasn_conv_desc& da, const pasn_conv_desc& dd, const pasn_conv_desc& dc, const pasn_conv_desc* dn, int dtype);
 // x3d_pe.hip: project conv (+ squeeze-excite gate in the prologue) chained with the next block's expand conv for the 432-channel X3D stage,
 // weights streamed per tile (nothing stationary); ok = 0: not covered
 struct PeGeom {

@@ -45,6 +45,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_NO_HALO",          "route", "no halo-tile implicit GEMM (igemm_halo.hip)"},
     {"PASN_NO_IGEMM",         "route", "no direct-to-LDS implicit GEMM (igemm.hip)"},
     {"PASN_NO_PACK",          "route", "1: training weights packed by torch ops instead of the one-launch pack kernel (host side, train.py)"},
+    {"PASN_NO_EDP",           "route", "1: no whole-block launch for the 7 x 7 stage (x3d_edp.hip)"},
     {"PASN_NO_PE",            "route", "1: no streamed project + expand pair launch for the 432-channel stage (x3d_pe.hip)"},
     {"PASN_NO_PWCONV",        "route", "no register-resident persistent pointwise conv (pwconv.hip)"},
     {"PASN_NO_PWTINY",        "route", "no one-wave-per-tile pointwise conv for small maps (pwconv_tiny.hip)"},
@@ -90,6 +91,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_EXPDW_ABL",        "dev",   "fused expand + stencil timing ablations (bit mask)"},
     {"PASN_HALO_ABL",         "dev",   "halo implicit GEMM timing ablations"},
     {"PASN_WS_ABL",           "dev",   "weight-stationary conv timing ablations (needs -DPASN_WS_ABLATE too)"},
+    {"PASN_EDP_STAMPS",       "dev",   "whole-block launch of the 7 x 7 stage: in-kernel phase stamps (tools/edp_bench.py)"},
     {"PASN_PE_STAMPS",        "dev",   "streamed project + expand pair: in-kernel phase stamps (tools/pe_bench.py)"},
     {"PASN_BLOCK_ABL",        "dev",   "fused residual block timing ablations (bit mask)"},
     {"PASN_DW_WT",            "dev",   "strip stencil: outputs per thread (4, 7, 8)"},

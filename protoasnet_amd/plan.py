@@ -656,6 +656,73 @@ class PlanBuilder:
                                                        ptrs[nb] if nb is not None else 0, rd, rc, ra, code, st)))
         return y, en
 
+    def x3d_edp(self, x: Act, conv_a: nn.Module, norm_a, conv_b: nn.Module, norm_b, conv_c: nn.Module, norm_c, conv_n: Optional[nn.Module] = None,
+                norm_n=None, probe: bool = False):
+        """A WHOLE X3D block without squeeze-excite on 7 x 7 planes in ONE launch (``pasn_x3d_edp_fwd``): expand conv + BN + ReLU -> depthwise
+        3x3x3 + BN + Swish -> project conv + BN + x + ReLU (-> ``conv_n``: the next block's expand conv + BN + ReLU).  ``x`` = the block input.
+        Returns (y, e_next or None), or None when the launch does not cover the block.  ``probe``: only say whether it would (True / False)."""
+        one, zero = (1, 1, 1), (0, 0, 0)
+        ok = (not x.planar and self.dtype == torch.bfloat16 and conv_b.groups == conv_b.in_channels == conv_a.out_channels and conv_a.groups == 1
+              and conv_c.groups == 1 and conv_a.in_channels == x.C and conv_c.in_channels == conv_b.in_channels and conv_c.out_channels == x.C
+              and conv_b.bias is None and _triple(conv_b.kernel_size, 1) == (3, 3, 3) and _triple(conv_b.stride, 1) == one
+              and _triple(conv_b.padding, 0) == (1, 1, 1))
+        for cv in (conv_a, conv_c, conv_n):
+            ok = ok and (cv is None or (_triple(cv.kernel_size, 1) == one and _triple(cv.stride, 1) == one and _triple(cv.padding, 0) == zero and cv.groups == 1))
+        if not ok or (conv_n is not None and conv_n.in_channels != conv_c.out_channels):
+            return False if probe else None
+        cm = conv_a.out_channels
+        mid = Act(x.N, x.T, x.H, x.W, cm, round_up(cm, 8), -1)   # expanded activation / stencil output: never materialised
+
+        def desc(src, dst, k, s, p, act, kc, rows):
+            d = ConvDesc(N=src.N, Ti=src.T, Hi=src.H, Wi=src.W, Cin=src.C, Cin_p=src.Cp, To=dst.T, Ho=dst.H, Wo=dst.W, Cout=dst.C, Cout_p=dst.Cp,
+                         kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2], act=_lib.ACT[act], in_swish=0,
+                         w_kc=kc, w_rows=rows, w_frag=1)
+            return d
+
+        rows_a, rows_c = round_up(mid.Cp, 128), round_up(x.Cp, 128)
+        yv = Act(x.N, x.T, x.H, x.W, x.C, x.Cp, -1)
+        da = desc(x, mid, one, one, zero, "relu", round_up(x.Cp, 16), rows_a)
+        dd = desc(mid, mid, (3, 3, 3), one, (1, 1, 1), "swish", 0, 0)
+        dd.w_frag = 0
+        dc = desc(mid, yv, one, one, zero, "relu", round_up(mid.Cp, 32), rows_c)
+        dn = None
+        if conv_n is not None:
+            nv = Act(x.N, x.T, x.H, x.W, conv_n.out_channels, round_up(conv_n.out_channels, 8), -1)
+            dn = desc(yv, nv, one, one, zero, "relu", round_up(x.Cp, 16), round_up(nv.Cp, 128))
+        if not int(self.lib.pasn_x3d_edp_supported(ctypes.byref(da), ctypes.byref(dd), ctypes.byref(dc), ctypes.byref(dn) if dn is not None else None, self.code)):
+            return False if probe else None
+        if probe:
+            return True
+        frag = lambda wp, rows, kc: wp.view(rows // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+        wa, kca, ra = pack_conv_weight(conv_a.weight, x.Cp, self.dtype)
+        wc, kcc, rc = pack_conv_weight(conv_c.weight, round_up(mid.Cp, 32), self.dtype)
+        assert (kca, ra, kcc, rc) == (da.w_kc, da.w_rows, dc.w_kc, dc.w_rows)
+        sa, ba = fold_norm(norm_a, conv_a.bias, cm, ra, self.device)
+        wd = stencil_operands(conv_b.weight.to(self.device), cm, mid.Cp)
+        sd, bd = fold_norm(norm_b, None, cm, mid.Cp, self.device)
+        sc, bc = fold_norm(norm_c, conv_c.bias, x.C, rc, self.device)
+        keep = [frag(wa, ra, kca), sa, ba, wd, sd, bd, frag(wc, rc, kcc), sc, bc]
+        y = self._out_act(mid, conv_c.out_channels, one, one, zero)
+        en = None
+        if conv_n is not None:
+            en = self._out_act(y, conv_n.out_channels, one, one, zero)
+            wn, kcn, rn = pack_conv_weight(conv_n.weight, y.Cp, self.dtype)
+            sn, bn = fold_norm(norm_n, conv_n.bias, en.C, rn, self.device)
+            keep += [frag(wn, rn, kcn), sn, bn]
+        self.keep += keep + [da, dd, dc] + ([dn] if dn is not None else [])
+        a = tuple(t.data_ptr() for t in keep) + ((0, 0, 0) if conv_n is None else ())
+        xb, yb, nb = x.buf, y.buf, (en.buf if en is not None else None)
+        r = (ctypes.byref(da), ctypes.byref(dd), ctypes.byref(dc), ctypes.byref(dn) if dn is not None else None)
+        self._use(xb, yb, nb)
+        pos, cn = y.N * y.positions, (en.C if en is not None else 0)
+        self._note("block" if en is None else "block+expand", f"x3d_edp_kernel<{kca // 16},{kcc // 16},{'true' if en is not None else 'false'}>",
+                   (pos * (2 * x.C + y.C + cn) + cm * x.C + 27 * cm + y.C * cm + cn * y.C) * self.es, 2 * pos * (cm * x.C + 27 * cm + y.C * cm + cn * y.C))
+        self.meta[-1]["shape"] = f"{x.C}->{cm} k111 -> dw k333 -> {cm}->{y.C}" + (f" -> {y.C}->{cn}" if cn else "") + f" k111 in{x.T}x{x.H}x{x.W}"
+        fn, code = self.lib.pasn_x3d_edp_fwd, self.code
+        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[xb], a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], ptrs[yb], a[9], a[10], a[11],
+                                                       ptrs[nb] if nb is not None else 0, r[0], r[1], r[2], r[3], code, st)))
+        return y, en
+
     def expand_dw(self, x: Act, conv_a: nn.Module, norm_a: Optional[nn.Module], conv_b: nn.Module, norm_b: Optional[nn.Module], act_b: str,
                   pool: bool = False):
         """Front half of an X3D block in ONE launch (``pasn_x3d_expdw_fwd``): 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 conv,

@@ -664,6 +664,77 @@ def test_project_conv_with_se_gate_in_its_prologue(c, cout, cse, n, thw, stride,
     assert_close(_from_cl(out, cout), _from_cl(two, cout), 1.6e-2 * scale, 1e-2, "prologue gate vs stand-alone gate launch")  # one bf16 ulp of the output
 
 
+@pytest.mark.parametrize("chain", [True, False])
+@pytest.mark.parametrize("n,t", [(3, 6), (2, 5), (5, 1), (2, 16)])
+def test_x3d_whole_block_one_launch_7x7(n, t, chain, monkeypatch):
+    """pasn_x3d_edp_fwd (x3d_edp.hip): a whole X3D block of the last stage -- expand conv + BN + ReLU -> depthwise 3x3x3 + BN + Swish -> project conv
+    + BN + x + ReLU (-> the next block's expand conv + BN + ReLU) -- in ONE launch with both wide tensors in LDS: against torch with the
+    rounding points of the separate launches, and BIT-IDENTICAL to those launches.  T even / odd (a tile with one output frame), T = 1 (every
+    neighbour frame outside the clip), with and without the chained expand conv."""
+    dtype = torch.bfloat16
+    cx, cm = 192, 432
+    torch.manual_seed(n * 10 + t)
+    x = F.relu(torch.randn(n, cx, t, 7, 7))
+    conv_a, conv_c, conv_n = nn.Conv3d(cx, cm, 1, bias=False), nn.Conv3d(cm, cx, 1, bias=False), nn.Conv3d(cx, cm, 1, bias=False)
+    conv_b = nn.Conv3d(cm, cm, 3, 1, 1, groups=cm, bias=False)
+    bns = [nn.BatchNorm3d(cm), nn.BatchNorm3d(cm), nn.BatchNorm3d(cx), nn.BatchNorm3d(cm)]
+    with torch.no_grad():
+        conv_a.weight.normal_(0, 0.1)
+        conv_b.weight.normal_(0, 0.25)
+        conv_c.weight.normal_(0, 0.08)
+        conv_n.weight.normal_(0, 0.1)
+        for b in bns:
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+            b.running_mean.normal_(0, 0.3)
+            b.running_var.uniform_(0.5, 1.5)
+            b.eval()
+    e = _rt(F.relu(bns[0](F.conv3d(_rt(x, dtype), _rt(conv_a.weight.data, dtype)))), dtype)
+    d = bns[1](F.conv3d(e, _rt(conv_b.weight.data, dtype), padding=1, groups=cm))
+    d = _rt(d * torch.sigmoid(d), dtype)
+    y = _rt(F.relu(bns[2](F.conv3d(d, _rt(conv_c.weight.data, dtype))) + _rt(x, dtype)), dtype).detach()
+    en = F.relu(bns[3](F.conv3d(y, _rt(conv_n.weight.data, dtype)))).detach()
+    mods = [m_.to(DEV) for m_ in (conv_a, bns[0], conv_b, bns[1], conv_c, bns[2], conv_n, bns[3])]
+
+    def run(whole: bool):
+        with _lib_env(PASN_NO_EDP=None if whole else "1"):
+            pb = _pb(dtype)
+            xa, xs = _cl_input(pb, x, dtype)
+            if whole:
+                out = pb.x3d_edp(xa, *mods[:6], mods[6] if chain else None, mods[7] if chain else None)
+                assert out is not None and pb.meta[-1]["kernel"].startswith("x3d_edp_kernel"), "the whole-block launch must cover this geometry"
+                o1, o2 = out
+            else:
+                assert pb.x3d_edp(xa, *mods[:6], probe=True) is False
+                ee = pb.conv(xa, mods[0], mods[1], act="relu")
+                dd = pb.dwconv(ee, mods[2], mods[3], act="swish")
+                o1 = pb.conv(dd, mods[4], mods[5], act="relu", residual=xa)
+                o2 = pb.conv(o1, mods[6], mods[7], act="relu") if chain else None
+            last = o2 if o2 is not None else o1
+            if o2 is not None:
+                pb.bufs[o1.buf].external = True
+            plan = pb.finish(xa, last)
+            out1 = torch.empty(n, t, 7, 7, o1.Cp, dtype=dtype, device=DEV)
+            if o2 is not None:
+                plan.ptrs[o1.buf] = out1.data_ptr()
+            outl = plan.run(xs).clone()
+            torch.cuda.synchronize()
+            return ((out1, outl) if o2 is not None else (outl, None)) + (len(plan.ops),)
+
+    f1, f2, nf = run(True)
+    assert nf == 1
+    assert_close(_from_cl(f1, cx), y, 4e-2 * max(1.0, float(y.abs().max())), 3e-2, "whole block: block output")
+    if chain:
+        assert_close(_from_cl(f2, cm), en, 4e-2 * max(1.0, float(en.abs().max())), 3e-2, "whole block: next expanded activation")
+    u1, u2, nu = run(False)
+    assert nu == (4 if chain else 3)
+    assert torch.equal(f1, u1), "block output must be bit-identical to the separate launches"
+    if chain:
+        assert torch.equal(f2, u2), "expanded activation must be bit-identical to the separate launches"
+    g1, g2, _ = run(True)
+    assert torch.equal(f1, g1) and (not chain or torch.equal(f2, g2)), "bitwise reproducible"
+
+
 @pytest.mark.parametrize("se", [False, True])
 @pytest.mark.parametrize("n,thw", [(32, (4, 7, 7)), (3, (5, 7, 7)), (5, (2, 6, 5))])
 def test_streamed_project_expand_pair_432(n, thw, se, monkeypatch):
