@@ -176,6 +176,9 @@ def test_plan_shapes_and_arena(cfg, shape):
     paired = 0 if os.environ.get("PASN_NO_XPAIR") == "1" or fused else (14 if os.environ.get("PASN_XPAIR_ALL") == "1" else 10)
     # round 4: the 6 project + expand pairs of the 432-channel stage in one launch each (x3d_pe.hip: weights streamed per row tile)
     paired += 0 if os.environ.get("PASN_NO_PE") == "1" else 6
+    # ... and the three blocks without squeeze-excite of that stage as ONE launch each (x3d_edp.hip: the stencil launch disappears; the
+    # pair launch that computed the block's expand conv becomes a single project conv with the gate in its prologue: same count)
+    paired += 0 if os.environ.get("PASN_NO_EDP") == "1" else 3
     max_c = int(os.environ.get("PASN_SE_FUSE_MAXC", "128"))
     mfma = os.environ.get("PASN_DWMFMA", "1") != "0" and "PASN_DWMFMA_MAXW" not in os.environ
     mfma_s2 = False
