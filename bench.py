@@ -662,11 +662,13 @@ def secondary(dev) -> dict:
             return run
 
         plan.ops[:] = [wrap(i, op) for i, op in enumerate(orig)]
+        was_serial, plan.serial = plan.serial, True  # per-launch times: every launch on the bracketed stream (the timed steps above overlap the weight gradients)
         try:
             step()
             torch.cuda.synchronize()
         finally:
             plan.ops[:] = orig
+            plan.serial = was_serial
         agg = {}
         for i, a, b in evs:
             k = ("fwd " if i < plan.n_fwd else "bwd ") + plan.op_names[i]

@@ -11,17 +11,23 @@
 namespace pasn {
 
 struct RowGeom {
-    int CG, CGb, RL, chunks, rows_per_chunk;
+    int CG, LPR, RL, chunks, rows_per_chunk;
 };
 
+// 256 threads = RL row lanes x LPR lanes per row; lane cg of a row owns channels 8 cg .. 8 cg + 7 (lanes cg >= CG and the threads beyond
+// RL * LPR idle).  LPR = the next power of two >= CG.  PASN_TRAIN_ROWS_CONTIG=1: LPR = CG -- a block's live threads read RL whole rows as
+// ONE contiguous span and 240-255 of 256 threads are live at the X3D widths instead of 75-88 %; measured +-0 on the step (the passes are
+// not short of requests in flight), and it re-partitions every sum, so the default keeps the summation order of rounds 1-3.
 static RowGeom row_geom(int N, int S, int Cp) {
     RowGeom g;
     g.CG = Cp / 8;
-    int b = 1;
-    while (b < g.CG) b <<= 1;
-    g.CGb = b;
-    g.RL = 256 / b;
-    const int want = std::max(1, 1024 / std::max(1, N));
+    g.LPR = 1;
+    while (g.LPR < g.CG) g.LPR <<= 1;
+    if (tune_is("PASN_TRAIN_ROWS_CONTIG", '1')) g.LPR = g.CG;
+    g.RL = 256 / g.LPR;
+    int blocks = 1024;
+    if (const char* e = tune("PASN_TRAIN_BLOCKS")) blocks = std::max(256, atoi(e));
+    const int want = std::max(1, blocks / std::max(1, N));
     const int maxc = std::max(1, S / (g.RL * 16));  // small tensors: fewer partials, the finalize pass is pure latency
     g.chunks = std::min(want, maxc);
     g.rows_per_chunk = ceil_div(S, g.chunks);
@@ -29,22 +35,38 @@ static RowGeom row_geom(int N, int S, int Cp) {
     return g;
 }
 
+// Rows in flight per thread: every pass below requests ROWS_U rows of each operand, then computes, then stores.  (A plain loop, even
+// unrolled, waited for each row's loads before the next row's went out wherever the pass writes in place or branches on the activation:
+// two or three 16-byte loads in flight per thread, 2.8-4 TB/s.)
+constexpr int ROWS_U = 4;
+template <typename T>
+struct Raw8 {
+    uint4 r[(8 * sizeof(T)) / 16];
+};
+template <typename T>
+__device__ __forceinline__ Raw8<T> load_raw8(const T* p) {
+    Raw8<T> q;
+#pragma unroll
+    for (int i = 0; i < (int)((8 * sizeof(T)) / 16); ++i) q.r[i] = reinterpret_cast<const uint4*>(p)[i];
+    return q;
+}
+
 // Sum the per-thread 8-channel accumulators `acc[W][8]` over the row lanes of the block (fixed order) and store them
 // at out[w * Cp + cg*8 + j].
 template <int W>
-__device__ __forceinline__ void block_reduce_rows(float (&acc)[W][8], float* red, float* out, int Cp, int CG, int CGb) {
-    const int tid = threadIdx.x, RL = 256 / CGb;
+__device__ __forceinline__ void block_reduce_rows(float (&acc)[W][8], float* red, float* out, int Cp, int CG, int LPR) {
+    const int tid = threadIdx.x, RL = 256 / LPR;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[w][j];
         __syncthreads();
-        for (int t = tid; t < CGb * 8; t += 256) {
+        for (int t = tid; t < LPR * 8; t += 256) {
             const int cg = t >> 3, j = t & 7;
             if (cg < CG) {
                 float s = 0.0f;
-                for (int rl = 0; rl < RL; ++rl) s += red[(rl * CGb + cg) * 8 + j];
+                for (int rl = 0; rl < RL; ++rl) s += red[(rl * LPR + cg) * 8 + j];
                 out[(size_t)w * Cp + cg * 8 + j] = s;
             }
         }
@@ -56,31 +78,37 @@ __device__ __forceinline__ void block_reduce_rows(float (&acc)[W][8], float* red
 // cancellation when |mean| >> std).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ y, float* __restrict__ ws, int S, int Cp,
-                                                               int CG, int CGb, int rows_per_chunk, int chunks) {
+                                                               int CG, int LPR, int rows_per_chunk, int chunks) {
     __shared__ float red[256 * 8];
     const int n = blockIdx.y, ch = blockIdx.x;
-    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
     float acc[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.0f;
-    if (cg < CG) {
+    if (cg < CG && rl < RL) {
         float k[8];
         load8(y + cg * 8, k);
         const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
         const T* base = y + (size_t)n * S * Cp + cg * 8;
-#pragma unroll 4
-        for (int r = r0 + rl; r < r1; r += RL) {
-            float v[8];
-            load8(base + (size_t)r * Cp, v);
+        for (int r = r0 + rl; r < r1; r += ROWS_U * RL) {
+            Raw8<T> yv[ROWS_U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float dlt = v[j] - k[j];
-                acc[0][j] += dlt;
-                acc[1][j] = fmaf(dlt, dlt, acc[1][j]);
+            for (int u = 0; u < ROWS_U; ++u) yv[u] = load_raw8(base + (size_t)min(r + u * RL, r1 - 1) * Cp);
+#pragma unroll
+            for (int u = 0; u < ROWS_U; ++u) {
+                float v[8];
+                raw_to_f8<T>(yv[u].r, v);
+                const bool ok = r + u * RL < r1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dlt = ok ? v[j] - k[j] : 0.0f;
+                    acc[0][j] += dlt;
+                    acc[1][j] = fmaf(dlt, dlt, acc[1][j]);
+                }
             }
         }
     }
-    block_reduce_rows<2>(acc, red, ws + ((size_t)n * chunks + ch) * 2 * Cp, Cp, CG, CGb);
+    block_reduce_rows<2>(acc, red, ws + ((size_t)n * chunks + ch) * 2 * Cp, Cp, CG, LPR);
 }
 
 // One block per 16 channels.  Totals: each of the 16 "parts" sums every 16th partial (independent loads, one LDS combine in a
@@ -159,35 +187,47 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ stat, const T* __restrict__ res,
                                                              const float* __restrict__ gate, T* __restrict__ a, int S, int Cp, int CG,
-                                                             int CGb, int rows_per_chunk, int act) {
+                                                             int LPR, int rows_per_chunk, int act) {
     const int n = blockIdx.y, ch = blockIdx.x;
-    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
-    if (cg >= CG) return;
+    const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
+    if (cg >= CG || rl >= RL) return;
     float sc[8], sh[8], g[8];
     load8(stat + 2 * Cp + cg * 8, sc);
     load8(stat + 3 * Cp + cg * 8, sh);
     if (gate) load8(gate + (size_t)n * Cp + cg * 8, g);
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
     const size_t base = (size_t)n * S * Cp + cg * 8;
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const size_t o = base + (size_t)r * Cp;
-        float v[8];
-        load8(y + o, v);
+    for (int r = r0 + rl; r < r1; r += ROWS_U * RL) {
+        size_t o[ROWS_U];
+        Raw8<T> yv[ROWS_U], qv[ROWS_U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+        for (int u = 0; u < ROWS_U; ++u) {
+            o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;  // past the chunk: the last row again, not stored
+            yv[u] = load_raw8(y + o[u]);
+        }
         if (res) {
-            float q[8];
-            load8(res + o, q);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += q[j];
+            for (int u = 0; u < ROWS_U; ++u) qv[u] = load_raw8(res + o[u]);
         }
-        if (gate) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= g[j];
+        for (int u = 0; u < ROWS_U; ++u) {
+            float v[8];
+            raw_to_f8<T>(yv[u].r, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+            if (res) {
+                float q[8];
+                raw_to_f8<T>(qv[u].r, q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += q[j];
+            }
+            if (gate) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= g[j];
+            }
+            act_vec(v, act);
+            if (r + u * RL < r1) store8(a + o[u], v);
         }
-        act_vec(v, act);
-        store8(a + o, v);
     }
 }
 
@@ -198,18 +238,19 @@ __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const T* __restrict
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
                                                         const T* __restrict__ res, const float* __restrict__ gate, const float* __restrict__ add,
-                                                        float* __restrict__ ws, int S, int Cp, int CG, int CGb, int rows_per_chunk,
+                                                        float* __restrict__ ws, int S, int Cp, int CG, int LPR, int rows_per_chunk,
                                                         int chunks, int act, int write_back) {
     __shared__ float red[256 * 8];
     const int n = blockIdx.y, ch = blockIdx.x;
-    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
+    const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
     constexpr int W = MODE == 4 ? 3 : 2;
+    constexpr int U = ROWS_U;
     float acc[W][8];
 #pragma unroll
     for (int w = 0; w < W; ++w)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[w][j] = 0.0f;
-    if (cg < CG) {
+    if (cg < CG && rl < RL) {
         float mean[8], invstd[8], sc[8], sh[8], g[8], ad[8];
         load8(stat + cg * 8, mean);
         load8(stat + Cp + cg * 8, invstd);
@@ -224,63 +265,79 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
         if (add) load8(add + (size_t)n * Cp + cg * 8, ad);
         const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
         const size_t base = (size_t)n * S * Cp + cg * 8;
-#pragma unroll 2
-        for (int r = r0 + rl; r < r1; r += RL) {
-            const size_t o = base + (size_t)r * Cp;
-            float v[8], dv[8];
-            load8(y + o, v);
-            load8(d + o, dv);
-            if (MODE == 0) {
-                float u[8];
+        for (int r = r0 + rl; r < r1; r += U * RL) {
+            size_t o[U];
+            Raw8<T> yv[U], dr[U], qv[U];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) u[j] = fmaf(v[j], sc[j], sh[j]);
-                if (res) {
-                    float q[8];
-                    load8(res + o, q);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) u[j] += q[j];
-                }
-                act_grad_mul(dv, u, act);
-            } else if (MODE == 1) {
-                float u[8], ug[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    u[j] = fmaf(v[j], sc[j], sh[j]);
-                    ug[j] = u[j] * g[j];
-                }
-                act_grad_mul(dv, ug, act);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[0][j] = fmaf(dv[j], u[j], acc[0][j]);
-            } else if (MODE == 4) {
-                // as mode 1, but the sums the squeeze-excite unit's norm needs are taken here, per clip: (sum d', sum d' yhat, sum yhat).
-                // d'' = d' gate + add[n] is affine in d' per clip, so sum d'' and sum d'' yhat follow without a second pass over (d, y)
-                // (pasn_se_gate_bwd_stat), and sum d' u = gamma sum d' yhat + beta sum d' (the gate's gradient) as well
-                float ug[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ug[j] = fmaf(v[j], sc[j], sh[j]) * g[j];
-                act_grad_mul(dv, ug, act);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float yh = (v[j] - mean[j]) * invstd[j];
-                    acc[0][j] += dv[j];
-                    acc[1][j] = fmaf(dv[j], yh, acc[1][j]);
-                    acc[W - 1][j] += yh;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dv[j] = fmaf(dv[j], g[j], ad[j]);
+            for (int u = 0; u < U; ++u) {
+                o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;  // past the chunk: the last row again, masked out of sums and stores
+                yv[u] = load_raw8(y + o[u]);
+                dr[u] = load_raw8(d + o[u]);
             }
-            if (MODE != 1 && MODE != 4) {
+            if (MODE == 0 && res) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    acc[0][j] += dv[j];
-                    acc[1][j] = fmaf(dv[j], (v[j] - mean[j]) * invstd[j], acc[1][j]);
-                }
+                for (int u = 0; u < U; ++u) qv[u] = load_raw8(res + o[u]);
             }
-            if (write_back) store8(d + o, dv);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = r + u * RL < r1;
+                float v[8], dv[8];
+                raw_to_f8<T>(yv[u].r, v);
+                raw_to_f8<T>(dr[u].r, dv);
+                if (MODE == 0) {
+                    float uu[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) uu[j] = fmaf(v[j], sc[j], sh[j]);
+                    if (res) {
+                        float q[8];
+                        raw_to_f8<T>(qv[u].r, q);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) uu[j] += q[j];
+                    }
+                    act_grad_mul(dv, uu, act);
+                } else if (MODE == 1) {
+                    float uu[8], ug[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        uu[j] = fmaf(v[j], sc[j], sh[j]);
+                        ug[j] = uu[j] * g[j];
+                    }
+                    act_grad_mul(dv, ug, act);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[0][j] = fmaf(ok ? dv[j] : 0.0f, uu[j], acc[0][j]);
+                } else if (MODE == 4) {
+                    // as mode 1, but the sums the squeeze-excite unit's norm needs are taken here, per clip: (sum d', sum d' yhat, sum yhat).
+                    // d'' = d' gate + add[n] is affine in d' per clip, so sum d'' and sum d'' yhat follow without a second pass over (d, y)
+                    // (pasn_se_gate_bwd_stat), and sum d' u = gamma sum d' yhat + beta sum d' (the gate's gradient) as well
+                    float ug[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ug[j] = fmaf(v[j], sc[j], sh[j]) * g[j];
+                    act_grad_mul(dv, ug, act);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float yh = ok ? (v[j] - mean[j]) * invstd[j] : 0.0f;
+                        const float dd = ok ? dv[j] : 0.0f;
+                        acc[0][j] += dd;
+                        acc[1][j] = fmaf(dd, yh, acc[1][j]);
+                        acc[W - 1][j] += yh;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dv[j] = fmaf(dv[j], g[j], ad[j]);
+                }
+                if (MODE != 1 && MODE != 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float dd = ok ? dv[j] : 0.0f;
+                        acc[0][j] += dd;
+                        acc[1][j] = fmaf(dd, (v[j] - mean[j]) * invstd[j], acc[1][j]);
+                    }
+                }
+                if (write_back && ok) store8(d + o[u], dv);
+            }
         }
     }
-    block_reduce_rows<W>(acc, red, ws + ((size_t)n * chunks + ch) * W * Cp, Cp, CG, CGb);
+    block_reduce_rows<W>(acc, red, ws + ((size_t)n * chunks + ch) * W * Cp, Cp, CG, LPR);
 }
 
 // totals of the mode 0 / 2 partials -> coef[2][Cp] = (sum d'/R, sum d' yhat / R), dgamma, dbeta (either may be NULL)
@@ -322,11 +379,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 // dy = sc * (d' - m1 - yhat * m2),  d' = d (act == NONE: already differentiated by the reduce pass) or d * act'(y*sc + sh)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
-                                                           const float* __restrict__ coef, T* __restrict__ dy, int S, int Cp, int CG, int CGb,
+                                                           const float* __restrict__ coef, T* __restrict__ dy, int S, int Cp, int CG, int LPR,
                                                            int rows_per_chunk, int act) {
     const int n = blockIdx.y, ch = blockIdx.x;
-    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
-    if (cg >= CG) return;
+    const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
+    if (cg >= CG || rl >= RL) return;
+    constexpr int U = ROWS_U;
     float mean[8], invstd[8], sc[8], sh[8], m1[8], m2[8];
     load8(stat + cg * 8, mean);
     load8(stat + Cp + cg * 8, invstd);
@@ -336,21 +394,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     load8(coef + Cp + cg * 8, m2);
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
     const size_t base = (size_t)n * S * Cp + cg * 8;
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const size_t o = base + (size_t)r * Cp;
-        float v[8], dv[8];
-        load8(y + o, v);
-        load8(d + o, dv);
-        if (act != PASN_ACT_NONE) {
-            float u[8];
+    for (int r = r0 + rl; r < r1; r += U * RL) {
+        size_t o[U];
+        Raw8<T> yv[U], dr[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = fmaf(v[j], sc[j], sh[j]);
-            act_grad_mul(dv, u, act);
+        for (int u = 0; u < U; ++u) {
+            o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;
+            yv[u] = load_raw8(y + o[u]);
+            dr[u] = load_raw8(d + o[u]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (dv[j] - m1[j] - (v[j] - mean[j]) * invstd[j] * m2[j]);
-        store8(dy + o, dv);
+        for (int u = 0; u < U; ++u) {
+            float v[8], dv[8];
+            raw_to_f8<T>(yv[u].r, v);
+            raw_to_f8<T>(dr[u].r, dv);
+            if (act != PASN_ACT_NONE) {
+                float uu[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) uu[j] = fmaf(v[j], sc[j], sh[j]);
+                act_grad_mul(dv, uu, act);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (dv[j] - m1[j] - (v[j] - mean[j]) * invstd[j] * m2[j]);
+            if (r + u * RL < r1) store8(dy + o[u], dv);
+        }
     }
 }
 
@@ -605,11 +672,11 @@ extern "C" int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, c
     const dim3 grid(g.chunks, N);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16) {
-        hipLaunchKernelGGL(bn_stats_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, ws, S, Cp, g.CG, g.CGb, g.rows_per_chunk, g.chunks);
+        hipLaunchKernelGGL(bn_stats_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, ws, S, Cp, g.CG, g.LPR, g.rows_per_chunk, g.chunks);
         hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)y, gamma, beta, running_mean,
                            running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr);
     } else {
-        hipLaunchKernelGGL(bn_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)y, ws, S, Cp, g.CG, g.CGb, g.rows_per_chunk, g.chunks);
+        hipLaunchKernelGGL(bn_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)y, ws, S, Cp, g.CG, g.LPR, g.rows_per_chunk, g.chunks);
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const float*)y, gamma, beta, running_mean,
                            running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr);
     }
@@ -695,10 +762,10 @@ extern "C" int pasn_affine_act_fwd(const void* y, const float* stat, const void*
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16)
         hipLaunchKernelGGL(affine_act_fwd_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, stat, (const __bf16*)residual, gate, (__bf16*)a,
-                           S, Cp, g.CG, g.CGb, g.rows_per_chunk, act);
+                           S, Cp, g.CG, g.LPR, g.rows_per_chunk, act);
     else
         hipLaunchKernelGGL(affine_act_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)y, stat, (const float*)residual, gate, (float*)a, S,
-                           Cp, g.CG, g.CGb, g.rows_per_chunk, act);
+                           Cp, g.CG, g.LPR, g.rows_per_chunk, act);
     return check_launch("affine_act_fwd");
 }
 
@@ -708,7 +775,7 @@ static void launch_grad_pass(int mode, void* d, const void* y, const float* stat
     const dim3 grid(g.chunks, N);
 #define GP(M)                                                                                                                      \
     hipLaunchKernelGGL((grad_pass_kernel<T, M>), grid, dim3(256), 0, s, (T*)d, (const T*)y, stat, (const T*)res, gate, add, ws, S, Cp, g.CG, \
-                       g.CGb, g.rows_per_chunk, g.chunks, act, (int)(mode != 3))
+                       g.LPR, g.rows_per_chunk, g.chunks, act, (int)(mode != 3))
     if (mode == 0 || mode == 3) GP(0);
     else if (mode == 1) GP(1);
     else if (mode == 4) GP(4);
@@ -743,10 +810,10 @@ extern "C" int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)d, (const __bf16*)y, stat, coef, (__bf16*)dy, S, Cp,
-                           g.CG, g.CGb, g.rows_per_chunk, act);
+                           g.CG, g.LPR, g.rows_per_chunk, act);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)d, (const float*)y, stat, coef, (float*)dy, S, Cp, g.CG,
-                           g.CGb, g.rows_per_chunk, act);
+                           g.LPR, g.rows_per_chunk, act);
     return check_launch("bn_bwd_apply");
 }
 
@@ -808,11 +875,12 @@ __global__ __launch_bounds__(256) void se_bn_coef_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
                                                               const float* __restrict__ coef, const float* __restrict__ gate,
-                                                              const float* __restrict__ add, T* __restrict__ dy, int S, int Cp, int CG, int CGb,
+                                                              const float* __restrict__ add, T* __restrict__ dy, int S, int Cp, int CG, int LPR,
                                                               int rows_per_chunk) {
     const int n = blockIdx.y, ch = blockIdx.x;
-    const int cg = threadIdx.x % CGb, rl = threadIdx.x / CGb, RL = 256 / CGb;
-    if (cg >= CG) return;
+    const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
+    if (cg >= CG || rl >= RL) return;
+    constexpr int U = ROWS_U;
     float mean[8], invstd[8], sc[8], m1[8], m2[8], g[8], ad[8];
     load8(stat + cg * 8, mean);
     load8(stat + Cp + cg * 8, invstd);
@@ -825,15 +893,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restric
     for (int j = 0; j < 8; ++j) ad[j] -= m1[j];
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
     const size_t base = (size_t)n * S * Cp + cg * 8;
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const size_t o = base + (size_t)r * Cp;
-        float v[8], dv[8];
-        load8(y + o, v);
-        load8(d + o, dv);
+    for (int r = r0 + rl; r < r1; r += U * RL) {
+        size_t o[U];
+        Raw8<T> yv[U], dr[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (fmaf(dv[j], g[j], ad[j]) - (v[j] - mean[j]) * invstd[j] * m2[j]);
-        store8(dy + o, dv);
+        for (int u = 0; u < U; ++u) {
+            o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;
+            yv[u] = load_raw8(y + o[u]);
+            dr[u] = load_raw8(d + o[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v[8], dv[8];
+            raw_to_f8<T>(yv[u].r, v);
+            raw_to_f8<T>(dr[u].r, dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (fmaf(dv[j], g[j], ad[j]) - (v[j] - mean[j]) * invstd[j] * m2[j]);
+            if (r + u * RL < r1) store8(dy + o[u], dv);
+        }
     }
 }
 
@@ -863,10 +940,10 @@ extern "C" int pasn_bn_bwd_apply_se(const void* d, const void* y, const float* s
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_se_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)d, (const __bf16*)y, stat, coef, gate, add, (__bf16*)dy,
-                           S, Cp, g.CG, g.CGb, g.rows_per_chunk);
+                           S, Cp, g.CG, g.LPR, g.rows_per_chunk);
     else
         hipLaunchKernelGGL(bn_bwd_apply_se_kernel<float>, grid, dim3(256), 0, s, (const float*)d, (const float*)y, stat, coef, gate, add, (float*)dy, S,
-                           Cp, g.CG, g.CGb, g.rows_per_chunk);
+                           Cp, g.CG, g.LPR, g.rows_per_chunk);
     return check_launch("bn_bwd_apply_se");
 }
 

@@ -57,6 +57,14 @@ class TrainBuilder(PlanBuilder):
         self.op_names: List[str] = []
         self.op_bytes: List[int] = []          # bytes of the arena / external buffers a launch touches, each buffer once (bench roofline)
         self._pending: Dict[int, int] = {}
+        # Weight-gradient launches have no reader before the optimizer: they go to a SECOND stream and overlap the main chain (the next
+        # units' reduce / apply / input-gradient passes).  op_kind: 0 main stream, 1 side stream, 2 join (the main stream waits for the
+        # side launch op_join names; the buffers that launch touches stay live in the arena until then).  At most ``side_depth`` side
+        # launches are outstanding.  PASN_TRAIN_STREAMS=1: everything on one stream.
+        self.op_kind: List[int] = []
+        self.op_join: Dict[int, int] = {}
+        self._forks: List[Tuple[int, tuple]] = []
+        self.side_depth = 0 if _lib.tuning_get("PASN_TRAIN_STREAMS") == "1" else int(_lib.tuning_get("PASN_TRAIN_SIDE_DEPTH") or 2)
         # activation buffer id -> does anything that produced it hold a parameter with requires_grad?  (The reference's agents
         # freeze the trunk / everything but the last layer in some phases: XProtoNet_Base.py:253-293; frozen parts get no
         # backward launches at all.)
@@ -91,9 +99,33 @@ class TrainBuilder(PlanBuilder):
             _lib.check(fn(*[a(ptrs) if callable(a) else a for a in bound], st))
 
         self.ops.append(run)
+        self.op_kind.append(0)
         self.op_names.append(getattr(fn, "__name__", "?"))
         self.op_bytes.append(sum(self._pending.values()))
         self._pending = {}
+
+    def _side_op(self, fn, bufs: tuple, *args) -> None:
+        """A launch nothing downstream reads before the optimizer (a weight gradient): recorded for the side stream."""
+        if self.side_depth <= 0:
+            self._use(*bufs)
+            self._op(fn, *args)
+            return
+        while len(self._forks) >= self.side_depth:
+            self._join()
+        self._use(*bufs)
+        self._op(fn, *args)
+        self.op_kind[-1] = 1
+        self._forks.append((len(self.ops) - 1, bufs))
+
+    def _join(self) -> None:
+        fork, bufs = self._forks.pop(0)
+        self._use(*bufs)  # the side launch's operands and scratch stay where they are until the main stream has waited for it
+        self._pending = {}
+        self.op_join[len(self.ops)] = fork
+        self.ops.append(lambda ptrs, st: None)
+        self.op_kind.append(2)
+        self.op_names.append("join")
+        self.op_bytes.append(0)
 
     def _use(self, *buf_ids) -> None:
         super()._use(*buf_ids)
@@ -370,14 +402,12 @@ class TrainBuilder(PlanBuilder):
                 if w_live:
                     wsz = int(lib.pasn_first_conv_wgrad_workspace_bytes(dref, code))
                     wsb = self._new_buf(wsz) if wsz else None
-                    self._use(x.buf, dy.buf, wsb)
-                    self._op(lib.pasn_first_conv_wgrad, B(x.buf), B(dy.buf), dW, dref, _lib.dtype_code(self.in_dtype), code, B(wsb))
+                    self._side_op(lib.pasn_first_conv_wgrad, (x.buf, dy.buf, wsb), B(x.buf), B(dy.buf), dW, dref, _lib.dtype_code(self.in_dtype), code, B(wsb))
                 return
             if kind == "dw":
                 if w_live:
                     wsb = self._new_buf(int(lib.pasn_dwconv3d_wgrad_workspace_floats(dref)) * 4)
-                    self._use(x.buf, dy.buf, wsb)
-                    self._op(lib.pasn_dwconv3d_wgrad, B(x.buf), B(dy.buf), B(wsb), dW, dref, code)
+                    self._side_op(lib.pasn_dwconv3d_wgrad, (x.buf, dy.buf, wsb), B(x.buf), B(dy.buf), B(wsb), dW, dref, code)
                 if not x_live:
                     return
                 dx = self.like(x)
@@ -415,8 +445,7 @@ class TrainBuilder(PlanBuilder):
             if w_live:
                 wsz = int(lib.pasn_conv3d_wgrad_workspace_bytes(dref, code))  # windowed stride-1 convs, bf16: partial-buffer path
                 wsb = self._new_buf(wsz) if wsz else None
-                self._use(x.buf, dy.buf, wsb)
-                self._op(lib.pasn_conv3d_wgrad_ws, B(x.buf), B(dy.buf), dW, dref, code, B(wsb))
+                self._side_op(lib.pasn_conv3d_wgrad_ws, (x.buf, dy.buf, wsb), B(x.buf), B(dy.buf), dW, dref, code, B(wsb))
             if not x_live:
                 return
             # ---- input gradient of the dense conv
@@ -556,6 +585,8 @@ class TrainBuilder(PlanBuilder):
         self.n_fwd = len(self.ops)
         for emit in reversed(self.tape):
             emit()
+        while self._forks:
+            self._join()
         live: List[Tuple[int, int, int]] = []
         total = 0
         for b in self.bufs:
@@ -599,7 +630,10 @@ def build_pack_tables(jobs: List[tuple], device) -> tuple:
 class TrainPlan:
     def __init__(self, tb: TrainBuilder, x_in: Act, ext: Dict[str, int], arena_bytes: int):
         self.ops, self.n_fwd, self.keep, self.refresh, self.op_names = tb.ops, tb.n_fwd, tb.keep, tb.refresh, tb.op_names
-        self.op_bytes = tb.op_bytes
+        self.op_bytes, self.op_kind, self.op_join = tb.op_bytes, tb.op_kind, tb.op_join
+        self.serial = not any(k == 1 for k in tb.op_kind)  # True: every launch on the caller's stream (also set by the per-launch profilers)
+        self._side = None
+        self._events: Dict[int, "torch.cuda.Event"] = {}
         self.offsets = [None if b.external else b.offset for b in tb.bufs]
         self.in_buf, self.ext, self.gbuf = x_in.buf, ext, tb.gbuf
         self.pslots, self.gsize, self.nbt = tb.pslots, tb.gsize, tb.nbt
@@ -651,8 +685,29 @@ class TrainPlan:
         for name, t in tensors.items():
             ptrs[self.ext[name]] = 0 if t is None else t.data_ptr()
         st = _lib.current_stream()
-        for op in self.ops[self.n_fwd:]:
-            op(ptrs, st)
+        if self.serial:
+            for op in self.ops[self.n_fwd:]:
+                op(ptrs, st)
+        else:
+            main = torch.cuda.current_stream(x.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(x.device)
+            side, sst, ev = self._side, self._side.cuda_stream, self._events
+            for i in range(self.n_fwd, len(self.ops)):
+                kind = self.op_kind[i]
+                if kind == 0:
+                    self.ops[i](ptrs, st)
+                elif kind == 1:
+                    # the side launch reads what the main stream has produced so far (its dy); the join below is where the main stream
+                    # may first overwrite what it reads
+                    before = ev.get(-i - 1) or ev.setdefault(-i - 1, torch.cuda.Event())
+                    before.record(main)
+                    side.wait_event(before)
+                    self.ops[i](ptrs, sst)
+                    done = ev.get(i) or ev.setdefault(i, torch.cuda.Event())
+                    done.record(side)
+                else:
+                    main.wait_event(ev[self.op_join[i]])
         return [G[o: o + n].view_as(p) for (p, o, n) in self.pslots]
 
 

@@ -124,8 +124,10 @@ def main(argv=None):
                 a.record(); op(ptrs, st); b.record(); evs.append((i, a, b))
             return run
         plan.ops[:] = [wrap(i, op) for i, op in enumerate(orig)]
+        was_serial, plan.serial = plan.serial, True  # per-launch times: every launch on the bracketed stream
         step(); torch.cuda.synchronize()
         plan.ops[:] = orig
+        plan.serial = was_serial
         agg = {}
         for i, a, b in evs:
             k = ('fwd ' if i < plan.n_fwd else 'bwd ') + plan.op_names[i]
