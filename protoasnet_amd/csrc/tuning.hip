@@ -45,6 +45,10 @@ static const TuneEntry kRegistry[] = {
     {"PASN_NO_HALO",          "route", "no halo-tile implicit GEMM (igemm_halo.hip)"},
     {"PASN_NO_IGEMM",         "route", "no direct-to-LDS implicit GEMM (igemm.hip)"},
     {"PASN_NO_PACK",          "route", "1: training weights packed by torch ops instead of the one-launch pack kernel (host side, train.py)"},
+    {"PASN_DWWG_MARCH2",      "route", "0: depthwise weight gradient by round 2's marching kernel instead of round 4's (wgrad.hip)"},
+    {"PASN_DWWG_CH",          "geom",  "channels per thread of the depthwise weight-gradient march (4 default, 2)"},
+    {"PASN_DWWG_WT",          "geom",  "outputs per strip of the depthwise weight-gradient march at stride 1 (2 default, 3)"},
+    {"PASN_DWWG_BLOCKS",      "geom",  "cap on the blocks (= partial rows) of the depthwise weight-gradient march (default 512)"},
     {"PASN_TRAIN_BLOCKS",     "geom",  "blocks an elementwise training pass is cut into (default 1024; the partial-sum workspaces scale with it)"},
     {"PASN_TRAIN_ROWS_CONTIG", "geom", "1: the elementwise training passes map Cp / 8 lanes to a row (contiguous spans, fewer idle lanes) instead of the next power of two"},
     {"PASN_TRAIN_STREAMS",    "route", "1: weight-gradient launches of the training step on the main stream instead of a second one (host side, train.py)"},

@@ -1062,6 +1062,147 @@ __global__ __launch_bounds__(256, 2) void dw_wgrad_march_kernel(const __bf16* __
     }
 }
 
+// ---- T-marching form, second cut (round 4) --------------------------------------------------------------------------------------------
+// The kernel above asks for a step's 18 rows at the top of the step and waits for all of them (two resident waves per SIMD at 256 VGPRs
+// cannot cover it): 1.1-1.7 TB/s, a quarter of its vector-issue bound.  Here
+//  * a thread owns CH = 4 (or 2: 4-byte loads, half the accumulators, 4 waves per SIMD) channels of a strip of WT = 2 outputs,
+//  * every row's registers are re-requested for the NEXT frame right after their conversion, ahead of the step's 27 x WT packed FMAs, and the
+//    gradients one frame further ahead: a step never waits for a load it asked for in the same step,
+//  * loads go through buffer descriptors: the frame offset is a scalar operand, positions outside the plane carry an out-of-range offset and
+//    read as zero (no select per loaded value, no 64-bit address arithmetic per step),
+//  * lanes map to (item, channel group) without padding the group count to a power of two.
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned WG_OOB = 0x80000000u;
+
+template <int CW>
+__device__ __forceinline__ void wg_load(unsigned (&r)[CW], __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    if constexpr (CW == 1) {
+        r[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0);
+    } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+        r[0] = v[0];
+        r[1] = v[1];
+    }
+}
+template <int CW>
+__device__ __forceinline__ void wg_cvt(const unsigned (&r)[CW], wg_f32x2 (&v)[CW]) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) v[c] = wg_f32x2{__uint_as_float(r[c] << 16), __uint_as_float(r[c] & 0xffff0000u)};
+}
+
+template <int SW, int WT, int CH>
+__global__ __launch_bounds__(256) void dw_wgrad_march2_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, float* __restrict__ partial,
+                                                              pasn_conv_desc d, int CG, int PL, int strips, long items) {
+    constexpr int IW = (WT - 1) * SW + 3, CW = CH / 2;
+    __shared__ float red[256 * CH];
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    const bool live = pl < PL;
+    wg_f32x2 acc[27][CW];
+#pragma unroll
+    for (int p = 0; p < 27; ++p)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) acc[p][c] = wg_f32x2{0.0f, 0.0f};
+    const int Cp = d.Cout_p;
+    const unsigned xframe = (unsigned)d.Hi * d.Wi * Cp * 2u, gframe = (unsigned)d.Ho * d.Wo * Cp * 2u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, (unsigned)d.N * d.Ti * xframe, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(dy), 0, (unsigned)d.N * d.To * gframe, 0x00020000);
+    for (long item = (long)blockIdx.x * PL + pl; live && item < items; item += (long)gridDim.x * PL) {  // (n, ho, strip)
+        const int strip = (int)(item % strips);
+        const long q = item / strips;
+        const int ho = (int)(q % d.Ho), n = (int)(q / d.Ho);
+        const int wo0 = strip * WT, wi0 = wo0 * SW - 1;
+        unsigned gv[WT], xv[3][IW];  // byte offsets inside frame 0 of clip n; outside the plane: out of range (reads as zero)
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+            gv[j] = wo0 + j < d.Wo ? (unsigned)n * d.To * gframe + (unsigned)((ho * d.Wo + wo0 + j) * Cp + cg * CH) * 2u : WG_OOB;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = ho * SW - 1 + dh;
+            const bool hok = hi >= 0 && hi < d.Hi;
+#pragma unroll
+            for (int i = 0; i < IW; ++i) {
+                const int wi = wi0 + i;
+                xv[dh][i] = (hok && wi >= 0 && wi < d.Wi) ? (unsigned)n * d.Ti * xframe + (unsigned)((hi * d.Wi + wi) * Cp + cg * CH) * 2u : WG_OOB;
+            }
+        }
+        wg_f32x2 g0[WT][CW], g1[WT][CW];  // gradients of output frames ti - 1, ti
+        unsigned gn[WT][CW], raw[3][IW][CW];
+#pragma unroll
+        for (int j = 0; j < WT; ++j) wg_load<CW>(gn[j], grs, gv[j], 0u);
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+            wg_cvt<CW>(gn[j], g1[j]);
+#pragma unroll
+            for (int c = 0; c < CW; ++c) g0[j][c] = wg_f32x2{0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int j = 0; j < WT; ++j) wg_load<CW>(gn[j], grs, d.To > 1 ? gv[j] : WG_OOB, d.To > 1 ? gframe : 0u);
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int i = 0; i < IW; ++i) wg_load<CW>(raw[dh][i], xrs, xv[dh][i], 0u);
+#pragma unroll 1
+        for (int ti = 0; ti < d.Ti; ++ti) {
+            wg_f32x2 g2[WT][CW];  // gradient of output frame ti + 1 (zero past the clip)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) wg_cvt<CW>(gn[j], g2[j]);
+            {
+                const bool more = ti + 2 < d.To;
+                const unsigned so = (unsigned)min(ti + 2, d.To - 1) * gframe;
+#pragma unroll
+                for (int j = 0; j < WT; ++j) wg_load<CW>(gn[j], grs, more ? gv[j] : WG_OOB, so);
+            }
+            wg_f32x2 xc[3][IW][CW];
+            const unsigned sx = (unsigned)min(ti + 1, d.Ti - 1) * xframe;  // (the last step's request is not used)
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+#pragma unroll
+                for (int i = 0; i < IW; ++i) wg_cvt<CW>(raw[dh][i], xc[dh][i]);
+#pragma unroll
+                for (int i = 0; i < IW; ++i) wg_load<CW>(raw[dh][i], xrs, xv[dh][i], sx);
+            }
+            // temporal tap a pairs input frame ti with output frame ti - a + 1: a = 0 -> g2, 1 -> g1, 2 -> g0
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw_ = 0; dw_ < 3; ++dw_)
+#pragma unroll
+                    for (int j = 0; j < WT; ++j)
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) {
+                            const wg_f32x2 xvv = xc[dh][j * SW + dw_][c];
+                            acc[0 * 9 + dh * 3 + dw_][c] = __builtin_elementwise_fma(g2[j][c], xvv, acc[0 * 9 + dh * 3 + dw_][c]);
+                            acc[1 * 9 + dh * 3 + dw_][c] = __builtin_elementwise_fma(g1[j][c], xvv, acc[1 * 9 + dh * 3 + dw_][c]);
+                            acc[2 * 9 + dh * 3 + dw_][c] = __builtin_elementwise_fma(g0[j][c], xvv, acc[2 * 9 + dh * 3 + dw_][c]);
+                        }
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    g0[j][c] = g1[j][c];
+                    g1[j][c] = g2[j][c];
+                }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * 27 * Cp;
+#pragma unroll
+    for (int p = 0; p < 27; ++p) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            red[threadIdx.x * CH + 2 * c] = acc[p][c][0];
+            red[threadIdx.x * CH + 2 * c + 1] = acc[p][c][1];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < CG * CH; t += 256) {
+            const int g2i = t / CH, j = t % CH;
+            float s = 0.0f;
+            for (int q2 = 0; q2 < PL; ++q2) s += red[(q2 * CG + g2i) * CH + j];
+            out[(size_t)p * Cp + g2i * CH + j] = s;
+        }
+    }
+}
+
 // dw[c][tap] = sum_chunks partial[chunk][tap*Cp + c]: 64 columns x 4 parts per block, parts combined in a fixed order
 __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int taps, int C,
                                                               int Cp) {
@@ -1192,11 +1333,40 @@ static long dw_wgrad_march_blocks(const pasn_conv_desc& d, const DwWgGeom& g) {
     return std::min<long>((items + g.PL - 1) / g.PL, 1024);
 }
 
+struct DwWgMarch2 {
+    int ok, SW, WT, CH, CG, PL, strips;
+    long items, blocks;
+};
+// second cut of the marching kernel (PASN_DWWG_MARCH2=0: the first one).  Measured at the X3D-S shapes (tools/dwwg_bench.py,
+// profiles/r04_dwwg_sweep.txt): 4 channels per thread and at most 512 blocks (= partial rows for the combine pass) is the best or within
+// 2 % of the best arm at every shape; 2 channels / strips of 3 / 256-1024 blocks are switches
+static DwWgMarch2 dw_wgrad_march2_geom(const pasn_conv_desc& d) {
+    DwWgMarch2 g{};
+    if (tune_is("PASN_DWWG_MARCH2", '0') || !dw_wgrad_march_ok(d) || d.sh != d.sw || (d.sh != 1 && d.sh != 2)) return g;
+    g.CH = tune_is("PASN_DWWG_CH", '2') ? 2 : 4;
+    if (d.Cout_p % g.CH || d.Cout_p / g.CH > 256) return g;
+    // 32-bit byte offsets into either tensor
+    if ((double)d.N * d.Ti * d.Hi * d.Wi * d.Cin_p * 2.0 >= 2147483648.0 || (double)d.N * d.To * d.Ho * d.Wo * d.Cout_p * 2.0 >= 2147483648.0) return g;
+    g.SW = d.sh;
+    g.WT = g.SW == 1 && tune_is("PASN_DWWG_WT", '3') ? 3 : 2;
+    g.strips = ceil_div(d.Wo, g.WT);
+    g.CG = d.Cout_p / g.CH;
+    g.PL = 256 / g.CG;
+    g.items = (long)d.N * d.Ho * g.strips;
+    int cap = 512;
+    if (const char* e = tune("PASN_DWWG_BLOCKS")) cap = std::max(64, atoi(e));
+    g.blocks = std::min<long>((g.items + g.PL - 1) / g.PL, cap);
+    g.ok = 1;
+    return g;
+}
+
 size_t dw_wgrad_strip_floats(const pasn_conv_desc& d) {
     if (dw_temporal_ok(d)) return (size_t)dw_temporal_blocks(d) * d.kt * d.Cout_p;
     const DwWgGeom g = dw_wgrad_strip_geom(d);
-    if (g.ok && dw_wgrad_march_ok(d))  // bf16 takes the marching kernel, fp32 the strip kernel: room for either
-        return (size_t)std::max<long>(dw_wgrad_march_blocks(d, g), g.blocks) * 27 * d.Cout_p;
+    if (g.ok && dw_wgrad_march_ok(d)) {  // bf16 takes a marching kernel, fp32 the strip kernel: room for either
+        const DwWgMarch2 m2 = dw_wgrad_march2_geom(d);
+        return (size_t)std::max<long>(std::max<long>(dw_wgrad_march_blocks(d, g), g.blocks), m2.ok ? m2.blocks : 0) * 27 * d.Cout_p;
+    }
     return g.ok ? (size_t)g.blocks * d.kt * 9 * d.Cout_p : 0;
 }
 
@@ -1217,6 +1387,24 @@ bool dw_wgrad_strip(const void* x, const void* dy, float* ws, float* dw, const p
     }
     const DwWgGeom g = dw_wgrad_strip_geom(d);
     if (!g.ok) return false;
+    if (const DwWgMarch2 m = dw_wgrad_march2_geom(d); dtype == PASN_BF16 && m.ok) {
+#define DWM2(SWv, WTv, CHv)                                                                                                                      \
+    hipLaunchKernelGGL((dw_wgrad_march2_kernel<SWv, WTv, CHv>), dim3((unsigned)m.blocks), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, ws, d, \
+                       m.CG, m.PL, m.strips, m.items)
+        if (m.SW == 2) {
+            if (m.CH == 2) DWM2(2, 2, 2);
+            else DWM2(2, 2, 4);
+        } else if (m.WT == 3) {
+            if (m.CH == 2) DWM2(1, 3, 2);
+            else DWM2(1, 3, 4);
+        } else {
+            if (m.CH == 2) DWM2(1, 2, 2);
+            else DWM2(1, 2, 4);
+        }
+#undef DWM2
+        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div((long)27 * d.Cout_p, 64)), dim3(256), 0, s, ws, dw, (int)m.blocks, 27, d.Cout, d.Cout_p);
+        return true;
+    }
     if (dtype == PASN_BF16 && dw_wgrad_march_ok(d)) {
         const long items = (long)d.N * d.Ho * g.strips, blocks = dw_wgrad_march_blocks(d, g);
 #define DWM(SWv, WTv) \

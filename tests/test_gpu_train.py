@@ -567,15 +567,21 @@ def test_depthwise_wgrad_march_bf16(c, s, shape, monkeypatch):
     d = _desc(x, y, (3, 3, 3), (1, s, s), (1, 1, 1))
     xd, dyd = _cl(x, dtype=torch.bfloat16), _cl(dy, dtype=torch.bfloat16)
     outs = []
-    for no_march in ("0", "1"):
-        monkeypatch.setenv("PASN_NO_DWWG_MARCH", no_march)
+    # round 4's marching kernel (4 channels per thread, strips of 2), its 2-channel and 3-wide instances, round 2's marching kernel, the strip kernel
+    arms = ({}, {"PASN_DWWG_CH": "2"}, {"PASN_DWWG_WT": "3"}, {"PASN_DWWG_CH": "2", "PASN_DWWG_WT": "3"}, {"PASN_DWWG_MARCH2": "0"}, {"PASN_NO_DWWG_MARCH": "1"})
+    for env in arms:
+        for k in ("PASN_DWWG_CH", "PASN_DWWG_WT", "PASN_DWWG_MARCH2", "PASN_NO_DWWG_MARCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         ws = torch.full((int(lib.pasn_dwconv3d_wgrad_workspace_floats(ctypes.byref(d))),), float("nan"), device=DEV)
         dw = torch.zeros(c, 27, device=DEV)
         _lib.check(lib.pasn_dwconv3d_wgrad(xd.data_ptr(), dyd.data_ptr(), ws.data_ptr(), dw.data_ptr(), ctypes.byref(d), BF16, _st()))
         torch.cuda.synchronize()
-        _rel(dw.view_as(wt), wt.grad, 1e-4, f"dW (PASN_NO_DWWG_MARCH={no_march})")
+        _rel(dw.view_as(wt), wt.grad, 1e-4, f"dW ({env})")
         outs.append(dw)
-    _rel(outs[0], outs[1], 1e-5, "marching vs strip kernel")
+    for o in outs[:-1]:
+        _rel(o, outs[-1], 1e-5, "marching vs strip kernel")
 
 
 @pytest.mark.parametrize("layer", ["c133_64_144", "c311_144_64", "c133_s2_64_230", "dw_54"])
