@@ -111,10 +111,12 @@ class ResNet18Features(_plan.HipTrunk):
         x = pb.maxpool(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
         for li in range(1, 5):
             for blk in getattr(self, f"layer{li}"):
-                identity = x
+                identity, branch = x, None
                 if blk.downsample is not None:
                     identity = pb.conv(x, blk.downsample[0], blk.downsample[1], act="none")
+                    branch = pb.fork_last()  # beside the block's first conv
                 y = pb.conv(x, blk.conv1, blk.bn1, act="relu")
+                pb.join(branch, x.buf, identity.buf)
                 x = pb.conv(y, blk.conv2, blk.bn2, act="relu", residual=identity)
         return x
 
@@ -205,14 +207,16 @@ class resnet2p1d_18(_plan.HipTrunk):  # noqa: N801 -- name is part of the refere
         x = pb.conv(x, stem[3], stem[4], act="relu")
         for layer in list(self.backbone)[1:]:
             for blk in layer:
-                identity = x
+                identity, branch = x, None
                 if blk.downsample is not None:
                     identity = pb.conv(x, blk.downsample[0], blk.downsample[1], act="none")
+                    branch = pb.fork_last()  # beside the block's first three convs
                 c = blk.conv1[0]
                 y = pb.conv(x, c[0], c[1], act="relu")
                 y = pb.conv(y, c[3], blk.conv1[1], act="relu")
                 c = blk.conv2[0]
                 y = pb.conv(y, c[0], c[1], act="relu")
+                pb.join(branch, x.buf, identity.buf)
                 x = pb.conv(y, c[3], blk.conv2[1], act="relu", residual=identity)
         return x
 
@@ -334,8 +338,10 @@ class X3DFeatures(_plan.HipTrunk):
                         x, pre = whole
                         continue
                 fuse_short = blk.shortcut is not None and pb.short_fusable(x, blk)  # the strided shortcut conv rides in the project conv's launch
+                branch, x_in = None, x
                 if blk.shortcut is not None and not fuse_short:
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
+                    branch = pb.fork_last()  # nothing reads it before the project conv: it runs beside expand conv and stencil
                 act_b = "none" if blk.se is not None else "swish"  # no gate between BN and Swish: the stencil applies Swish
                 gate = None
                 # expand conv + stencil in one launch where the pair is covered (block width <= 48): the expanded activation never leaves LDS
@@ -368,6 +374,7 @@ class X3DFeatures(_plan.HipTrunk):
                 # project conv; where the geometry allows, chained in ONE launch with the next block's expand conv
                 nxt = blocks[i + 1] if i + 1 < len(blocks) else None
                 pair = None
+                pb.join(branch, x_in.buf, sc.buf)
                 if isinstance(gate, tuple):  # squeeze-excite gate in the project conv's prologue
                     if fuse_short:  # (not combined with the fused shortcut: different kernels)
                         sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")

@@ -53,6 +53,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_TRAIN_ROWS_CONTIG", "geom", "1: the elementwise training passes map Cp / 8 lanes to a row (contiguous spans, fewer idle lanes) instead of the next power of two"},
     {"PASN_TRAIN_STREAMS",    "route", "1: weight-gradient launches of the training step on the main stream instead of a second one (host side, train.py)"},
     {"PASN_TRAIN_SIDE_DEPTH", "geom",  "side-stream weight-gradient launches outstanding before the main stream waits (default 2)"},
+    {"PASN_BRANCH",           "route", "1: shortcut / downsample convs on the plan's side stream beside their block's main branch (host side, plan.py; measured slower)"},
     {"PASN_NO_EDP",           "route", "1: no whole-block launch for the 7 x 7 stage (x3d_edp.hip)"},
     {"PASN_NO_PE",            "route", "1: no streamed project + expand pair launch for the 432-channel stage (x3d_pe.hip)"},
     {"PASN_NO_PWCONV",        "route", "no register-resident persistent pointwise conv (pwconv.hip)"},

@@ -134,6 +134,13 @@ class PlanBuilder:
         self.ops: List[Callable[[List[int], int], None]] = []
         self.keep: List[object] = []  # packed weights / descriptors kept alive with the plan
         self.meta: List[dict] = []  # per launch: kernel instance name, algorithmic bytes and flops (DESIGN.md "Measurement")
+        # launches that run on the plan's SIDE stream (a shortcut / downsample conv beside its block's main branch: nothing reads its output
+        # until the block's last conv) and, per launch index, the side launches the main stream waits for before it.  OPT-IN (PASN_BRANCH=1):
+        # measured, the fork / join edges cost more than the 27 us of shortcut launches they hide (X3D-S 11.84 k vs 11.98 k clips/s as one
+        # chain; R(2+1)D-18 +-0: profiles/README.md entry 124)
+        self.op_side: set = set()
+        self.op_wait: Dict[int, List[int]] = {}
+        self.branches = _lib.tuning_get("PASN_BRANCH") == "1"
         self.lib = _lib.lib()
         self.tname = "bf16" if dtype == torch.bfloat16 else "f32"
         # arrival counters of the fused SE-gate launches, one [N] slice per launch, packed so that Plan.run clears them with ONE fill before
@@ -151,6 +158,22 @@ class PlanBuilder:
         for b in buf_ids:
             if b is not None:
                 self.bufs[b].last = len(self.ops)
+
+    def fork_last(self) -> Optional[int]:
+        """The launch recorded last goes to the side stream; returns the token ``join`` takes (None: branches are off)."""
+        if not self.branches or not self.ops:
+            return None
+        idx = len(self.ops) - 1
+        self.op_side.add(idx)
+        return idx
+
+    def join(self, token: Optional[int], *bufs: int) -> None:
+        """The NEXT launch recorded (and everything behind it) waits for side launch ``token``; ``bufs`` -- what that launch reads and
+        writes -- stay where they are in the arena until then (the main branch runs beside it and must not be handed their memory)."""
+        if token is None:
+            return
+        self._use(*bufs)
+        self.op_wait.setdefault(len(self.ops), []).append(token)
 
     def input(self, shape) -> Act:
         if len(shape) == 4:
@@ -905,6 +928,9 @@ class PlanBuilder:
 class Plan:
     def __init__(self, pb: PlanBuilder, x_in: Act, y_out: Act, arena_bytes: int):
         self.ops, self.keep, self.meta = pb.ops, pb.keep, pb.meta
+        self.op_side, self.op_wait = frozenset(pb.op_side), {k: tuple(v) for k, v in pb.op_wait.items()}
+        self._side = None
+        self._events: Dict[int, tuple] = {}
         self.in_buf, self.out_buf, self.out = x_in.buf, y_out.buf, y_out
         self.dtype = pb.dtype
         self.arena_bytes = arena_bytes
@@ -925,9 +951,31 @@ class Plan:
         st = _lib.current_stream()
         if self.se_counters is not None:
             self.se_counters.zero_()  # one 16-byte-multiple fill on the launch stream (see PlanBuilder.__init__)
-        if not timers:
+        if not timers and not self.op_side:
             for op in self.ops:
                 op(ptrs, st)
+            return y
+        if not timers:
+            # two branches: a side launch waits for what the main stream has produced so far and leaves an event its consumer waits for
+            # (inside a hipGraph capture these become the graph's fork and join edges)
+            main = torch.cuda.current_stream(x.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(x.device)
+                self._events = {i: (torch.cuda.Event(), torch.cuda.Event()) for i in self.op_side}
+            side, sst = self._side, self._side.cuda_stream
+            for i, op in enumerate(self.ops):
+                for tok in self.op_wait.get(i, ()):
+                    main.wait_event(self._events[tok][1])
+                if i in self.op_side:
+                    before, done = self._events[i]
+                    before.record(main)
+                    side.wait_event(before)
+                    op(ptrs, sst)
+                    done.record(side)
+                else:
+                    op(ptrs, st)
+            for tok in self.op_wait.get(len(self.ops), ()):
+                main.wait_event(self._events[tok][1])
             return y
         for i, op in enumerate(self.ops):
             sink = timers.get(i)
