@@ -330,6 +330,21 @@ __device__ __forceinline__ void raw_to_f8<float>(const uint4 (&r)[2], float (&v)
     v[4] = __uint_as_float(r[1].x); v[5] = __uint_as_float(r[1].y); v[6] = __uint_as_float(r[1].z); v[7] = __uint_as_float(r[1].w);
 }
 
+// Sum of `rows` floats pp[b * stride], b = 0 .. rows - 1, IN INDEX ORDER (bitwise reproducible), with the loads of eight rows in flight
+// at a time whatever `rows` is.  (A `for (; b < rows; ++b) sum += pp[...]` tail is one dependent L2 round trip per row: the squeeze-excite
+// gates of the 14 x 14 and 7 x 7 stages have 4 and 2 partial rows per clip and read them one after the other -- ~1 us each, per clip.)
+__device__ __forceinline__ float sum_rows_in_order(const float* pp, int rows, long stride, float sum = 0.0f) {
+    for (int b = 0; b < rows; b += 8) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = pp[(long)min(b + e, rows - 1) * stride];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (b + e < rows) sum += t[e];
+    }
+    return sum;
+}
+
 // Logical block id for physical workgroup `bid` of an `nwg`-block 1-D grid such that the blocks sharing an XCD
 // (bid % 8, observed round-robin dispatch) form ONE contiguous logical range.  Placement affects speed only.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -1078,7 +1078,15 @@ __global__ __launch_bounds__(256) void se_gate_fast_kernel(const float* __restri
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc += t[k];
             }
-            for (; q < pool_blocks; q += 2) acc += *reinterpret_cast<const f32x4*>(pp + (long)q * Cp);
+            if (q < pool_blocks) {  // the rest (fewer than eight rows of this parity): in flight together as well, added in the same order
+                const int last = q + 2 * ((pool_blocks - 1 - q) / 2);
+                f32x4 t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(pp + (long)min(q + 2 * k, last) * Cp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (q + 2 * k < pool_blocks) acc += t[k];
+            }
             *reinterpret_cast<f32x4*>(part + par * Cp + quad * 4) = acc;
         }
     }

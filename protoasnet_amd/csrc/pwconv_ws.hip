@@ -257,19 +257,30 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
         float b1r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) b1r[u] = se.b1[wave + 8 * u < cse ? wave + 8 * u : 0];
-        for (int q = 0; q < ncl; ++q) {
-            const float* pp = se.pool + (long)(n_first + q) * se.pool_blocks * Cin_p + (tid < Cin_p ? tid : 0);
-            float sum = 0.0f;
-            int b = 0;
-            for (; b + 8 <= se.pool_blocks; b += 8) {
-                float t[8];
+        {
+            // partial rows of both clips, eight rows each in flight together; every sum in row order (as se_gate_kernel)
+            const float* pp0 = se.pool + (long)n_first * se.pool_blocks * Cin_p + (tid < Cin_p ? tid : 0);
+            const float* pp1 = pp0 + (ncl > 1 ? (long)se.pool_blocks * Cin_p : 0);
+            float sum0 = 0.0f, sum1 = 0.0f;
+            for (int b = 0; b < se.pool_blocks; b += 8) {
+                float t0[8], t1[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = pp[(long)(b + e) * Cin_p];
+                for (int e = 0; e < 8; ++e) {
+                    const long o = (long)min(b + e, se.pool_blocks - 1) * Cin_p;
+                    t0[e] = pp0[o];
+                    t1[e] = pp1[o];
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sum += t[e];
+                for (int e = 0; e < 8; ++e)
+                    if (b + e < se.pool_blocks) {
+                        sum0 += t0[e];
+                        sum1 += t1[e];
+                    }
             }
-            for (; b < se.pool_blocks; ++b) sum += pp[(long)b * Cin_p];
-            if (tid < Cin_p) mean[q * Cin_p + tid] = sum * se.inv_positions;
+            if (tid < Cin_p) {
+                mean[tid] = sum0 * se.inv_positions;
+                if (ncl > 1) mean[Cin_p + tid] = sum1 * se.inv_positions;
+            }
         }
         ws_barrier();
         for (int q = 0; q < ncl; ++q) {

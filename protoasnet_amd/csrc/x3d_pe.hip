@@ -70,28 +70,31 @@ __device__ __attribute__((noinline)) void pe_se_gate(const float* __restrict__ p
     float b1r[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) b1r[u] = b1[wave + 8 * u < cse ? wave + 8 * u : 0];
-    for (int q = 0; q < ncl; ++q) {
-        const float* pp = pool + (long)(n0 + q) * pool_blocks * Cmp + (tid < Cmp ? tid : 0);
-        // (the SUM runs in the fixed order b = 0, 1, ... of pwconv_ws.hip; the LOADS of up to 16 partial rows are in flight together:
-        // eight at a time, as there, is eight dependent round trips for the 64 rows of this stage)
-        float sum = 0.0f;
-        int b = 0;
-        for (; b + 16 <= pool_blocks; b += 16) {
-            float t[16];
+    {
+        // (the SUMS run in the fixed order b = 0, 1, ... of pwconv_ws.hip; the loads of both clips' partial rows are in flight together, eight
+        // rows each at a time)
+        const float* pp0 = pool + (long)n0 * pool_blocks * Cmp + (tid < Cmp ? tid : 0);
+        const float* pp1 = pp0 + (ncl > 1 ? (long)pool_blocks * Cmp : 0);
+        float sum0 = 0.0f, sum1 = 0.0f;
+        for (int b = 0; b < pool_blocks; b += 8) {
+            float t0[8], t1[8];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) t[e] = pp[(long)(b + e) * Cmp];
+            for (int e = 0; e < 8; ++e) {
+                const long o = (long)min(b + e, pool_blocks - 1) * Cmp;
+                t0[e] = pp0[o];
+                t1[e] = pp1[o];
+            }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum += t[e];
+            for (int e = 0; e < 8; ++e)
+                if (b + e < pool_blocks) {
+                    sum0 += t0[e];
+                    sum1 += t1[e];
+                }
         }
-        for (; b + 8 <= pool_blocks; b += 8) {
-            float t[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = pp[(long)(b + e) * Cmp];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += t[e];
+        if (tid < Cmp) {
+            mean[tid] = sum0 * inv_positions;
+            if (ncl > 1) mean[Cmp + tid] = sum1 * inv_positions;
         }
-        for (; b < pool_blocks; ++b) sum += pp[(long)b * Cmp];
-        if (tid < Cmp) mean[q * Cmp + tid] = sum * inv_positions;
     }
     pe_barrier();
     for (int q = 0; q < ncl; ++q) {

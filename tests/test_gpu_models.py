@@ -505,3 +505,29 @@ def test_ppnet_callable_prototype_activation():
         other, _ = m(x)
         assert_close(other, torch.nn.functional.linear(torch.exp(-min_d / 64.0), m.last_layer.weight), 1e-6, 1e-6, "callable logits")
         assert_close(m.distance_2_similarity(min_d), torch.exp(-min_d / 64.0), 0, 0, "distance_2_similarity with a callable")
+
+
+@pytest.mark.parametrize("cfg_name", ["CFG_VIDEO_X3D", "CFG_VIDEO_R2P1D"])
+def test_side_stream_branches_give_the_same_outputs(cfg_name, monkeypatch):
+    """PASN_BRANCH=1 (opt-in): shortcut / downsample convs run on the plan's side stream beside their block's main branch, launch by launch
+    and inside a captured graph (fork / join edges).  Same launches, same operands: outputs bit-identical to the single chain, and the
+    side launch's operands are not handed to the main branch while it runs (the arena rule of PlanBuilder.join)."""
+    from protoasnet_amd.graph import GraphedForward
+
+    cfg = globals()[cfg_name]
+    shape = (2, 3, 16, 160, 160) if cfg_name == "CFG_VIDEO_X3D" else (2, 3, 16, 112, 112)
+    x = synth.echo_clips(shape).to(DEV).bfloat16()
+    outs = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("PASN_BRANCH", arm)
+        m = _gpu(cfg).set_compute_dtype(torch.bfloat16)
+        with torch.no_grad():
+            eager = [t.clone() for t in m(x)]
+        plan = m.cnn_backbone.plan_for(x)
+        assert bool(plan.op_side) == (arm == "1")
+        graphed = [t.clone() for t in GraphedForward(m)(x)]
+        for a, b in zip(eager, graphed):
+            assert torch.equal(a, b)
+        outs[arm] = eager
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
