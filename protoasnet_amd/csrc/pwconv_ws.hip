@@ -232,7 +232,10 @@ __global__ __launch_bounds__(512) void pwconv_ws_kernel(const __bf16* __restrict
         for (int ks = 0; ks < KS2; ++ks)
             if (ks >= pr2.nks2) A2[ks] = zero_frag<__bf16>();
     }
-    if (se_on) {
+    if (se_on && (abl & 64)) {
+        float* G = reinterpret_cast<float*>(smem + g.xreg);
+        for (int i = threadIdx.x; i < 2 * GPR * 4; i += NW * 64) G[i] = 1.0f;
+    } else if (se_on) {
         // both FC weight sets are requested first (they do not depend on the clip), then per clip: mean over positions from the partial rows
         // (fixed order) -> fc1 + ReLU (a wave per hidden unit, lanes over channels) -> fc2 + sigmoid (a thread per channel).  Scratch: the X
         // region of stage 2 (its first DMA group is issued in iteration 0, after this)
