@@ -493,6 +493,31 @@ int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const float* stat, co
 int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp, int act,
                       int dtype, void* stream);
 
+/* Statistics GROUPS (round 4).  The `_g` forms of the entry points above take `groups`: the batch is `groups` runs of N / groups consecutive
+ * clips, each normalised with its OWN batch statistics -- stat is [groups][4][Cp], coef [groups][2][Cp]; the running estimates are updated
+ * group by group in order (num_batches_tracked is the caller's: + groups); dgamma / dbeta are the parameter's (summed over the groups).
+ * groups = 2 runs the two trunk passes of the reference's loss recipe (model(x), then model.compute_occurence_map(warp(x)): loss.py:302)
+ * as ONE pass over [clips, warped clips] with exactly the statistics two passes would have used.  groups = 1 == the plain entry point.
+ * 1 <= groups <= 4, N % groups == 0. */
+int pasn_bn_stats_fwd_g(const void* y, float* ws, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float momentum, float eps, float* stat, float* pool_u, int N, int S, int C, int Cp, int dtype, int groups, void* stream);
+int pasn_dwconv3d_stats_fwd_g(const void* x, const float* w, const float* scale, const float* bias, void* y, float* ws, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* stat, float* pool_u,
+                              const pasn_conv_desc* d, int dtype, int groups, void* stream);
+int pasn_affine_act_fwd_g(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S, int C, int Cp,
+                          int act, int dtype, int groups, void* stream);
+int pasn_unit_bwd_reduce_g(int mode, void* d, const void* y, const float* stat, const void* residual, const float* gate, const float* add,
+                           float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int act, int dtype, int groups,
+                           void* stream);
+int pasn_bn_bwd_apply_g(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp, int act,
+                        int dtype, int groups, void* stream);
+int pasn_se_gate_bwd_stat_g(float* ws3, const float* pool_u, const float* stat, const float* gate, const float* fc1_w, const float* fc1_b,
+                            const float* fc2_w, const float* fc2_b, float* add, float* pn, float* dfc1_w, float* dfc1_b, float* dfc2_w,
+                            float* dfc2_b, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int Cse, int groups,
+                            void* stream);
+int pasn_bn_bwd_apply_se_g(const void* d, const void* y, const float* stat, const float* coef, const float* gate, const float* add, void* dy,
+                           int N, int S, int C, int Cp, int dtype, int groups, void* stream);
+
 /* Squeeze-excite backward: from the mode-1 partials `ws` and the pooled input `pool_u`, through sigmoid / fc2 / ReLU / fc1:
  *   add : fp32 [N][Cp] = dpool / S (the term mode 2 adds);  dw1 [Cse][C], db1 [Cse], dw2 [C][Cse], db2 [C]
  *   pn  : workspace of pasn_se_bwd_workspace_floats(N, C, Cse) floats */

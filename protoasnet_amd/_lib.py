@@ -101,6 +101,14 @@ SIGNATURES = {
     "pasn_affine_act_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "pasn_unit_bwd_reduce": (c_int, [c_int] + [c_void_p] * 10 + [c_int] * 6 + [c_void_p]),
     "pasn_bn_bwd_apply": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    # ... with statistics groups (stat [groups][4][Cp], coef [groups][2][Cp]): the paired training pass
+    "pasn_bn_stats_fwd_g": (c_int, [c_void_p] * 6 + [c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pasn_dwconv3d_stats_fwd_g": (c_int, [c_void_p] * 10 + [c_float, c_float, c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),
+    "pasn_affine_act_fwd_g": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "pasn_unit_bwd_reduce_g": (c_int, [c_int] + [c_void_p] * 10 + [c_int] * 7 + [c_void_p]),
+    "pasn_bn_bwd_apply_g": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "pasn_se_gate_bwd_stat_g": (c_int, [c_void_p] * 17 + [c_int] * 6 + [c_void_p]),
+    "pasn_bn_bwd_apply_se_g": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "pasn_se_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "pasn_se_gate_bwd": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "pasn_scatter_strided": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p]),

@@ -10,6 +10,8 @@
 
 namespace pasn {
 
+constexpr int PASN_MAX_GROUPS = 4;  // statistics groups of one pass (bn_finalize_kernel)
+
 struct RowGeom {
     int CG, LPR, RL, chunks, rows_per_chunk;
 };
@@ -117,64 +119,72 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ y, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* rmean, float* rvar,  // (no restrict: `shift` may alias rmean)
                                                           float momentum, float eps, float* __restrict__ stat, float* __restrict__ pool_u,
-                                                          int N, int S, int C, int Cp, int chunks, const float* shift) {
+                                                          int N, int S, int C, int Cp, int chunks, const float* shift, int gdiv) {
+    // GROUPS (round 4): clips n / gdiv form one statistics group -- the two trunk passes of the reference's loss recipe (the clips and their
+    // warped copies) run as ONE 2N-clip pass, each half with its own batch statistics: stat[g][4][Cp], the running estimates updated group by
+    // group in order, exactly as two N-clip passes leave them.  gdiv = N: one group, the layout of rounds 1-3.
     __shared__ float red[2][16][16];
-    __shared__ float scsh[2][16];
+    __shared__ float scsh[2][PASN_MAX_GROUPS][16];
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool live = c < Cp;
+    const int G = N / gdiv;
     // the shift the partials were taken with: y[0][0][c] (bn_stats_partial_kernel), or `shift` (the stencils' fused statistics: the running
     // mean as it stood BEFORE this update -- read here ahead of the barrier, written below behind it), or 0
     float k = !live ? 0.0f : y ? (float)y[c] : (shift && c < C) ? shift[c] : 0.0f;  // `shift` holds C floats (padded channels: 0)
     asm volatile("" : "+v"(k));  // the value is taken HERE: `shift` may be the running mean this kernel updates behind the barrier
-    float a1 = 0.0f, a2 = 0.0f;
-    if (live) {
-        const int total = N * chunks;
+    for (int g = 0; g < G; ++g) {
+        float a1 = 0.0f, a2 = 0.0f;
+        if (live) {
+            const int lo = g * gdiv * chunks, hi = lo + gdiv * chunks;
 #pragma unroll 8
-        for (int i = part; i < total; i += 16) {
-            const float* p = ws + (size_t)i * 2 * Cp + c;
-            a1 += p[0];
-            a2 += p[Cp];
-        }
-    }
-    red[0][part][cl] = a1;
-    red[1][part][cl] = a2;
-    __syncthreads();
-    if (part == 0) {
-        float t1 = 0.0f, t2 = 0.0f;
-        for (int q = 0; q < 16; ++q) {
-            t1 += red[0][q][cl];
-            t2 += red[1][q][cl];
-        }
-        float mean = 0.0f, invstd = 0.0f, sc = 0.0f, sh = 0.0f;
-        if (live && c < C) {
-            const float R = (float)N * (float)S;
-            const float m = t1 / R;
-            const float var = fmaxf(t2 / R - m * m, 0.0f);
-            mean = k + m;
-            invstd = 1.0f / sqrtf(var + eps);
-            const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-            sc = g * invstd;
-            sh = b - mean * sc;
-            if (rmean) {
-                rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
-                rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (R / fmaxf(R - 1.0f, 1.0f));
+            for (int i = lo + part; i < hi; i += 16) {
+                const float* p = ws + (size_t)i * 2 * Cp + c;
+                a1 += p[0];
+                a2 += p[Cp];
             }
         }
-        if (live) {
-            stat[c] = mean;
-            stat[Cp + c] = invstd;
-            stat[2 * Cp + c] = sc;
-            stat[3 * Cp + c] = sh;
+        if (g) __syncthreads();  // the previous group's totals have been read
+        red[0][part][cl] = a1;
+        red[1][part][cl] = a2;
+        __syncthreads();
+        if (part == 0) {
+            float t1 = 0.0f, t2 = 0.0f;
+            for (int q = 0; q < 16; ++q) {
+                t1 += red[0][q][cl];
+                t2 += red[1][q][cl];
+            }
+            float mean = 0.0f, invstd = 0.0f, sc = 0.0f, sh = 0.0f;
+            if (live && c < C) {
+                const float R = (float)gdiv * (float)S;
+                const float m = t1 / R;
+                const float var = fmaxf(t2 / R - m * m, 0.0f);
+                mean = k + m;
+                invstd = 1.0f / sqrtf(var + eps);
+                const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+                sc = gm * invstd;
+                sh = bt - mean * sc;
+                if (rmean) {
+                    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (R / fmaxf(R - 1.0f, 1.0f));
+                }
+            }
+            if (live) {
+                float* st = stat + (size_t)g * 4 * Cp;
+                st[c] = mean;
+                st[Cp + c] = invstd;
+                st[2 * Cp + c] = sc;
+                st[3 * Cp + c] = sh;
+            }
+            scsh[0][g][cl] = sc;
+            scsh[1][g][cl] = sh;
         }
-        scsh[0][cl] = sc;
-        scsh[1][cl] = sh;
     }
     if (pool_u == nullptr) return;
     __syncthreads();
     if (!live) return;
-    const float sc = scsh[0][cl], sh = scsh[1][cl];
     for (int n = part; n < N; n += 16) {
+        const float sc = scsh[0][n / gdiv][cl], sh = scsh[1][n / gdiv][cl];
         float b1 = 0.0f;
         const float* p = ws + (size_t)n * chunks * 2 * Cp + c;
 #pragma unroll 4
@@ -187,10 +197,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ stat, const T* __restrict__ res,
                                                              const float* __restrict__ gate, T* __restrict__ a, int S, int Cp, int CG,
-                                                             int LPR, int rows_per_chunk, int act) {
+                                                             int LPR, int rows_per_chunk, int act, int gdiv) {
     const int n = blockIdx.y, ch = blockIdx.x;
     const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
     if (cg >= CG || rl >= RL) return;
+    stat += (size_t)(n / gdiv) * 4 * Cp;  // this clip's statistics group
     float sc[8], sh[8], g[8];
     load8(stat + 2 * Cp + cg * 8, sc);
     load8(stat + 3 * Cp + cg * 8, sh);
@@ -239,9 +250,10 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
                                                         const T* __restrict__ res, const float* __restrict__ gate, const float* __restrict__ add,
                                                         float* __restrict__ ws, int S, int Cp, int CG, int LPR, int rows_per_chunk,
-                                                        int chunks, int act, int write_back) {
+                                                        int chunks, int act, int write_back, int gdiv) {
     __shared__ float red[256 * 8];
     const int n = blockIdx.y, ch = blockIdx.x;
+    stat += (size_t)(n / gdiv) * 4 * Cp;  // this clip's statistics group
     const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
     constexpr int W = MODE == 4 ? 3 : 2;
     constexpr int U = ROWS_U;
@@ -340,39 +352,47 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
     block_reduce_rows<W>(acc, red, ws + ((size_t)n * chunks + ch) * W * Cp, Cp, CG, LPR);
 }
 
-// totals of the mode 0 / 2 partials -> coef[2][Cp] = (sum d'/R, sum d' yhat / R), dgamma, dbeta (either may be NULL)
+// totals of the mode 0 / 2 partials -> coef[g][2][Cp] = (sum d'/R, sum d' yhat / R) per statistics group, dgamma, dbeta (either may be NULL)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ coef, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int N, int S, int C, int Cp, int chunks) {
+                                                              float* __restrict__ dbeta, int N, int S, int C, int Cp, int chunks, int gdiv) {
+    // per statistics group g (clips n / gdiv): coef[g][2][Cp]; dgamma / dbeta are the parameter's: summed over the groups in order
     __shared__ float red[2][16][16];
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool live = c < Cp;
-    float a1 = 0.0f, a2 = 0.0f;
-    if (live) {
-        const int total = N * chunks;
+    const int G = N / gdiv;
+    float dg = 0.0f, db = 0.0f;
+    for (int g = 0; g < G; ++g) {
+        float a1 = 0.0f, a2 = 0.0f;
+        if (live) {
+            const int lo = g * gdiv * chunks, hi = lo + gdiv * chunks;
 #pragma unroll 8
-        for (int i = part; i < total; i += 16) {
-            const float* p = ws + (size_t)i * 2 * Cp + c;
-            a1 += p[0];
-            a2 += p[Cp];
+            for (int i = lo + part; i < hi; i += 16) {
+                const float* p = ws + (size_t)i * 2 * Cp + c;
+                a1 += p[0];
+                a2 += p[Cp];
+            }
+        }
+        if (g) __syncthreads();
+        red[0][part][cl] = a1;
+        red[1][part][cl] = a2;
+        __syncthreads();
+        if (part == 0 && live) {
+            float b1 = 0.0f, b2 = 0.0f;
+            for (int q = 0; q < 16; ++q) {
+                b1 += red[0][q][cl];
+                b2 += red[1][q][cl];
+            }
+            const float R = (float)gdiv * (float)S;
+            coef[(size_t)g * 2 * Cp + c] = b1 / R;
+            coef[(size_t)g * 2 * Cp + Cp + c] = b2 / R;
+            dg += b2;
+            db += b1;
         }
     }
-    red[0][part][cl] = a1;
-    red[1][part][cl] = a2;
-    __syncthreads();
-    if (part == 0 && live) {
-        float b1 = 0.0f, b2 = 0.0f;
-        for (int q = 0; q < 16; ++q) {
-            b1 += red[0][q][cl];
-            b2 += red[1][q][cl];
-        }
-        const float R = (float)N * (float)S;
-        coef[c] = b1 / R;
-        coef[Cp + c] = b2 / R;
-        if (c < C) {
-            if (dgamma) dgamma[c] = b2;
-            if (dbeta) dbeta[c] = b1;
-        }
+    if (part == 0 && live && c < C) {
+        if (dgamma) dgamma[c] = dg;
+        if (dbeta) dbeta[c] = db;
     }
 }
 
@@ -380,10 +400,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
                                                            const float* __restrict__ coef, T* __restrict__ dy, int S, int Cp, int CG, int LPR,
-                                                           int rows_per_chunk, int act) {
+                                                           int rows_per_chunk, int act, int gdiv) {
     const int n = blockIdx.y, ch = blockIdx.x;
     const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
     if (cg >= CG || rl >= RL) return;
+    stat += (size_t)(n / gdiv) * 4 * Cp;  // this clip's statistics group
+    coef += (size_t)(n / gdiv) * 2 * Cp;
     constexpr int U = ROWS_U;
     float mean[8], invstd[8], sc[8], sh[8], m1[8], m2[8];
     load8(stat + cg * 8, mean);
@@ -427,8 +449,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ ws, int chunks, const float* __restrict__ pool_u,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, float* __restrict__ add, float* __restrict__ pn, int S, int C,
-                                                         int Cp, int Cse, const float* __restrict__ stat, float* __restrict__ ws3) {
+                                                         int Cp, int Cse, const float* __restrict__ stat, float* __restrict__ ws3, int gdiv) {
     extern __shared__ float sm[];
+    if (stat) stat += (size_t)(blockIdx.x / gdiv) * 4 * Cp;  // this clip's statistics group
     float* pool = sm;             // [C]
     float* ds = pool + C;         // [C]
     float* h = ds + C;            // [Cse]
@@ -657,6 +680,8 @@ using namespace pasn;
     PASN_REQUIRE((N) > 0 && (S) > 0 && (C) > 0 && (Cp) >= (C) && (Cp) % 8 == 0, "bad tensor extents");   \
     PASN_REQUIRE((Cp) <= 2048, "channel stride above 2048 is not covered")
 
+#define GROUPS_OK(N, groups) PASN_REQUIRE((groups) >= 1 && (groups) <= PASN_MAX_GROUPS && (N) % (groups) == 0, "statistics groups must divide the batch (1 .. 4)")
+
 extern "C" int pasn_train_chunks(int N, int S, int Cp) {
     if (N <= 0 || S <= 0 || Cp <= 0 || Cp % 8 || Cp > 2048) return 0;
     return row_geom(N, S, Cp).chunks;
@@ -665,7 +690,15 @@ extern "C" int pasn_train_chunks(int N, int S, int Cp) {
 extern "C" int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, float momentum, float eps, float* stat, float* pool_u, int N, int S, int C,
                                  int Cp, int dtype, void* stream) {
+    return pasn_bn_stats_fwd_g(y, ws, gamma, beta, running_mean, running_var, momentum, eps, stat, pool_u, N, S, C, Cp, dtype, 1, stream);
+}
+
+// ... with `groups` statistics groups of N / groups consecutive clips each: stat[groups][4][Cp]; running estimates updated group by group
+extern "C" int pasn_bn_stats_fwd_g(const void* y, float* ws, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* stat, float* pool_u, int N, int S, int C,
+                                   int Cp, int dtype, int groups, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
+    GROUPS_OK(N, groups);
     PASN_REQUIRE(y && ws && stat, "null pointer");
     PASN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean / running_var go together");
     const RowGeom g = row_geom(N, S, Cp);
@@ -674,11 +707,11 @@ extern "C" int pasn_bn_stats_fwd(const void* y, float* ws, const float* gamma, c
     if (dtype == PASN_BF16) {
         hipLaunchKernelGGL(bn_stats_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, ws, S, Cp, g.CG, g.LPR, g.rows_per_chunk, g.chunks);
         hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)y, gamma, beta, running_mean,
-                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr);
+                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr, N / groups);
     } else {
         hipLaunchKernelGGL(bn_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)y, ws, S, Cp, g.CG, g.LPR, g.rows_per_chunk, g.chunks);
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const float*)y, gamma, beta, running_mean,
-                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr);
+                           running_var, momentum, eps, stat, pool_u, N, S, C, Cp, g.chunks, (const float*)nullptr, N / groups);
     }
     return check_launch("bn_stats_fwd");
 }
@@ -702,7 +735,14 @@ extern "C" int pasn_dwconv3d_stats_rows(const pasn_conv_desc* d, int dtype) {
 extern "C" int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const float* scale, const float* bias, void* y, float* ws, const float* gamma, const float* beta,
                                        float* running_mean, float* running_var, float momentum, float eps, float* stat, float* pool_u,
                                        const pasn_conv_desc* d, int dtype, void* stream) {
+    return pasn_dwconv3d_stats_fwd_g(x, w, scale, bias, y, ws, gamma, beta, running_mean, running_var, momentum, eps, stat, pool_u, d, dtype, 1, stream);
+}
+
+extern "C" int pasn_dwconv3d_stats_fwd_g(const void* x, const float* w, const float* scale, const float* bias, void* y, float* ws, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float eps, float* stat, float* pool_u,
+                                         const pasn_conv_desc* d, int dtype, int groups, void* stream) {
     PASN_REQUIRE(x && w && scale && bias && y && ws && stat && d, "null pointer");
+    GROUPS_OK(d->N, groups);
     PASN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean / running_var go together");
     PASN_REQUIRE(d->act == PASN_ACT_NONE, "the training stencil writes the raw conv output");
     const int rows = pasn_dwconv3d_stats_rows(d, dtype);
@@ -719,7 +759,7 @@ extern "C" int pasn_dwconv3d_stats_fwd(const void* x, const float* w, const floa
     }
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel<__bf16>, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, (const __bf16*)nullptr, gamma, beta, running_mean,
-                       running_var, momentum, eps, stat, pool_u, d->N, S, d->Cout, Cp, rows, (const float*)running_mean);
+                       running_var, momentum, eps, stat, pool_u, d->N, S, d->Cout, Cp, rows, (const float*)running_mean, d->N / groups);
     return check_launch("dwconv3d_stats_fwd");
 }
 
@@ -749,33 +789,39 @@ extern "C" int pasn_dwconv3d_dgrad_reduce(const void* dy, const float* w_flipped
     const DwRedArgs rd = {y_prev, stat_prev, act_prev};
     const int rc = launch_dw_march(dy, w_flipped, scale, bias, dx, ws, *d, m, s, DwSeArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, 1, &rd);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, coef, dgamma, dbeta, d->N, S, d->Cout, Cp, rows);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, coef, dgamma, dbeta, d->N, S, d->Cout, Cp, rows, d->N);
     return check_launch("dwconv3d_dgrad_reduce");
 }
 
 extern "C" int pasn_affine_act_fwd(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S,
                                    int C, int Cp, int act, int dtype, void* stream) {
+    return pasn_affine_act_fwd_g(y, stat, residual, gate, a, N, S, C, Cp, act, dtype, 1, stream);
+}
+
+extern "C" int pasn_affine_act_fwd_g(const void* y, const float* stat, const void* residual, const float* gate, void* a, int N, int S,
+                                     int C, int Cp, int act, int dtype, int groups, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
+    GROUPS_OK(N, groups);
     PASN_REQUIRE(y && stat && a, "null pointer");
     const RowGeom g = row_geom(N, S, Cp);
     const dim3 grid(g.chunks, N);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16)
         hipLaunchKernelGGL(affine_act_fwd_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, stat, (const __bf16*)residual, gate, (__bf16*)a,
-                           S, Cp, g.CG, g.LPR, g.rows_per_chunk, act);
+                           S, Cp, g.CG, g.LPR, g.rows_per_chunk, act, N / groups);
     else
         hipLaunchKernelGGL(affine_act_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)y, stat, (const float*)residual, gate, (float*)a, S,
-                           Cp, g.CG, g.LPR, g.rows_per_chunk, act);
+                           Cp, g.CG, g.LPR, g.rows_per_chunk, act, N / groups);
     return check_launch("affine_act_fwd");
 }
 
 template <typename T>
 static void launch_grad_pass(int mode, void* d, const void* y, const float* stat, const void* res, const float* gate, const float* add,
-                             float* ws, int N, int S, int Cp, const RowGeom& g, int act, hipStream_t s) {
+                             float* ws, int N, int S, int Cp, const RowGeom& g, int act, hipStream_t s, int gdiv) {
     const dim3 grid(g.chunks, N);
 #define GP(M)                                                                                                                      \
     hipLaunchKernelGGL((grad_pass_kernel<T, M>), grid, dim3(256), 0, s, (T*)d, (const T*)y, stat, (const T*)res, gate, add, ws, S, Cp, g.CG, \
-                       g.LPR, g.rows_per_chunk, g.chunks, act, (int)(mode != 3))
+                       g.LPR, g.rows_per_chunk, g.chunks, act, (int)(mode != 3), gdiv)
     if (mode == 0 || mode == 3) GP(0);
     else if (mode == 1) GP(1);
     else if (mode == 4) GP(4);
@@ -786,7 +832,14 @@ static void launch_grad_pass(int mode, void* d, const void* y, const float* stat
 extern "C" int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const float* stat, const void* residual, const float* gate,
                                     const float* add, float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp,
                                     int act, int dtype, void* stream) {
+    return pasn_unit_bwd_reduce_g(mode, d, y, stat, residual, gate, add, ws, coef, dgamma, dbeta, N, S, C, Cp, act, dtype, 1, stream);
+}
+
+extern "C" int pasn_unit_bwd_reduce_g(int mode, void* d, const void* y, const float* stat, const void* residual, const float* gate,
+                                      const float* add, float* ws, float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp,
+                                      int act, int dtype, int groups, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
+    GROUPS_OK(N, groups);
     PASN_REQUIRE(mode >= 0 && mode <= 4, "mode must be 0 .. 4");
     PASN_REQUIRE(d && y && stat && ws, "null pointer");
     PASN_REQUIRE(mode == 1 || mode == 4 || coef, "coef is required for modes 0, 2 and 3");
@@ -794,26 +847,32 @@ extern "C" int pasn_unit_bwd_reduce(int mode, void* d, const void* y, const floa
     PASN_REQUIRE(mode != 3 || residual == nullptr, "mode 3 leaves d untouched: a residual branch needs the differentiated d of mode 0");
     const RowGeom g = row_geom(N, S, Cp);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == PASN_BF16) launch_grad_pass<__bf16>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s);
-    else launch_grad_pass<float>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s);
+    if (dtype == PASN_BF16) launch_grad_pass<__bf16>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s, N / groups);
+    else launch_grad_pass<float>(mode, d, y, stat, residual, gate, add, ws, N, S, Cp, g, act, s, N / groups);
     if (mode != 1 && mode != 4)
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, coef, dgamma, dbeta, N, S, C, Cp, g.chunks);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 16)), dim3(256), 0, s, ws, coef, dgamma, dbeta, N, S, C, Cp, g.chunks, N / groups);
     return check_launch("unit_bwd_reduce");
 }
 
 extern "C" int pasn_bn_bwd_apply(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp,
                                  int act, int dtype, void* stream) {
+    return pasn_bn_bwd_apply_g(d, y, stat, coef, dy, N, S, C, Cp, act, dtype, 1, stream);
+}
+
+extern "C" int pasn_bn_bwd_apply_g(const void* d, const void* y, const float* stat, const float* coef, void* dy, int N, int S, int C, int Cp,
+                                   int act, int dtype, int groups, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
+    GROUPS_OK(N, groups);
     PASN_REQUIRE(d && y && stat && coef && dy, "null pointer");
     const RowGeom g = row_geom(N, S, Cp);
     const dim3 grid(g.chunks, N);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)d, (const __bf16*)y, stat, coef, (__bf16*)dy, S, Cp,
-                           g.CG, g.LPR, g.rows_per_chunk, act);
+                           g.CG, g.LPR, g.rows_per_chunk, act, N / groups);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)d, (const float*)y, stat, coef, (float*)dy, S, Cp, g.CG,
-                           g.LPR, g.rows_per_chunk, act);
+                           g.LPR, g.rows_per_chunk, act, N / groups);
     return check_launch("bn_bwd_apply");
 }
 
@@ -829,7 +888,7 @@ extern "C" int pasn_se_gate_bwd(const float* ws, const float* pool_u, const floa
     const RowGeom g = row_geom(N, S, Cp);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), lds, s, ws, g.chunks, pool_u, w1, b1, w2, b2, add, pn, S, C, Cp, Cse, (const float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, N);
     const size_t len = 2 * (size_t)C * Cse + Cse + C;
     hipLaunchKernelGGL(se_sum_over_clips_kernel, dim3(ceil_div((long)len, 256)), dim3(256), 0, s, pn, dw1, db1, dw2, db2, N, C, Cse);
     return check_launch("se_gate_bwd");
@@ -839,35 +898,42 @@ extern "C" int pasn_se_gate_bwd(const float* ws, const float* pool_u, const floa
 // se_mlp_bwd_kernel left in chunk 0 of the mode-4 partials:  sum d'' = sum_n gate A1 + S add,  sum d'' yhat = sum_n gate A2 + add A3.
 __global__ __launch_bounds__(256) void se_bn_coef_kernel(const float* __restrict__ ws3, int chunks, const float* __restrict__ gate,
                                                          const float* __restrict__ add, float* __restrict__ coef, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, int N, int S, int C, int Cp) {
+                                                         float* __restrict__ dbeta, int N, int S, int C, int Cp, int gdiv) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Cp) return;
-    float b1 = 0.0f, b2 = 0.0f;
-    for (int n0 = 0; n0 < N; n0 += 8) {  // 8 clips' loads in flight, the sums in clip order
-        float q0[8], q1[8], q2[8], g[8], a[8];
+    float dg = 0.0f, db = 0.0f;
+    for (int lo = 0; lo < N; lo += gdiv) {  // one statistics group after the other
+        const int hi = lo + gdiv;
+        float b1 = 0.0f, b2 = 0.0f;
+        for (int n0 = lo; n0 < hi; n0 += 8) {  // 8 clips' loads in flight, the sums in clip order
+            float q0[8], q1[8], q2[8], g[8], a[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int n = min(n0 + u, N - 1);
-            const float* q = ws3 + (size_t)n * chunks * 3 * Cp + c;
-            q0[u] = q[0];
-            q1[u] = q[Cp];
-            q2[u] = q[2 * Cp];
-            g[u] = gate[(size_t)n * Cp + c];
-            a[u] = add[(size_t)n * Cp + c];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (n0 + u < N) {
-                b1 += fmaf(g[u], q0[u], (float)S * a[u]);
-                b2 += fmaf(g[u], q1[u], a[u] * q2[u]);
+            for (int u = 0; u < 8; ++u) {
+                const int n = min(n0 + u, hi - 1);
+                const float* q = ws3 + (size_t)n * chunks * 3 * Cp + c;
+                q0[u] = q[0];
+                q1[u] = q[Cp];
+                q2[u] = q[2 * Cp];
+                g[u] = gate[(size_t)n * Cp + c];
+                a[u] = add[(size_t)n * Cp + c];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (n0 + u < hi) {
+                    b1 += fmaf(g[u], q0[u], (float)S * a[u]);
+                    b2 += fmaf(g[u], q1[u], a[u] * q2[u]);
+                }
+        }
+        const float R = (float)gdiv * (float)S;
+        float* cf = coef + (size_t)(lo / gdiv) * 2 * Cp;
+        cf[c] = b1 / R;
+        cf[Cp + c] = b2 / R;
+        dg += b2;
+        db += b1;
     }
-    const float R = (float)N * (float)S;
-    coef[c] = b1 / R;
-    coef[Cp + c] = b2 / R;
     if (c < C) {
-        if (dgamma) dgamma[c] = b2;
-        if (dbeta) dbeta[c] = b1;
+        if (dgamma) dgamma[c] = dg;
+        if (dbeta) dbeta[c] = db;
     }
 }
 
@@ -876,10 +942,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restrict__ d, const T* __restrict__ y, const float* __restrict__ stat,
                                                               const float* __restrict__ coef, const float* __restrict__ gate,
                                                               const float* __restrict__ add, T* __restrict__ dy, int S, int Cp, int CG, int LPR,
-                                                              int rows_per_chunk) {
+                                                              int rows_per_chunk, int gdiv) {
     const int n = blockIdx.y, ch = blockIdx.x;
     const int cg = threadIdx.x % LPR, rl = threadIdx.x / LPR, RL = 256 / LPR;
     if (cg >= CG || rl >= RL) return;
+    stat += (size_t)(n / gdiv) * 4 * Cp;  // this clip's statistics group
+    coef += (size_t)(n / gdiv) * 2 * Cp;
     constexpr int U = ROWS_U;
     float mean[8], invstd[8], sc[8], m1[8], m2[8], g[8], ad[8];
     load8(stat + cg * 8, mean);
@@ -917,33 +985,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restric
 extern "C" int pasn_se_gate_bwd_stat(float* ws3, const float* pool_u, const float* stat, const float* gate, const float* w1, const float* b1,
                                      const float* w2, const float* b2, float* add, float* pn, float* dw1, float* db1, float* dw2, float* db2,
                                      float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int Cse, void* stream) {
+    return pasn_se_gate_bwd_stat_g(ws3, pool_u, stat, gate, w1, b1, w2, b2, add, pn, dw1, db1, dw2, db2, coef, dgamma, dbeta, N, S, C, Cp, Cse, 1, stream);
+}
+
+extern "C" int pasn_se_gate_bwd_stat_g(float* ws3, const float* pool_u, const float* stat, const float* gate, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, float* add, float* pn, float* dw1, float* db1, float* dw2, float* db2,
+                                       float* coef, float* dgamma, float* dbeta, int N, int S, int C, int Cp, int Cse, int groups, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
+    GROUPS_OK(N, groups);
     PASN_REQUIRE(Cse > 0 && ws3 && pool_u && stat && gate && w1 && b1 && w2 && b2 && add && pn && dw1 && db1 && dw2 && db2 && coef, "null pointer");
     const size_t lds = (2 * (size_t)C + 2 * Cse) * sizeof(float);
     PASN_REQUIRE(lds <= 64 * 1024, "squeeze-excite width above the LDS budget");
     const RowGeom g = row_geom(N, S, Cp);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), lds, s, (const float*)nullptr, g.chunks, pool_u, w1, b1, w2, b2, add, pn, S, C, Cp, Cse,
-                       stat, ws3);
+                       stat, ws3, N / groups);
     const size_t len = 2 * (size_t)C * Cse + Cse + C;
     hipLaunchKernelGGL(se_sum_over_clips_kernel, dim3(ceil_div((long)len, 256)), dim3(256), 0, s, pn, dw1, db1, dw2, db2, N, C, Cse);
-    hipLaunchKernelGGL(se_bn_coef_kernel, dim3(ceil_div(Cp, 256)), dim3(256), 0, s, ws3, g.chunks, gate, add, coef, dgamma, dbeta, N, S, C, Cp);
+    hipLaunchKernelGGL(se_bn_coef_kernel, dim3(ceil_div(Cp, 256)), dim3(256), 0, s, ws3, g.chunks, gate, add, coef, dgamma, dbeta, N, S, C, Cp, N / groups);
     return check_launch("se_gate_bwd_stat");
 }
 
 extern "C" int pasn_bn_bwd_apply_se(const void* d, const void* y, const float* stat, const float* coef, const float* gate, const float* add,
                                     void* dy, int N, int S, int C, int Cp, int dtype, void* stream) {
+    return pasn_bn_bwd_apply_se_g(d, y, stat, coef, gate, add, dy, N, S, C, Cp, dtype, 1, stream);
+}
+
+extern "C" int pasn_bn_bwd_apply_se_g(const void* d, const void* y, const float* stat, const float* coef, const float* gate, const float* add,
+                                      void* dy, int N, int S, int C, int Cp, int dtype, int groups, void* stream) {
     ROWS_ARGS_OK(N, S, C, Cp);
+    GROUPS_OK(N, groups);
     PASN_REQUIRE(d && y && stat && coef && gate && add && dy, "null pointer");
     const RowGeom g = row_geom(N, S, Cp);
     const dim3 grid(g.chunks, N);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASN_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_se_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)d, (const __bf16*)y, stat, coef, gate, add, (__bf16*)dy,
-                           S, Cp, g.CG, g.LPR, g.rows_per_chunk);
+                           S, Cp, g.CG, g.LPR, g.rows_per_chunk, N / groups);
     else
         hipLaunchKernelGGL(bn_bwd_apply_se_kernel<float>, grid, dim3(256), 0, s, (const float*)d, (const float*)y, stat, coef, gate, add, (float*)dy, S,
-                           Cp, g.CG, g.LPR, g.rows_per_chunk);
+                           Cp, g.CG, g.LPR, g.rows_per_chunk, N / groups);
     return check_launch("bn_bwd_apply_se");
 }
 

@@ -65,6 +65,17 @@ class TransformLoss(object):
         transformed_x = affine_warp(x, cfg["angle"], cfg["scale"])  # per-frame 2-D warp of (N,3,[T,]H,W)
         return self.compute_from_maps(occurrence_map, model.compute_occurence_map(transformed_x), cfg)
 
+    def paired_forward(self, x, model, config=None):
+        """The model's forward AND this term from ONE trunk pass over [x, warp(x)] (``model.forward_pair``): returns
+        ``((logits, similarity, occurrence_map), loss_term)``.  The affine parameters are drawn here, i.e. BEFORE the forward where
+        ``compute`` draws them after it; nothing in between consumes random numbers, so a seeded run sees the same transforms."""
+        if self.loss_weight == 0 or not hasattr(model, "forward_pair"):
+            out = model(x)
+            return out, (torch.zeros((), device=x.device) if self.loss_weight == 0 else self.compute(x, out[2], model, config))
+        cfg = config or get_affine_config()
+        out, occ_t = model.forward_pair(x, affine_warp(x, cfg["angle"], cfg["scale"]))
+        return out, self.compute_from_maps(out[2], occ_t, cfg)
+
     def compute_from_maps(self, occurrence_map, occurrence_map_transformed, config):
         """loss.py:302-320 once both sets of maps exist: ``occurrence_map_transformed`` = the model's maps of the warped clip (the
         caller may have produced them in the same pass as the originals: eval mode uses running statistics, so a 2N-clip batch of

@@ -402,6 +402,22 @@ class _XProtoHeadMixin:
     def compute_occurence_map(self, x: torch.Tensor) -> torch.Tensor:
         return self._xproto(x, 1)[2]
 
+    def forward_pair(self, x: torch.Tensor, x_transformed: torch.Tensor):
+        """``(forward(x), compute_occurence_map(x_transformed))`` of the reference's loss recipe (Video_XProtoNet_e2e.py:84 + loss.py:302) from
+        ONE pass over the 2N clips.  Eval mode: running statistics, so a 2N batch gives every clip what two N-clip passes give.  Train mode:
+        one compiled pass with TWO statistics groups (``train.TrainRunner`` mode 2) -- each half is normalised with its own batch statistics,
+        the running estimates move twice, in order, and ``num_batches_tracked`` by 2: the state two passes leave.  Both halves are differentiable;
+        the add-on path of the second half receives no gradient (its logits / similarities are not returned), as in the reference."""
+        if x.shape != x_transformed.shape:
+            raise ValueError("forward_pair takes the clips and their transformed copies: same shape")
+        nb = x.shape[0]
+        both = torch.cat([x, x_transformed])
+        if self.training:
+            logits, sim, occ = self._train_pass(both, 2)
+        else:
+            logits, sim, occ, _ = self._xproto(both, 0)
+        return (logits[:nb], sim[:nb], occ[:nb]), occ[nb:]
+
     def push_forward(self, x: torch.Tensor):
         if self.training:
             raise RuntimeError("push_forward runs in eval mode (the reference pushes under model.eval(): push_abs_revision.py:210)")

@@ -36,8 +36,11 @@ def _need_fp32_param(p: torch.Tensor, what: str) -> None:
 
 
 class TrainBuilder(PlanBuilder):
-    def __init__(self, device, dtype, in_dtype):
+    def __init__(self, device, dtype, in_dtype, groups: int = 1):
         super().__init__(device, dtype, in_dtype)
+        # statistics groups: the batch is `groups` runs of N / groups clips, each normalised with its own batch statistics (2: the clips and
+        # their warped copies of the reference's loss recipe in ONE pass -- TrainRunner mode 2)
+        self.groups = int(groups)
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[int, Act] = {}        # activation buffer id -> Act holding its gradient
         self.readers: Dict[int, int] = {}      # activation buffer id -> number of ops that consume it (conv input, residual, pool, head)
@@ -274,28 +277,29 @@ class TrainBuilder(PlanBuilder):
             fused_dw = kind == "dw" and dw_rows > 0
             chunks = dw_rows if fused_dw else int(lib.pasn_train_chunks(N, S, Cp))
             ws = self._new_buf(N * chunks * 2 * Cp * 4)
-            stat_buf = self._new_buf(4 * Cp * 4)
+            stat_buf = self._new_buf(self.groups * 4 * Cp * 4)
             pool_buf = self._new_buf(N * Cp * 4) if se is not None else None
             track = bool(norm.track_running_stats and norm.running_mean is not None)
             if track:
                 self.nbt.append(norm.num_batches_tracked)
             if fused_dw:
                 self._use(x.buf, y.buf, ws, stat_buf, pool_buf)
-                self._op(lib.pasn_dwconv3d_stats_fwd, B(x.buf), dw_w.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), B(ws), Pm(norm.weight),
+                self._op(lib.pasn_dwconv3d_stats_fwd_g, B(x.buf), dw_w.data_ptr(), one.data_ptr(), zero.data_ptr(), B(y.buf), B(ws), Pm(norm.weight),
                          Pm(norm.bias), Pm(norm.running_mean if track else None), Pm(norm.running_var if track else None), float(norm.momentum),
-                         float(norm.eps), B(stat_buf), B(pool_buf), dref, code)
+                         float(norm.eps), B(stat_buf), B(pool_buf), dref, code, self.groups)
             else:
                 self._use(y.buf, ws, stat_buf, pool_buf)
-                self._op(lib.pasn_bn_stats_fwd, B(y.buf), B(ws), Pm(norm.weight), Pm(norm.bias), Pm(norm.running_mean if track else None),
-                         Pm(norm.running_var if track else None), float(norm.momentum), float(norm.eps), B(stat_buf), B(pool_buf), N, S, C, Cp, code)
+                self._op(lib.pasn_bn_stats_fwd_g, B(y.buf), B(ws), Pm(norm.weight), Pm(norm.bias), Pm(norm.running_mean if track else None),
+                         Pm(norm.running_var if track else None), float(norm.momentum), float(norm.eps), B(stat_buf), B(pool_buf), N, S, C, Cp, code,
+                         self.groups)
             stat = B(stat_buf)
         elif not plain:
-            stat_t = torch.zeros(4, Cp, dtype=torch.float32, device=self.device)  # (mean 0, invstd 1, sc 1, sh = bias)
-            stat_t[1, :C] = 1.0
-            stat_t[2, :C] = 1.0
+            stat_t = torch.zeros(self.groups, 4, Cp, dtype=torch.float32, device=self.device)  # per group (mean 0, invstd 1, sc 1, sh = bias)
+            stat_t[:, 1, :C] = 1.0
+            stat_t[:, 2, :C] = 1.0
             if conv.bias is not None:
                 _need_fp32_param(conv.bias, "a conv bias")
-                self.refresh.append(lambda: stat_t[3, :C].copy_(conv.bias.detach()))
+                self.refresh.append(lambda: stat_t[:, 3, :C].copy_(conv.bias.detach().expand(self.groups, C)))
             self.keep.append(stat_t)
             stat = stat_t.data_ptr()
         if se is not None:
@@ -315,9 +319,9 @@ class TrainBuilder(PlanBuilder):
                 assert (residual.N, residual.positions, residual.Cp) == (N, S, Cp)
             rb = residual.buf if residual is not None else None
             self._use(y.buf, out.buf, rb, stat_buf, gate_buf)
-            self._op(lib.pasn_affine_act_fwd, B(y.buf), stat, B(rb), B(gate_buf), B(out.buf), N, S, C, Cp, actc, code)
+            self._op(lib.pasn_affine_act_fwd_g, B(y.buf), stat, B(rb), B(gate_buf), B(out.buf), N, S, C, Cp, actc, code, self.groups)
 
-        if norm is not None and se is None and residual is None and not plain:
+        if norm is not None and se is None and residual is None and not plain and self.groups == 1:
             # a consumer whose input gradient is a stencil launch (stride-1 depthwise dgrad) may take this unit's backward sums in that
             # launch: it leaves the coefficient buffer in hook["coef"], and backward() below then skips its own reduce pass
             self.red_hook[out.buf] = {"y_buf": y.buf, "stat": stat, "stat_buf": stat_buf, "actc": actc,
@@ -339,9 +343,9 @@ class TrainBuilder(PlanBuilder):
             if not plain:
                 chunks = int(lib.pasn_train_chunks(N, S, Cp))
                 ws = self._new_buf(N * chunks * 2 * Cp * 4)
-                coef = self._new_buf(2 * Cp * 4)
+                coef = self._new_buf(self.groups * 2 * Cp * 4)
                 rb = residual.buf if residual is not None else None
-                red = lib.pasn_unit_bwd_reduce
+                red = lib.pasn_unit_bwd_reduce_g
                 if norm is not None:
                     dg, db = self.Gof(norm.weight), self.Gof(norm.bias)
                 elif conv.bias is not None:
@@ -355,7 +359,7 @@ class TrainBuilder(PlanBuilder):
                     coef = hook["coef"]  # the consumer's fused dgrad already took the sums (and dgamma / dbeta)
                 elif se is None:
                     self._use(g.buf, y.buf, rb, stat_buf, ws, coef)
-                    self._op(red, 3 if lazy else 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
+                    self._op(red, 3 if lazy else 0, B(g.buf), B(y.buf), stat, B(rb), 0, 0, B(ws), B(coef), dg, db, N, S, C, Cp, actc, code, self.groups)
                 elif residual is None and not _lib.tuning_get("PASN_NO_SE_ANALYTIC"):
                     # squeeze-excite unit, ONE pass over (d, y): mode 4 leaves d' = d act'(.) and per-clip (sum d', sum d' yhat, sum yhat);
                     # the gate's gradient, the norm's coefficients and dgamma / dbeta follow from those per clip (d'' = d' gate + add is
@@ -367,33 +371,33 @@ class TrainBuilder(PlanBuilder):
                     ws3 = self._new_buf(N * chunks * 3 * Cp * 4)
                     o = [self.Gof(t, nullable=False) for t in (se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)]
                     self._use(g.buf, y.buf, stat_buf, gate_buf, ws3)
-                    self._op(red, 4, B(g.buf), B(y.buf), stat, 0, B(gate_buf), 0, B(ws3), 0, 0, 0, N, S, C, Cp, actc, code)
+                    self._op(red, 4, B(g.buf), B(y.buf), stat, 0, B(gate_buf), 0, B(ws3), 0, 0, 0, N, S, C, Cp, actc, code, self.groups)
                     self._use(ws3, pool_buf, stat_buf, gate_buf, addb, pn, coef)
-                    self._op(lib.pasn_se_gate_bwd_stat, B(ws3), B(pool_buf), stat, B(gate_buf), Pm(se.fc1.weight), Pm(se.fc1.bias),
-                             Pm(se.fc2.weight), Pm(se.fc2.bias), B(addb), B(pn), o[0], o[1], o[2], o[3], B(coef), dg, db, N, S, C, Cp, cse)
+                    self._op(lib.pasn_se_gate_bwd_stat_g, B(ws3), B(pool_buf), stat, B(gate_buf), Pm(se.fc1.weight), Pm(se.fc1.bias),
+                             Pm(se.fc2.weight), Pm(se.fc2.bias), B(addb), B(pn), o[0], o[1], o[2], o[3], B(coef), dg, db, N, S, C, Cp, cse, self.groups)
                 else:
                     cse = se.fc1.out_channels
                     addb = self._new_buf(N * Cp * 4)
                     pn = self._new_buf(int(lib.pasn_se_bwd_workspace_floats(N, C, cse)) * 4)
                     o = [self.Gof(t, nullable=False) for t in (se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)]
                     self._use(g.buf, y.buf, stat_buf, gate_buf, ws)
-                    self._op(red, 1, B(g.buf), B(y.buf), stat, 0, B(gate_buf), 0, B(ws), 0, 0, 0, N, S, C, Cp, actc, code)
+                    self._op(red, 1, B(g.buf), B(y.buf), stat, 0, B(gate_buf), 0, B(ws), 0, 0, 0, N, S, C, Cp, actc, code, self.groups)
                     self._use(ws, pool_buf, addb, pn)
                     self._op(lib.pasn_se_gate_bwd, B(ws), B(pool_buf), Pm(se.fc1.weight), Pm(se.fc1.bias), Pm(se.fc2.weight), Pm(se.fc2.bias),
                              B(addb), B(pn), o[0], o[1], o[2], o[3], N, S, C, Cp, cse)
                     self._use(g.buf, y.buf, stat_buf, gate_buf, addb, ws, coef)
-                    self._op(red, 2, B(g.buf), B(y.buf), stat, 0, B(gate_buf), B(addb), B(ws), B(coef), dg, db, N, S, C, Cp, actc, code)
+                    self._op(red, 2, B(g.buf), B(y.buf), stat, 0, B(gate_buf), B(addb), B(ws), B(coef), dg, db, N, S, C, Cp, actc, code, self.groups)
                 if residual is not None and res_live:
                     self.add_grad(residual, g)  # after mode 0, g is the gradient of the pre-activation sum
                 if not (x_live or w_live):
                     return  # only this unit's norm / bias / SE parameters were trainable: their gradients are out already
                 if norm is not None and se_analytic:
                     self._use(g.buf, y.buf, stat_buf, coef, gate_buf, addb)
-                    self._op(lib.pasn_bn_bwd_apply_se, B(g.buf), B(y.buf), stat, B(coef), B(gate_buf), B(addb), B(g.buf), N, S, C, Cp, code)
+                    self._op(lib.pasn_bn_bwd_apply_se_g, B(g.buf), B(y.buf), stat, B(coef), B(gate_buf), B(addb), B(g.buf), N, S, C, Cp, code, self.groups)
                 elif norm is not None:
                     dy = self.like(y) if residual is not None else g
                     self._use(g.buf, y.buf, stat_buf, coef, dy.buf)
-                    self._op(lib.pasn_bn_bwd_apply, B(g.buf), B(y.buf), stat, B(coef), B(dy.buf), N, S, C, Cp, actc if lazy else 0, code)
+                    self._op(lib.pasn_bn_bwd_apply_g, B(g.buf), B(y.buf), stat, B(coef), B(dy.buf), N, S, C, Cp, actc if lazy else 0, code, self.groups)
             elif not (x_live or w_live):
                 return
             # ---- weight gradient
@@ -636,7 +640,7 @@ class TrainPlan:
         self._events: Dict[int, "torch.cuda.Event"] = {}
         self.offsets = [None if b.external else b.offset for b in tb.bufs]
         self.in_buf, self.ext, self.gbuf = x_in.buf, ext, tb.gbuf
-        self.pslots, self.gsize, self.nbt = tb.pslots, tb.gsize, tb.nbt
+        self.pslots, self.gsize, self.nbt, self.groups = tb.pslots, tb.gsize, tb.nbt, tb.groups
         self.arena_bytes = arena_bytes
         self.naive_bytes = sum(b.nbytes for b in tb.bufs if not b.external)
         self.device, self.dtype = tb.device, tb.dtype
@@ -663,7 +667,7 @@ class TrainPlan:
             for r in self.refresh:
                 r()
             if self.nbt:
-                torch._foreach_add_(self.nbt, 1)
+                torch._foreach_add_(self.nbt, self.groups)
         self._pack_weights(_lib.current_stream())
         arena = torch.empty(self.arena_bytes + ALIGN, dtype=torch.uint8, device=x.device)
         ptrs = self._ptrs(arena)
@@ -751,7 +755,9 @@ class TrainRunner:
 
     def __init__(self, model, x: torch.Tensor, mode: int, head: str = "B"):
         dtype = model._dtype()
-        tb = TrainBuilder(x.device, dtype, x.dtype)
+        # mode 2 (head B): mode 0 over [clips, warped clips] -- two statistics groups, the first half's (logits, similarity, occurrence map)
+        # and the second half's occurrence map are what the reference's two passes (forward + compute_occurence_map) return
+        tb = TrainBuilder(x.device, dtype, x.dtype, groups=2 if mode == 2 else 1)
         x_in = tb.input(tuple(x.shape))
         trunk = model.cnn_backbone if head == "B" else model.features
         feat = trunk.build_train(tb, x_in)
@@ -761,7 +767,7 @@ class TrainRunner:
         if head == "B":
             ext = {n: tb._new_buf(0, external=True) for n in ("occ", "feat", "sim", "logits", "dlogits", "dsim", "docc")}
             z = None
-            if mode == 0:
+            if mode in (0, 2):
                 z = feat
                 for conv, act in model.add_on_layers._steps():
                     z = tb.unit(z, conv, None, act)
@@ -769,8 +775,8 @@ class TrainRunner:
             for conv, act in model.occurrence_module._steps():
                 r = tb.unit(r, conv, None, act)
             tb.xproto_tail(z, r, model, ext)
-            self.out_names = ("logits", "sim", "occ") if mode == 0 else ("occ",)
-            self.grad_names = ("dlogits", "dsim", "docc") if mode == 0 else ("docc",)
+            self.out_names = ("logits", "sim", "occ") if mode in (0, 2) else ("occ",)
+            self.grad_names = ("dlogits", "dsim", "docc") if mode in (0, 2) else ("docc",)
         else:
             ext = {n: tb._new_buf(0, external=True) for n in ("min_d", "logits", "dlogits", "dmin")}
             z = feat
@@ -787,7 +793,7 @@ class TrainRunner:
         if self.head == "A":
             return {"logits": torch.empty((self.N, K), dtype=f32, device=dev), "min_d": torch.empty((self.N, P), dtype=f32, device=dev)}
         outs = {"occ": torch.empty((self.N, P, 1) + self.spatial, dtype=f32, device=dev)}
-        if self.mode == 0:
+        if self.mode in (0, 2):
             outs["feat"] = torch.empty((self.N, P, D), dtype=f32, device=dev)
             outs["sim"] = torch.empty((self.N, P), dtype=f32, device=dev)
             outs["logits"] = torch.empty((self.N, K), dtype=f32, device=dev)
@@ -801,7 +807,7 @@ class TrainRunner:
                 tensors["dlogits"] = torch.zeros_like(outs["logits"])
             tensors.setdefault("dmin", None)
             return tensors
-        if self.mode == 0 and tensors.get("dlogits") is None:
+        if self.mode in (0, 2) and tensors.get("dlogits") is None:
             tensors["dlogits"] = torch.zeros_like(outs["logits"])
         if self.mode == 1:
             tensors.setdefault("dlogits", None)

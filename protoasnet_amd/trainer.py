@@ -245,7 +245,9 @@ class DPTrainer:
                                        "must bring the same number (shard with a DistributedSampler(drop_last=True) or equal file lists)")
             if mode != "train":
                 self.sync_norm_buffers()
-        warp_in_batch = mode != "train" and self.Trans_occurrence.loss_weight != 0
+        # the reference's second trunk pass (loss.py:302) rides in the first one's launch list: eval epochs on running statistics, training
+        # epochs with two statistics groups (model.forward_pair; PASN_NO_TRAIN_PAIR=1: two passes)
+        warp_in_batch = self.Trans_occurrence.loss_weight != 0 and (mode != "train" or (hasattr(self.model, "forward_pair") and os.environ.get("PASN_NO_TRAIN_PAIR") != "1"))
         with torch.set_grad_enabled(mode == "train"):
             for i, sample in enumerate(loader):
                 inp = sample["cine"].to(self.device, non_blocking=True)
@@ -253,9 +255,13 @@ class DPTrainer:
                 if warp_in_batch:  # the reference's second trunk pass (loss.py:302) shares the launch list of the first
                     cfg = losses.get_affine_config()
                     nb = inp.shape[0]
-                    logit, similarities, occurrence_map = self.model(torch.cat([inp, losses.affine_warp(inp, cfg["angle"], cfg["scale"])]))
-                    occ_t = occurrence_map[nb:]
-                    logit, similarities, occurrence_map = logit[:nb], similarities[:nb], occurrence_map[:nb]
+                    warped = losses.affine_warp(inp, cfg["angle"], cfg["scale"])
+                    if hasattr(self.model, "forward_pair"):
+                        (logit, similarities, occurrence_map), occ_t = self.model.forward_pair(inp, warped)
+                    else:
+                        logit, similarities, occurrence_map = self.model(torch.cat([inp, warped]))
+                        occ_t = occurrence_map[nb:]
+                        logit, similarities, occurrence_map = logit[:nb], similarities[:nb], occurrence_map[:nb]
                     loss, terms = self.compute_loss(inp, target, logit, similarities, occurrence_map, occ_t, cfg)
                 else:
                     logit, similarities, occurrence_map = self.model(inp)

@@ -1213,3 +1213,61 @@ def test_cfg3_full_size_train_step_bf16_tracks_fp32():
                         f"(name, cos, max|g| fp32, bf16): {bigcos}; lowest {per[:4]}; sim diff {float((outs['bf16'][1] - outs['f32'][1]).abs().max()):.3g}")
     for k, v in stats["f32"].items():
         assert float((stats["bf16"][k] - v).abs().max()) <= 1e-2 * (float(v.abs().max()) + 1e-6) + 1e-4, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_paired_pass_equals_forward_plus_compute_occurence_map(dtype):
+    """model.forward_pair(x, x_w) in train mode -- ONE compiled pass over [x, x_w] with two statistics groups (TrainRunner mode 2) -- against the
+    reference's two passes, model(x) then model.compute_occurence_map(x_w) (Video_XProtoNet_e2e.py:84, loss.py:302), on models with identical
+    weights: outputs, every parameter gradient of the summed loss, the running statistics (updated twice, in order) and num_batches_tracked.
+    Each half sees only its own batch statistics: the same numbers up to the fp32 summation order (fp32 run) / bf16 storage (bf16 run)."""
+    import copy
+
+    shape, spatial = (4, 3, 8, 96, 96), (8, 3, 3)
+    m1 = _train_model(kink_free=True)
+    m2 = copy.deepcopy(m1)
+    if dtype == torch.bfloat16:
+        m1.set_compute_dtype(torch.bfloat16)
+        m2.set_compute_dtype(torch.bfloat16)
+    x = synth.echo_clips(shape).to(DEV)
+    xw = torch.roll(x, shifts=(3, -5), dims=(3, 4)) * 0.8 + 0.05  # a different clip distribution: different batch statistics per half
+    wl, ws, wo = (t.to(DEV) for t in _loss_weights(shape[0], 30, 3, spatial))
+    wo2 = wo.flip(0) * 0.7
+
+    logits, sim, occ = m1(x)
+    occ_w = m1.compute_occurence_map(xw)
+    ((logits * wl).sum() + (sim * ws).sum() + (occ * wo).sum() + (occ_w * wo2).sum()).backward()
+
+    (l2, s2, o2), ow2 = m2.forward_pair(x, xw)
+    ((l2 * wl).sum() + (s2 * ws).sum() + (o2 * wo).sum() + (ow2 * wo2).sum()).backward()
+
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for a, b, name in ((l2, logits, "logits"), (s2, sim, "similarity"), (o2, occ, "occurrence_map"), (ow2, occ_w, "occurrence_map of the second half")):
+        _rel(a, b, tol, name)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        if "num_batches_tracked" in k:
+            assert int(sd1[k]) == int(sd2[k]) == 2, k
+        elif "running_" in k:
+            _rel(sd2[k], sd1[k], 1e-4 if dtype == torch.float32 else 2e-2, k)
+    gtol = 2e-3 if dtype == torch.float32 else 5e-2
+    g1 = {n: p.grad for n, p in m1.named_parameters()}
+    errs = []
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert (p1.grad is None) == (p2.grad is None), n1
+        if p1.grad is not None:
+            scale = float(p1.grad.abs().max()) + 1e-12
+            sib = g1.get(n1[:-4] + "weight") if n1.endswith(".bias") else None
+            if sib is not None and sib.shape == p1.grad.shape:
+                scale = max(scale, float(sib.abs().max()))  # dbeta lives on the scale of its sibling dgamma (a norm in front of another norm: ~0)
+            if dtype == torch.float32:
+                err = float((p1.grad - p2.grad).abs().max()) / scale
+            else:  # bf16 storage of every activation and gradient, two summation orders: compare in the L2 sense (single entries of the stem's
+                err = float((p1.grad - p2.grad).norm()) / (float(p1.grad.norm()) + scale)  # gradient move by 8 % of the largest one)
+            errs.append((err, n1))
+    if dtype == torch.float32:
+        assert max(errs)[0] < gtol, f"paired-pass gradient off by {max(errs)[0]:.2e} of its scale: {max(errs)[1]}"
+    else:  # per tensor the two bf16 runs differ as two bf16 evaluations of one network do (measured: median 5 %, worst 17 % in the L2 sense, i.e.
+        # direction cosines 0.999 / 0.985 -- the bf16-vs-fp32 tests of this file ask 0.9 per tensor)
+        med = sorted(e for e, _ in errs)[len(errs) // 2]
+        assert med < 8e-2 and max(errs)[0] < 0.3, f"paired-pass gradients (bf16): median {med:.2e}, worst {max(errs)}"

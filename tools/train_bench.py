@@ -34,7 +34,7 @@ def main(argv=None):
     ap.add_argument("--arch", default="x3d_s")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--per-op", default="", help="write per-launch device times of one step to this file")
-    ap.add_argument("--loss", default="reference", choices=["reference", "simple"])
+    ap.add_argument("--loss", default="reference", choices=["reference", "reference_two_passes", "simple"])
     args = ap.parse_args(argv)
     import bench  # repo root: the rank launcher / process-group set-up shared with the forward benchmark
 
@@ -71,11 +71,16 @@ def main(argv=None):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        logits, sim, occ = model(x)
-        if args.loss == "reference":
+        if args.loss == "reference":  # the transform term's second trunk pass in the forward's launch list (model.forward_pair)
+            (logits, sim, occ), t_loss = trans.paired_forward(x, model)
+            loss = (ce.compute(logits, labels) + cluster.compute(sim, labels) + separation.compute(sim, labels)
+                    + t_loss + fc_l1.compute(model.last_layer.weight))
+        elif args.loss == "reference_two_passes":  # ... as a second pass (model.compute_occurence_map, loss.py:302)
+            logits, sim, occ = model(x)
             loss = (ce.compute(logits, labels) + cluster.compute(sim, labels) + separation.compute(sim, labels)
                     + trans.compute(x, occ, model) + fc_l1.compute(model.last_layer.weight))
         else:
+            logits, sim, occ = model(x)
             own = ident[:, labels].t()  # (N, P): prototypes of the clip's class
             loss = F.cross_entropy(logits, labels) + 1e-3 * occ.abs().mean() + 0.1 * ((1 - sim) * own).sum(1).mean()
         loss.backward()
@@ -110,7 +115,7 @@ def main(argv=None):
             step()
         with open(os.environ["PASN_TB_TORCHPROF"], "w") as fh:
             fh.write(prof.key_averages(group_by_stack_n=4).table(sort_by="self_cpu_time_total", row_limit=60, max_name_column_width=40))
-    runner = next(r for r in model._train_runners.values() if r.mode == 0)
+    runner = next(r for r in model._train_runners.values() if r.mode == (2 if args.loss == 'reference' else 0))
     roofline = per_entry = None
     if rank == 0:
         # one more step with every launch of the first-pass plan bracketed by HIP events on the launch stream: device time per C-ABI entry
