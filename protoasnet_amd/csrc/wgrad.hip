@@ -695,15 +695,27 @@ static void launch_pw_wgrad_bf16(const void* x, const void* dy, float* dw, const
 constexpr int WT_KT = 128, WT_PITCH = WT_KT * 2 + 16;
 
 __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, float* __restrict__ dw,
-                                                            pasn_conv_desc d, int co_pairs, int ci_pairs, int rows_per_block) {
+                                                            pasn_conv_desc d, int co_pairs, int ci_pairs, int rows_per_block, int gy2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* At = lds;                          // [64 co channels][WT_PITCH]
     unsigned char* Bt = lds + (size_t)64 * WT_PITCH;  // [64 ci channels][WT_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5;
     const long R = (long)d.N * d.To * d.Ho * d.Wo;
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    const int cop = blockIdx.y / ci_pairs, cip = blockIdx.y % ci_pairs;
+    // Block -> (row range, tile group).  The gy tile groups of one row range read the same rows (each its own 64 + 64 channels of them): as
+    // blockIdx.y of a 2-D grid they ran a whole sweep over the rows apart, and every group fetched its rows from the fabric again -- 327 MB for
+    // a 125 MB layer at 216 <-> 96 channels, 3.5 TB/s of fabric traffic for 1.3 TB/s of algorithmic bytes.  1-D grid (gy2 > 0): workgroups
+    // b, b + 8, b + 16, ... share an XCD (round-robin dispatch), so the j-th block of XCD b % 8 takes tile group j % gy of row range
+    // (j / gy) * 8 + b % 8: the groups of a row range run back to back on ONE L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gy2 > 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        by = j % gy2;
+        bx = (j / gy2) * 8 + xcd;
+        if ((long)bx * rows_per_block >= R) return;  // (the grid is padded to whole groups of 8 row ranges)
+    }
+    const long r0 = (long)bx * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    const int cop = by / ci_pairs, cip = by % ci_pairs;
     const int co0 = cop * 64, ci0 = cip * 64;  // first channel of this block's two co / ci tiles
     // staging role: one 8-row x 8-channel patch per thread and step -- 16 row octets x (8 co + 8 ci channel groups)
     const int g = tid & 15, r8 = tid >> 4;
@@ -774,9 +786,11 @@ static bool pw_wgrad_tile(const void* x, const void* dy, float* dw, const pasn_c
     const long target = tune_dev("PASN_WGT_BLOCKS") ? atol(tune_dev("PASN_WGT_BLOCKS")) : 1024;
     long parts = std::max<long>(1, std::min<long>(target / gy + 1, R / (2 * WT_KT)));
     long rpb = (ceil_div(R, parts) + WT_KT - 1) / WT_KT * WT_KT;
-    const dim3 grid((unsigned)ceil_div(R, rpb), gy);
+    const long gx = ceil_div(R, rpb);
+    const bool xcd = !tune_is("PASN_WGT_XCD", '0');
+    const dim3 grid = xcd ? dim3((unsigned)(ceil_div(gx, 8L) * 8 * gy)) : dim3((unsigned)gx, gy);
     hipLaunchKernelGGL(pw_wgrad_tile_kernel, grid, dim3(256), (size_t)128 * WT_PITCH, s, (const __bf16*)x, (const __bf16*)dy, dw, d, co_pairs,
-                       ci_pairs, (int)rpb);
+                       ci_pairs, (int)rpb, xcd ? gy : 0);
     return true;
 }
 
