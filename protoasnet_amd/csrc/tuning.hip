@@ -45,6 +45,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_NO_HALO",          "route", "no halo-tile implicit GEMM (igemm_halo.hip)"},
     {"PASN_NO_IGEMM",         "route", "no direct-to-LDS implicit GEMM (igemm.hip)"},
     {"PASN_NO_PACK",          "route", "1: training weights packed by torch ops instead of the one-launch pack kernel (host side, train.py)"},
+    {"PASN_WGT_WIDE",         "geom",  "0: the wide pointwise weight gradient with one 32 x 32 tile per wave everywhere (no 1 x 2 / 2 x 1 tiles per wave along the wide side)"},
     {"PASN_WGT_XCD",          "geom",  "0: the wide pointwise weight gradient's tile groups as blockIdx.y (a sweep apart) instead of back to back on one XCD"},
     {"PASN_DWWG_MARCH2",      "route", "0: depthwise weight gradient by round 2's marching kernel instead of round 4's (wgrad.hip)"},
     {"PASN_DWWG_CH",          "geom",  "channels per thread of the depthwise weight-gradient march (4 default, 2)"},

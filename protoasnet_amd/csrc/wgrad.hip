@@ -694,15 +694,21 @@ static void launch_pw_wgrad_bf16(const void* x, const void* dy, float* dw, const
 // so one block's round trip hides under another's MFMAs), and 4 x 1024 atomics per block instead of 16 x 1024.
 constexpr int WT_KT = 128, WT_PITCH = WT_KT * 2 + 16;
 
+// COT x CIT tiles per WAVE (round 4): a block owns (2 COT) x (2 CIT) tiles.  (1, 1) stages 32 KB per 128-row step for 8 MFMAs per wave -- more than a
+// CU takes from L2 in the time; (1, 2) / (2, 1) stage 48 KB for 16 (one shared fragment read per two MFMAs) and halve the groups along the wide side.
+template <int COT, int CIT>
 __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, float* __restrict__ dw,
-                                                            pasn_conv_desc d, int co_pairs, int ci_pairs, int rows_per_block, int gy2) {
+                                                            pasn_conv_desc d, int co_groups, int ci_groups, int rows_per_block, int gy2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* At = lds;                          // [64 co channels][WT_PITCH]
-    unsigned char* Bt = lds + (size_t)64 * WT_PITCH;  // [64 ci channels][WT_PITCH]
+    constexpr int CA = 64 * COT, CB = 64 * CIT;       // channels of dy / x a block stages
+    constexpr int GA = CA / 8, GB = CB / 8, NG = GA + GB;  // 8-channel groups
+    constexpr int NP = (16 * NG + 255) / 256;         // 8-row x 8-channel patches per thread and step
+    unsigned char* At = lds;                          // [CA co channels][WT_PITCH]
+    unsigned char* Bt = lds + (size_t)CA * WT_PITCH;  // [CB ci channels][WT_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5;
     const long R = (long)d.N * d.To * d.Ho * d.Wo;
-    // Block -> (row range, tile group).  The gy tile groups of one row range read the same rows (each its own 64 + 64 channels of them): as
+    // Block -> (row range, tile group).  The gy tile groups of one row range read the same rows (each its own channels of them): as
     // blockIdx.y of a 2-D grid they ran a whole sweep over the rows apart, and every group fetched its rows from the fabric again -- 327 MB for
     // a 125 MB layer at 216 <-> 96 channels, 3.5 TB/s of fabric traffic for 1.3 TB/s of algorithmic bytes.  1-D grid (gy2 > 0): workgroups
     // b, b + 8, b + 16, ... share an XCD (round-robin dispatch), so the j-th block of XCD b % 8 takes tile group j % gy of row range
@@ -715,62 +721,95 @@ __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __rest
         if ((long)bx * rows_per_block >= R) return;  // (the grid is padded to whole groups of 8 row ranges)
     }
     const long r0 = (long)bx * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    const int cop = by / ci_pairs, cip = by % ci_pairs;
-    const int co0 = cop * 64, ci0 = cip * 64;  // first channel of this block's two co / ci tiles
-    // staging role: one 8-row x 8-channel patch per thread and step -- 16 row octets x (8 co + 8 ci channel groups)
-    const int g = tid & 15, r8 = tid >> 4;
-    const bool is_a = g < 8;
-    const int cg = is_a ? g : g - 8;
-    const int cp = is_a ? d.Cout_p : d.Cin_p;
-    const int ch = (is_a ? co0 : ci0) + cg * 8;
-    const bool ch_ok = ch < cp;  // a pair past the last tile: zeros
-    const __bf16* src = (is_a ? dy : x) + (ch_ok ? ch : 0);
-    unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * WT_PITCH + r8 * 16;
-    f32x16 acc;
+    const int cop = by / ci_groups, cip = by % ci_groups;
+    const int co0 = cop * CA, ci0 = cip * CB;  // first channel of this block's co / ci tiles
+    // staging roles: NP patches of 8 rows x 8 channels per thread and step; patch p = tid + 256 k -> channel group p % NG (fastest: a row's
+    // groups are contiguous in memory), row octet p / NG
+    const __bf16* src[NP];
+    unsigned char* dst[NP];
+    int cpp[NP], r8[NP];
+    bool pok[NP];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const int tco = wave >> 1, tci = wave & 1;  // this wave's tile inside the 2 x 2 group
+    for (int k = 0; k < NP; ++k) {
+        const int p = tid + 256 * k;
+        const int g = p % NG;
+        r8[k] = min(p / NG, 15);
+        const bool is_a = g < GA;
+        const int cg = is_a ? g : g - GA;
+        cpp[k] = is_a ? d.Cout_p : d.Cin_p;
+        const int ch = (is_a ? co0 : ci0) + cg * 8;
+        pok[k] = p < 16 * NG && ch < cpp[k];  // a group past the last tile, or no patch: zeros / nothing
+        src[k] = (is_a ? dy : x) + (pok[k] ? ch : 0);
+        dst[k] = p < 16 * NG ? (is_a ? At : Bt) + (size_t)(cg * 8) * WT_PITCH + r8[k] * 16 : nullptr;
+    }
+    f32x16 acc[COT][CIT];
+#pragma unroll
+    for (int a = 0; a < COT; ++a)
+#pragma unroll
+        for (int b = 0; b < CIT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    const int tco = (wave >> 1) * COT, tci = (wave & 1) * CIT;  // this wave's first tile inside the block's group
     // The rows of step s + 1 are requested BEFORE the MFMAs of step s (register double buffer): a block's steps no longer each expose a
-    // memory round trip, so fewer, longer blocks do the job -- and every block ends in 4 x 1024 fp32 atomics on the same small matrix.
-    uint4 pre[8];
-    unsigned okbits = 0;  // applied after ALL loads are issued (a select next to a load serialises the batch)
+    // memory round trip, so fewer, longer blocks do the job -- and every block ends in fp32 atomics on the same small matrix.
+    uint4 pre[NP][8];
+    unsigned okbits[NP];  // applied after ALL loads are issued (a select next to a load serialises the batch)
     auto request = [&](long rb) {
-        okbits = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const long r = rb + r8 * 8 + i;
-            const bool ok = ch_ok && r < r1;
-            pre[i] = *reinterpret_cast<const uint4*>(src + (ok ? r : r0) * cp);
-            okbits |= (ok ? 1u : 0u) << i;
+        for (int k = 0; k < NP; ++k) {
+            okbits[k] = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long r = rb + r8[k] * 8 + i;
+                const bool ok = pok[k] && r < r1;
+                pre[k][i] = *reinterpret_cast<const uint4*>(src[k] + (ok ? r : r0) * cpp[k]);
+                okbits[k] |= (ok ? 1u : 0u) << i;
+            }
         }
     };
     if (r0 < r1) request(r0);
     for (long rb = r0; rb < r1; rb += WT_KT) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (!((okbits >> i) & 1u)) pre[i] = make_uint4(0, 0, 0, 0);
-        uint4 out[8];
-        transpose8x8_bf16(pre, out);
+        for (int k = 0; k < NP; ++k) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst + c * WT_PITCH) = out[c];
-        if (rb + WT_KT < r1) request(rb + WT_KT);  // in flight under the barrier and the 8 MFMAs below
+            for (int i = 0; i < 8; ++i)
+                if (!((okbits[k] >> i) & 1u)) pre[k][i] = make_uint4(0, 0, 0, 0);
+            uint4 out[8];
+            transpose8x8_bf16(pre[k], out);
+            if (dst[k] != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst[k] + c * WT_PITCH) = out[c];
+            }
+        }
+        if (rb + WT_KT < r1) request(rb + WT_KT);  // in flight under the barrier and the MFMAs below
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < WT_KT / 16; ++kk) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (size_t)(tco * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (size_t)(tci * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            bf16x8 a[COT], b[CIT];
+#pragma unroll
+            for (int i = 0; i < COT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(At + (size_t)((tco + i) * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
+#pragma unroll
+            for (int j = 0; j < CIT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bt + (size_t)((tci + j) * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
-    const int cig = ci0 + tci * 32 + m;
-    if (cig < d.Cin) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int cog = co0 + tco * 32 + acc_row(reg, h);
-            if (cog < d.Cout) unsafeAtomicAdd(dw + (size_t)cog * d.Cin + cig, acc[reg]);
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) {
+            const int cig = ci0 + (tci + j) * 32 + m;
+            if (cig < d.Cin) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int cog = co0 + (tco + i) * 32 + acc_row(reg, h);
+                    if (cog < d.Cout) unsafeAtomicAdd(dw + (size_t)cog * d.Cin + cig, acc[i][j][reg]);
+                }
+            }
         }
-    }
 }
 
 static bool pw_wgrad_tile(const void* x, const void* dy, float* dw, const pasn_conv_desc& d, hipStream_t s) {
@@ -779,18 +818,28 @@ static bool pw_wgrad_tile(const void* x, const void* dy, float* dw, const pasn_c
     const bool pointwise = d.kt * d.kh * d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
     const int co_tiles = ceil_div(d.Cout_p, 32), ci_tiles = ceil_div(d.Cin_p, 32);
     if (!pointwise || co_tiles + ci_tiles <= 6) return false;  // narrow layers: every block stages all channels anyway
-    const int co_pairs = ceil_div(co_tiles, 2), ci_pairs = ceil_div(ci_tiles, 2);
+    // tiles per wave along the wide side (PASN_WGT_WIDE=0: one tile per wave everywhere, the kernel of rounds 2-3)
+    const bool wide = !tune_is("PASN_WGT_WIDE", '0');
+    const int cot = wide && co_tiles >= 2 * ci_tiles ? 2 : 1, cit = wide && cot == 1 && ci_tiles >= 2 * co_tiles ? 2 : 1;
+    const int co_groups = ceil_div(co_tiles, 2 * cot), ci_groups = ceil_div(ci_tiles, 2 * cit);
     const long R = (long)d.N * d.To * d.Ho * d.Wo;
-    const int gy = co_pairs * ci_pairs;
+    const int gy = co_groups * ci_groups;
     // row partitions: about four blocks per CU in flight, at least two 128-row steps each
-    const long target = tune_dev("PASN_WGT_BLOCKS") ? atol(tune_dev("PASN_WGT_BLOCKS")) : 1024;
+    // (two tiles per wave: the same ~13 steps per block, i.e. half the blocks -- 57-59 us at 216 <-> 96 against 64-69 with 1024: r04_pwwg_xcd.txt)
+    const long target = tune_dev("PASN_WGT_BLOCKS") ? atol(tune_dev("PASN_WGT_BLOCKS")) : (cot * cit == 2 ? 512 : 1024);
     long parts = std::max<long>(1, std::min<long>(target / gy + 1, R / (2 * WT_KT)));
     long rpb = (ceil_div(R, parts) + WT_KT - 1) / WT_KT * WT_KT;
     const long gx = ceil_div(R, rpb);
     const bool xcd = !tune_is("PASN_WGT_XCD", '0');
     const dim3 grid = xcd ? dim3((unsigned)(ceil_div(gx, 8L) * 8 * gy)) : dim3((unsigned)gx, gy);
-    hipLaunchKernelGGL(pw_wgrad_tile_kernel, grid, dim3(256), (size_t)128 * WT_PITCH, s, (const __bf16*)x, (const __bf16*)dy, dw, d, co_pairs,
-                       ci_pairs, (int)rpb, xcd ? gy : 0);
+    const size_t lds = (size_t)64 * (cot + cit) * WT_PITCH;
+#define WGT(A, B)                                                                                                                       \
+    hipLaunchKernelGGL((pw_wgrad_tile_kernel<A, B>), grid, dim3(256), lds, s, (const __bf16*)x, (const __bf16*)dy, dw, d, co_groups, ci_groups, \
+                       (int)rpb, xcd ? gy : 0)
+    if (cot == 2) WGT(2, 1);
+    else if (cit == 2) WGT(1, 2);
+    else WGT(1, 1);
+#undef WGT
     return true;
 }
 
