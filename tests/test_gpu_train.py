@@ -107,6 +107,55 @@ def test_bn_unit_forward_backward(c, shape, offset):
     _rel(_ncl(dy, c), y2.grad, 2e-4, "dy (lazy differentiation)")
 
 
+@pytest.mark.parametrize("c,shape,groups", [(54, (4, 3, 9, 7), 2), (24, (6, 2, 8, 8), 3), (216, (2, 2, 5, 4), 2)])
+def test_bn_unit_statistics_groups(c, shape, groups):
+    """The `_g` entry points: `groups` runs of N / groups clips, each normalised with its own batch statistics (stat [groups][4][Cp],
+    coef [groups][2][Cp]), the running estimates updated group by group, dgamma / dbeta summed over the groups -- against autograd of `groups`
+    separate relu(batch_norm(.) + residual) calls on the sub-batches sharing gamma / beta / running buffers (what the reference's two trunk
+    passes do to a norm layer)."""
+    lib = _lib.lib()
+    n, t, h, w = shape
+    gd = n // groups
+    g = torch.Generator().manual_seed(c + groups)
+    y = torch.randn(n, c, t, h, w, generator=g) * 2
+    y = (y + torch.arange(n).view(n, 1, 1, 1, 1) // gd * 1.5).requires_grad_()  # groups with different means
+    res = torch.randn(n, c, t, h, w, generator=g).requires_grad_()
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_()
+    beta = torch.randn(c, generator=g).requires_grad_()
+    rm, rv = torch.zeros(c), torch.ones(c)
+    out = torch.cat([F.relu(F.batch_norm(y[k * gd:(k + 1) * gd], rm, rv, gamma, beta, True, 0.1, 1e-5) + res[k * gd:(k + 1) * gd]) for k in range(groups)])
+    da = torch.randn(out.shape, generator=g)
+    out.backward(da)
+    cp, S = (c + 7) // 8 * 8, t * h * w
+    yd, rd, dd = _cl(y.detach()), _cl(res.detach()), _cl(da)
+    chunks = lib.pasn_train_chunks(n, S, cp)
+    ws = torch.zeros(n * chunks * 2 * cp, device=DEV)
+    stat, coef = torch.zeros(groups * 4 * cp, device=DEV), torch.zeros(groups * 2 * cp, device=DEV)
+    gm, bt = gamma.detach().to(DEV), beta.detach().to(DEV)
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    _lib.check(lib.pasn_bn_stats_fwd_g(yd.data_ptr(), ws.data_ptr(), gm.data_ptr(), bt.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 0.1, 1e-5,
+                                       stat.data_ptr(), 0, n, S, c, cp, F32, groups, _st()))
+    a = torch.empty_like(yd)
+    _lib.check(lib.pasn_affine_act_fwd_g(yd.data_ptr(), stat.data_ptr(), rd.data_ptr(), 0, a.data_ptr(), n, S, c, cp, 1, F32, groups, _st()))
+    _rel(_ncl(a, c), out, 1e-4, "unit output")
+    _rel(rmd, rm, 1e-5, "running_mean after the groups' updates, in order")
+    _rel(rvd, rv, 1e-4, "running_var")
+    means = stat.view(groups, 4, cp)[:, 0, :c].cpu()
+    for k in range(groups):
+        _rel(means[k], y.detach()[k * gd:(k + 1) * gd].mean(dim=(0, 2, 3, 4)), 1e-5, f"mean of group {k}")
+    dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    _lib.check(lib.pasn_unit_bwd_reduce_g(0, dd.data_ptr(), yd.data_ptr(), stat.data_ptr(), rd.data_ptr(), 0, 0, ws.data_ptr(), coef.data_ptr(),
+                                          dg.data_ptr(), db.data_ptr(), n, S, c, cp, 1, F32, groups, _st()))
+    _rel(_ncl(dd, c), res.grad, 1e-5, "residual gradient")
+    dy = torch.empty_like(yd)
+    _lib.check(lib.pasn_bn_bwd_apply_g(dd.data_ptr(), yd.data_ptr(), stat.data_ptr(), coef.data_ptr(), dy.data_ptr(), n, S, c, cp, 0, F32, groups, _st()))
+    _rel(dg, gamma.grad, 1e-4, "dgamma (summed over the groups)")
+    _rel(db, beta.grad, 1e-4, "dbeta")
+    _rel(_ncl(dy, c), y.grad, 2e-4, "dy")
+    # an indivisible batch is refused
+    assert lib.pasn_affine_act_fwd_g(yd.data_ptr(), stat.data_ptr(), 0, 0, a.data_ptr(), n, S, c, cp, 1, F32, n + 1, _st()) != 0
+
+
 def test_se_unit_forward_backward():
     """BN -> squeeze-excite gate -> Swish (X3D block with SE): forward and the three backward passes vs autograd."""
     lib = _lib.lib()
