@@ -327,11 +327,11 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
                     act_grad_mul(dv, ug, act);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float yh = ok ? (v[j] - mean[j]) * invstd[j] : 0.0f;
+                        const float yc = ok ? v[j] - mean[j] : 0.0f;  // (x invstd once, behind the loop)
                         const float dd = ok ? dv[j] : 0.0f;
                         acc[0][j] += dd;
-                        acc[1][j] = fmaf(dd, yh, acc[1][j]);
-                        acc[W - 1][j] += yh;
+                        acc[1][j] = fmaf(dd, yc, acc[1][j]);
+                        acc[W - 1][j] += yc;
                     }
                 } else {
 #pragma unroll
@@ -342,10 +342,19 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
                     for (int j = 0; j < 8; ++j) {
                         const float dd = ok ? dv[j] : 0.0f;
                         acc[0][j] += dd;
-                        acc[1][j] = fmaf(dd, (v[j] - mean[j]) * invstd[j], acc[1][j]);
+                        acc[1][j] = fmaf(dd, v[j] - mean[j], acc[1][j]);  // sum d' (y - mean); x invstd once, behind the loop
                     }
                 }
                 if (write_back && ok) store8(d + o[u], dv);
+            }
+        }
+        // yhat = (y - mean) invstd: the factor invstd[c] is common to a thread's whole sum (the kernels are bound by vector issue, not bytes: 70-78 %
+        // of the SIMD cycles carry a vector instruction; one multiply per element and sum less)
+        if (MODE != 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[1][j] *= invstd[j];
+                if (MODE == 4) acc[W - 1][j] *= invstd[j];
             }
         }
     }
@@ -414,6 +423,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     load8(stat + 3 * Cp + cg * 8, sh);
     load8(coef + cg * 8, m1);
     load8(coef + Cp + cg * 8, m2);
+    // dy = sc (d' - m1 - (y - mean) invstd m2) = sc d' + bq (y - mean) + cq: one subtraction and two FMAs per element
+    float bq[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bq[j] = -sc[j] * invstd[j] * m2[j];
+        cq[j] = -sc[j] * m1[j];
+    }
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
     const size_t base = (size_t)n * S * Cp + cg * 8;
     for (int r = r0 + rl; r < r1; r += U * RL) {
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 act_grad_mul(dv, uu, act);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (dv[j] - m1[j] - (v[j] - mean[j]) * invstd[j] * m2[j]);
+            for (int j = 0; j < 8; ++j) dv[j] = fmaf(sc[j], dv[j], fmaf(bq[j], v[j] - mean[j], cq[j]));
             if (r + u * RL < r1) store8(dy + o[u], dv);
         }
     }
@@ -957,8 +973,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restric
     load8(coef + Cp + cg * 8, m2);
     load8(gate + (size_t)n * Cp + cg * 8, g);
     load8(add + (size_t)n * Cp + cg * 8, ad);
+    // dy = sc (d' gate + add - m1 - (y - mean) invstd m2) = sg d' + bq (y - mean) + cq
+    float sg[8], bq[8], cq[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ad[j] -= m1[j];
+    for (int j = 0; j < 8; ++j) {
+        sg[j] = sc[j] * g[j];
+        bq[j] = -sc[j] * invstd[j] * m2[j];
+        cq[j] = sc[j] * (ad[j] - m1[j]);
+    }
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
     const size_t base = (size_t)n * S * Cp + cg * 8;
     for (int r = r0 + rl; r < r1; r += U * RL) {
@@ -976,7 +998,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restric
             raw_to_f8<T>(yv[u].r, v);
             raw_to_f8<T>(dr[u].r, dv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dv[j] = sc[j] * (fmaf(dv[j], g[j], ad[j]) - (v[j] - mean[j]) * invstd[j] * m2[j]);
+            for (int j = 0; j < 8; ++j) dv[j] = fmaf(sg[j], dv[j], fmaf(bq[j], v[j] - mean[j], cq[j]));
             if (r + u * RL < r1) store8(dy + o[u], dv);
         }
     }
