@@ -53,6 +53,35 @@ __device__ __forceinline__ Raw8<T> load_raw8(const T* p) {
     return q;
 }
 
+// Rows through a buffer descriptor that ends where the block's chunk ends (num_records = r1 rows): a row past the chunk reads as zeros and its
+// store is dropped by the hardware -- no clamped row index, no 64-bit address per row, no select per element to keep such a row out of the sums
+// (these passes are bound by vector issue).  Offsets are 32-bit bytes inside ONE clip (the launchers check S * Cp * sizeof(T) < 2^31).
+typedef unsigned rb_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const T* clip, int rows, int Cp) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(clip), 0, (unsigned)rows * (unsigned)Cp * (unsigned)sizeof(T), 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ Raw8<T> load_raw8(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    Raw8<T> q;
+#pragma unroll
+    for (int i = 0; i < (int)((8 * sizeof(T)) / 16); ++i) {
+        const rb_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16 * i), 0, 0);
+        q.r[i] = uint4{v[0], v[1], v[2], v[3]};
+    }
+    return q;
+}
+__device__ __forceinline__ void store8(__amdgpu_buffer_rsrc_t rs, unsigned off, const float (&v)[8], const __bf16*) {
+    bf16x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rb_u32x4, a), rs, (int)off, 0, 0);
+}
+__device__ __forceinline__ void store8(__amdgpu_buffer_rsrc_t rs, unsigned off, const float (&v)[8], const float*) {
+    __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rs, (int)off + 16, 0, 0);
+}
+
 // Sum the per-thread 8-channel accumulators `acc[W][8]` over the row lanes of the block (fixed order) and store them
 // at out[w * Cp + cg*8 + j].
 template <int W>
@@ -207,18 +236,20 @@ __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const T* __restrict
     load8(stat + 3 * Cp + cg * 8, sh);
     if (gate) load8(gate + (size_t)n * Cp + cg * 8, g);
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
-    const size_t base = (size_t)n * S * Cp + cg * 8;
+    const size_t clip = (size_t)n * S * Cp;
+    const __amdgpu_buffer_rsrc_t yrs = row_rsrc(y + clip, r1, Cp), qrs = row_rsrc(res ? res + clip : y + clip, r1, Cp), ars = row_rsrc(a + clip, r1, Cp);
+    const unsigned rowb = (unsigned)Cp * (unsigned)sizeof(T), cgo = (unsigned)cg * 8u * (unsigned)sizeof(T);
     for (int r = r0 + rl; r < r1; r += ROWS_U * RL) {
-        size_t o[ROWS_U];
+        unsigned o[ROWS_U];
         Raw8<T> yv[ROWS_U], qv[ROWS_U];
 #pragma unroll
         for (int u = 0; u < ROWS_U; ++u) {
-            o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;  // past the chunk: the last row again, not stored
-            yv[u] = load_raw8(y + o[u]);
+            o[u] = (unsigned)(r + u * RL) * rowb + cgo;  // past the chunk: out of range -- zeros in, nothing out
+            yv[u] = load_raw8<T>(yrs, o[u]);
         }
         if (res) {
 #pragma unroll
-            for (int u = 0; u < ROWS_U; ++u) qv[u] = load_raw8(res + o[u]);
+            for (int u = 0; u < ROWS_U; ++u) qv[u] = load_raw8<T>(qrs, o[u]);
         }
 #pragma unroll
         for (int u = 0; u < ROWS_U; ++u) {
@@ -237,7 +268,7 @@ __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const T* __restrict
                 for (int j = 0; j < 8; ++j) v[j] *= g[j];
             }
             act_vec(v, act);
-            if (r + u * RL < r1) store8(a + o[u], v);
+            store8(ars, o[u], v, (const T*)nullptr);
         }
     }
 }
@@ -276,19 +307,22 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
         if (gate) load8(gate + (size_t)n * Cp + cg * 8, g);
         if (add) load8(add + (size_t)n * Cp + cg * 8, ad);
         const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
-        const size_t base = (size_t)n * S * Cp + cg * 8;
+        const size_t clip = (size_t)n * S * Cp;
+        const __amdgpu_buffer_rsrc_t yrs = row_rsrc(y + clip, r1, Cp), drs = row_rsrc(d + clip, r1, Cp),
+                                     qrs = row_rsrc((MODE == 0 && res) ? res + clip : y + clip, r1, Cp);
+        const unsigned rowb = (unsigned)Cp * (unsigned)sizeof(T), cgo = (unsigned)cg * 8u * (unsigned)sizeof(T);
         for (int r = r0 + rl; r < r1; r += U * RL) {
-            size_t o[U];
+            unsigned o[U];
             Raw8<T> yv[U], dr[U], qv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;  // past the chunk: the last row again, masked out of sums and stores
-                yv[u] = load_raw8(y + o[u]);
-                dr[u] = load_raw8(d + o[u]);
+                o[u] = (unsigned)(r + u * RL) * rowb + cgo;  // past the chunk: out of range -- zeros in, nothing out
+                yv[u] = load_raw8<T>(yrs, o[u]);
+                dr[u] = load_raw8<T>(drs, o[u]);
             }
             if (MODE == 0 && res) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) qv[u] = load_raw8(res + o[u]);
+                for (int u = 0; u < U; ++u) qv[u] = load_raw8<T>(qrs, o[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -316,7 +350,7 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
                     }
                     act_grad_mul(dv, ug, act);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[0][j] = fmaf(ok ? dv[j] : 0.0f, uu[j], acc[0][j]);
+                    for (int j = 0; j < 8; ++j) acc[0][j] = fmaf(dv[j], uu[j], acc[0][j]);  // (a row past the chunk: d = 0)
                 } else if (MODE == 4) {
                     // as mode 1, but the sums the squeeze-excite unit's norm needs are taken here, per clip: (sum d', sum d' yhat, sum yhat).
                     // d'' = d' gate + add[n] is affine in d' per clip, so sum d'' and sum d'' yhat follow without a second pass over (d, y)
@@ -327,25 +361,23 @@ __global__ __launch_bounds__(256) void grad_pass_kernel(T* __restrict__ d, const
                     act_grad_mul(dv, ug, act);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float yc = ok ? v[j] - mean[j] : 0.0f;  // (x invstd once, behind the loop)
-                        const float dd = ok ? dv[j] : 0.0f;
-                        acc[0][j] += dd;
-                        acc[1][j] = fmaf(dd, yc, acc[1][j]);
-                        acc[W - 1][j] += yc;
+                        const float yc = v[j] - mean[j];  // (x invstd once, behind the loop)
+                        acc[0][j] += dv[j];               // (a row past the chunk: d = 0, so d' = 0)
+                        acc[1][j] = fmaf(dv[j], yc, acc[1][j]);
+                        acc[W - 1][j] += ok ? yc : 0.0f;
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dv[j] = fmaf(dv[j], g[j], ad[j]);
+                    for (int j = 0; j < 8; ++j) dv[j] = ok ? fmaf(dv[j], g[j], ad[j]) : 0.0f;  // (add[n][c] != 0: a row past the chunk must stay out of the sums)
                 }
                 if (MODE != 1 && MODE != 4) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float dd = ok ? dv[j] : 0.0f;
-                        acc[0][j] += dd;
-                        acc[1][j] = fmaf(dd, v[j] - mean[j], acc[1][j]);  // sum d' (y - mean); x invstd once, behind the loop
+                        acc[0][j] += dv[j];  // (a row past the chunk: d' = 0)
+                        acc[1][j] = fmaf(dv[j], v[j] - mean[j], acc[1][j]);  // sum d' (y - mean); x invstd once, behind the loop
                     }
                 }
-                if (write_back && ok) store8(d + o[u], dv);
+                if (write_back) store8(drs, o[u], dv, (const T*)nullptr);
             }
         }
         // yhat = (y - mean) invstd: the factor invstd[c] is common to a thread's whole sum (the kernels are bound by vector issue, not bytes: 70-78 %
@@ -431,15 +463,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         cq[j] = -sc[j] * m1[j];
     }
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
-    const size_t base = (size_t)n * S * Cp + cg * 8;
+    const size_t clip = (size_t)n * S * Cp;
+    const __amdgpu_buffer_rsrc_t yrs = row_rsrc(y + clip, r1, Cp), drs = row_rsrc(d + clip, r1, Cp), ors = row_rsrc(dy + clip, r1, Cp);
+    const unsigned rowb = (unsigned)Cp * (unsigned)sizeof(T), cgo = (unsigned)cg * 8u * (unsigned)sizeof(T);
     for (int r = r0 + rl; r < r1; r += U * RL) {
-        size_t o[U];
+        unsigned o[U];
         Raw8<T> yv[U], dr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;
-            yv[u] = load_raw8(y + o[u]);
-            dr[u] = load_raw8(d + o[u]);
+            o[u] = (unsigned)(r + u * RL) * rowb + cgo;  // past the chunk: out of range -- zeros in, nothing out
+            yv[u] = load_raw8<T>(yrs, o[u]);
+            dr[u] = load_raw8<T>(drs, o[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -454,7 +488,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) dv[j] = fmaf(sc[j], dv[j], fmaf(bq[j], v[j] - mean[j], cq[j]));
-            if (r + u * RL < r1) store8(dy + o[u], dv);
+            store8(ors, o[u], dv, (const T*)nullptr);
         }
     }
 }
@@ -694,7 +728,8 @@ using namespace pasn;
 
 #define ROWS_ARGS_OK(N, S, C, Cp)                                                                         \
     PASN_REQUIRE((N) > 0 && (S) > 0 && (C) > 0 && (Cp) >= (C) && (Cp) % 8 == 0, "bad tensor extents");   \
-    PASN_REQUIRE((Cp) <= 2048, "channel stride above 2048 is not covered")
+    PASN_REQUIRE((Cp) <= 2048, "channel stride above 2048 is not covered");                                     \
+    PASN_REQUIRE((long)(S) * (Cp) * 4 < 2147483648L, "one clip's rows must stay below 2 GiB (32-bit offsets inside a clip)")
 
 #define GROUPS_OK(N, groups) PASN_REQUIRE((groups) >= 1 && (groups) <= PASN_MAX_GROUPS && (N) % (groups) == 0, "statistics groups must divide the batch (1 .. 4)")
 
@@ -982,15 +1017,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restric
         cq[j] = sc[j] * (ad[j] - m1[j]);
     }
     const int r0 = ch * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
-    const size_t base = (size_t)n * S * Cp + cg * 8;
+    const size_t clip = (size_t)n * S * Cp;
+    const __amdgpu_buffer_rsrc_t yrs = row_rsrc(y + clip, r1, Cp), drs = row_rsrc(d + clip, r1, Cp), ors = row_rsrc(dy + clip, r1, Cp);
+    const unsigned rowb = (unsigned)Cp * (unsigned)sizeof(T), cgo = (unsigned)cg * 8u * (unsigned)sizeof(T);
     for (int r = r0 + rl; r < r1; r += U * RL) {
-        size_t o[U];
+        unsigned o[U];
         Raw8<T> yv[U], dr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            o[u] = base + (size_t)min(r + u * RL, r1 - 1) * Cp;
-            yv[u] = load_raw8(y + o[u]);
-            dr[u] = load_raw8(d + o[u]);
+            o[u] = (unsigned)(r + u * RL) * rowb + cgo;  // past the chunk: out of range -- zeros in, nothing out
+            yv[u] = load_raw8<T>(yrs, o[u]);
+            dr[u] = load_raw8<T>(drs, o[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -999,7 +1036,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_se_kernel(const T* __restric
             raw_to_f8<T>(dr[u].r, dv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) dv[j] = fmaf(sg[j], dv[j], fmaf(bq[j], v[j] - mean[j], cq[j]));
-            if (r + u * RL < r1) store8(dy + o[u], dv);
+            store8(ors, o[u], dv, (const T*)nullptr);
         }
     }
 }
