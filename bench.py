@@ -646,8 +646,8 @@ def secondary(dev) -> dict:
             opt.step()
             return loss
 
-        sec = timed(step, 2, 4)
-        sec_two = timed(lambda: step(False), 2, 4)
+        sec = timed(step, 3, 10)  # (four timed steps read 46-48 ms for the same build; ten: +-0.3)
+        sec_two = timed(lambda: step(False), 2, 5)
         line = {"workload": "BASELINE config 3, per-GPU work: one training step (forward + the reference's loss recipe incl. the transform term's "
                             "second trunk pass + backward + Adam), X3D-S + prototype layer, 32x16x224x224", "value": round(32 / sec, 1),
                 "unit": "clips/s", "ms_per_step": round(sec * 1e3, 2),
