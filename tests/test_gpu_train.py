@@ -1264,6 +1264,51 @@ def test_cfg3_full_size_train_step_bf16_tracks_fp32():
         assert float((stats["bf16"][k] - v).abs().max()) <= 1e-2 * (float(v.abs().max()) + 1e-6) + 1e-4, k
 
 
+@pytest.mark.parametrize("cfg,shape,spatial,env", [(CFG_XPROTO, (4, 3, 96, 96), (3, 3), ""), (CFG_VIDEO_R2P1D, (2, 3, 8, 32, 32), (2, 4, 4), ""),
+                                                   (CFG_VIDEO_X3D, (4, 3, 8, 96, 96), (8, 3, 3), "PASN_NO_SE_ANALYTIC"),
+                                                   (CFG_VIDEO_X3D, (4, 3, 8, 96, 96), (8, 3, 3), "PASN_TRAIN_STREAMS")],
+                         ids=["xprotonet_resnet18", "video_r2plus1d", "x3d_se_three_pass_backward", "x3d_one_stream"])
+def test_paired_pass_other_trunks_and_routes(cfg, shape, spatial, env, monkeypatch):
+    """forward_pair against the two passes (fp32) on the reference's own trunks -- BatchNorm2d behind a max-pool, windowed dense 3-D convs -- and on
+    the X3D model with the three-pass squeeze-excite backward (modes 1 + 2: the per-clip `add` and the per-group coefficients meet in mode 2) and
+    with every launch on one stream."""
+    import copy
+
+    if env:
+        monkeypatch.setenv(env, "1")
+    m1 = _train_model(kink_free=True, cfg=cfg)
+    m2 = copy.deepcopy(m1)
+    n, P, K = shape[0], m1.num_prototypes, m1.num_classes
+    x = synth.echo_clips(shape).to(DEV)
+    xw = torch.roll(x, shifts=(3, -5), dims=(-2, -1)) * 0.8 + 0.05
+    wl, ws, wo = (t.to(DEV) for t in _loss_weights(n, P, K, spatial))
+    wo2 = wo.flip(0) * 0.7
+    logits, sim, occ = m1(x)
+    occ_w = m1.compute_occurence_map(xw)
+    ((logits * wl).sum() + (sim * ws).sum() + (occ * wo).sum() + (occ_w * wo2).sum()).backward()
+    (l2, s2, o2), ow2 = m2.forward_pair(x, xw)
+    ((l2 * wl).sum() + (s2 * ws).sum() + (o2 * wo).sum() + (ow2 * wo2).sum()).backward()
+    for a, b, name in ((l2, logits, "logits"), (s2, sim, "similarity"), (o2, occ, "occurrence_map"), (ow2, occ_w, "occurrence_map of the second half")):
+        _rel(a, b, 2e-4, name)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        if "num_batches_tracked" in k:
+            assert int(sd1[k]) == int(sd2[k]) == 2, k
+        elif "running_" in k:
+            _rel(sd2[k], sd1[k], 1e-4, k)
+    g1 = {nm: p.grad for nm, p in m1.named_parameters()}
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert (p1.grad is None) == (p2.grad is None), n1
+        if p1.grad is None:
+            continue
+        scale = float(p1.grad.abs().max()) + 1e-12
+        sib = g1.get(n1[:-4] + "weight") if n1.endswith(".bias") else None
+        if sib is not None and sib.shape == p1.grad.shape:
+            scale = max(scale, float(sib.abs().max()))
+        err = float((p1.grad - p2.grad).abs().max()) / scale
+        assert err < 2e-3, f"{n1}: paired-pass gradient off by {err:.2e} of its scale"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_paired_pass_equals_forward_plus_compute_occurence_map(dtype):
     """model.forward_pair(x, x_w) in train mode -- ONE compiled pass over [x, x_w] with two statistics groups (TrainRunner mode 2) -- against the
