@@ -311,7 +311,11 @@ int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, cons
  * images of a (clip, two frames) tile; results are bit-identical to those launches.
  *   x        : block input = residual, channels-last [N][T][7][7][d_a->Cin_p];   y : block output, same shape
  *   w_a, w_c : fragment-major (w_frag = 1); d_a->w_kc = Cin_p, d_c->w_kc = 32 * ceil(Cin_p / 32) (K zero-padded to an even number of steps)
- *   w_dw     : conv_b as the stencil's matrix-core operands (the table pasn_x3d_block_fwd takes); scale / bias: the folded norms
+ *   w_dw     : conv_b weights as the stencil's matrix-core operands: uint16 [ceil(Cp / 16)][2][64][8], row (16-channel tile, half, lane):
+ *              entry e = kt * 5 + j (half e >> 3, slot e & 7; entry 15 unused) = bf16 bits (round-to-nearest-even) of tap
+ *              kt * 9 + 2 j + (lane >> 5) of channel 16 tile + (lane & 15), for lanes with ((lane >> 3) & 1) == ((lane >> 4) & 1), a tap index
+ *              < 9 and a real channel; 0 otherwise -- the one possibly nonzero element per lane of the block-diagonal A operands that
+ *              pasn_dwconv3d_fwd's matrix-core kernel builds in its own prologue; scale / bias: the folded norms
  *   w_n ...  : the next block's conv_a in w_a's form and its output e_next [N][T][7][7][d_n->Cout_p]; all NULL (with d_n == NULL): none
  * _supported() == 0: issue the separate launches.
  */
@@ -336,31 +340,6 @@ int pasn_x3d_pe_fwd(const void* x, const void* w1, const float* scale1, const fl
                     void* y1, const pasn_conv_desc* d1, const void* w2, const float* scale2, const float* bias2, void* y2,
                     const pasn_conv_desc* d2, int dtype, void* stream);
 
-/*
- * The body of an X3D residual block WITHOUT squeeze-excite in ONE launch (bf16): conv_b (depthwise 3x3x3, stride 1, pad 1) + norm_b +
- * Swish -> conv_c (1x1x1) + norm_c + residual + ReLU -> the NEXT block's conv_a (1x1x1) + norm_a + ReLU (pytorchvideo's
- * BottleneckTransform / ResBlock as instantiated by the x3d trunks BASELINE.json names; the reference itself ships no X3D -- SURVEY 8a row
- * 5).  Replaces pasn_dwconv3d_fwd + pasn_conv3d_pair_fwd (or + two pasn_conv3d_fwd): the stencil's output (2.25x the block width) only
- * ever exists as a tile in LDS; results are bit-identical to those launches (same rounding points, same accumulation order).
- *   e        : this block's expanded activation, channels-last [N][T][H][W][d_dw->Cin_p] (what the previous launch's expand conv wrote)
- *   w_dw     : conv_b weights as the stencil's matrix-core operands: uint16 [ceil(Cp / 16)][2][64][8], row (16-channel tile, half, lane):
- *              entry e = kt * 5 + j (half e >> 3, slot e & 7; entry 15 unused) = bf16 bits (round-to-nearest-even) of tap
- *              kt * 9 + 2 j + (lane >> 5) of channel 16 tile + (lane & 15), for lanes with ((lane >> 3) & 1) == ((lane >> 4) & 1), a tap index
- *              < 9 and a real channel; 0 otherwise -- the one possibly nonzero element per lane of the block-diagonal A operands that
- *              pasn_dwconv3d_fwd's matrix-core kernel builds in its own prologue;
- *              scale_dw / bias_dw: folded norm_b [Cp], zero beyond the channels                          (d_dw->act = PASN_ACT_SWISH)
- *   w_c      : conv_c weights FRAGMENT-MAJOR (w_frag = 1) with K zero-padded to an EVEN number of 16-wide steps (d_c->w_kc = 32 *
- *              ceil(Cin_p / 32)); scale_c / bias_c: folded norm_c [d_c->w_rows]; residual: the block input [N][T][H][W][d_c->Cout_p]
- *   y        : the block output [N][T][H][W][d_c->Cout_p]                                                  (d_c->act = PASN_ACT_RELU)
- *   w_a ...  : the next block's conv_a in the same form (d_a->w_kc = 32 * ceil(d_c->Cout_p / 32)), its folded norm and its output
- *              e_next [N][T][H][W][d_a->Cout_p]; all NULL (with d_a == NULL) for the last block of a stage
- * _supported() == 0: issue the separate launches.
- */
-int pasn_x3d_block_supported(const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_a, int dtype);
-int pasn_x3d_block_fwd(const void* e, const void* w_dw, const float* scale_dw, const float* bias_dw, const void* w_c, const float* scale_c,
-                       const float* bias_c, const void* residual, void* y, const void* w_a, const float* scale_a, const float* bias_a,
-                       void* e_next, const pasn_conv_desc* d_dw, const pasn_conv_desc* d_c, const pasn_conv_desc* d_a, int dtype,
-                       void* stream);
 
 
 int pasn_xproto_head_splits(const pasn_xproto_desc* d);

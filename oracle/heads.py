@@ -43,17 +43,32 @@ def add_on_layers(sd, x: torch.Tensor, final_sigmoid: bool) -> torch.Tensor:
     return x
 
 
-def occurrence_map_abs(sd, x: torch.Tensor) -> torch.Tensor:
-    """``get_occurence_map_absolute_val``: conv-ReLU-conv-ReLU-conv(no bias), abs, unsqueeze(2).
+def occurrence_logits(sd, x: torch.Tensor) -> torch.Tensor:
+    """``self.occurrence_module(x)``: conv-ReLU-conv-ReLU-conv(no bias), (N, P, [T,] H, W).
 
-    Reference: src/models/Video_XProtoNet.py:42-62,106-109; src/models/XProtoNet.py:21-41,82-85.
+    Reference: src/models/Video_XProtoNet.py:42-62; src/models/XProtoNet.py:21-41.
     """
     idx = _chain_indices(sd, "occurrence_module")
     for j, i in enumerate(idx):
         x = _conv1x1(x, sd[f"occurrence_module.{i}.weight"], sd.get(f"occurrence_module.{i}.bias"))
         if j + 1 < len(idx):
             x = F.relu(x)
-    return torch.abs(x).unsqueeze(2)
+    return x
+
+
+def occurrence_map_abs(sd, x: torch.Tensor) -> torch.Tensor:
+    """``get_occurence_map_absolute_val``: the occurrence module, abs, unsqueeze(2).
+
+    Reference: src/models/Video_XProtoNet.py:106-109; src/models/XProtoNet.py:82-85.
+    """
+    return torch.abs(occurrence_logits(sd, x)).unsqueeze(2)
+
+
+def occurrence_map_softmaxed(sd, x: torch.Tensor) -> torch.Tensor:
+    """``get_occurence_map_softmaxed`` (src/models/XProtoNet.py:75-80): softmax over the flattened positions, unsqueeze(2)."""
+    om = occurrence_logits(sd, x)
+    n, p = om.shape[:2]
+    return torch.softmax(om.reshape(n, p, -1), dim=-1).reshape(om.shape).unsqueeze(2)
 
 
 # ------------------------------------------------------------------ head A (PPNet)

@@ -65,8 +65,6 @@ SIGNATURES = {
     "pasn_x3d_pe_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_int]),
     "pasn_x3d_pe_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, POINTER(ConvDesc)] + [c_void_p] * 4
                         + [POINTER(ConvDesc), c_int, c_void_p]),
-    "pasn_x3d_block_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), POINTER(ConvDesc), c_int]),
-    "pasn_x3d_block_fwd": (c_int, [c_void_p] * 13 + [POINTER(ConvDesc), POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_dwconv3d_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_se_pool_blocks": (c_int, [POINTER(ConvDesc), c_int]),
     "pasn_dwconv3d_variant": (c_int, [POINTER(ConvDesc), c_int]),
@@ -185,9 +183,20 @@ def current_stream() -> int:
 
 
 # ---- tuning switches (csrc/tuning.h): the library reads the PASN_* environment ONCE ----------------------------------------------------
+_TUNING_EPOCH = [0]
+
+
 def tuning_reload() -> None:
-    """Take a new snapshot of the PASN_* environment (after ``os.environ`` / ``monkeypatch.setenv`` changed it: tests, A/B tools)."""
+    """Take a new snapshot of the PASN_* environment (after ``os.environ`` / ``monkeypatch.setenv`` changed it: tests, A/B tools).
+    Bumps ``tuning_epoch()``: compiled plans, training runners and captured graphs are keyed on it, because their workspaces were sized
+    under the geometry switches of the snapshot they were built with (PASN_TRAIN_BLOCKS, PASN_DWWG_BLOCKS ...) while the launchers
+    recompute the geometry per launch -- a plan from an older snapshot is rebuilt instead of replayed."""
     lib().pasn_tuning_reload()
+    _TUNING_EPOCH[0] += 1
+
+
+def tuning_epoch() -> int:
+    return _TUNING_EPOCH[0]
 
 
 def tuning_get(name: str):

@@ -111,12 +111,10 @@ class ResNet18Features(_plan.HipTrunk):
         x = pb.maxpool(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
         for li in range(1, 5):
             for blk in getattr(self, f"layer{li}"):
-                identity, branch = x, None
+                identity = x
                 if blk.downsample is not None:
                     identity = pb.conv(x, blk.downsample[0], blk.downsample[1], act="none")
-                    branch = pb.fork_last()  # beside the block's first conv
                 y = pb.conv(x, blk.conv1, blk.bn1, act="relu")
-                pb.join(branch, x.buf, identity.buf)
                 x = pb.conv(y, blk.conv2, blk.bn2, act="relu", residual=identity)
         return x
 
@@ -207,16 +205,14 @@ class resnet2p1d_18(_plan.HipTrunk):  # noqa: N801 -- name is part of the refere
         x = pb.conv(x, stem[3], stem[4], act="relu")
         for layer in list(self.backbone)[1:]:
             for blk in layer:
-                identity, branch = x, None
+                identity = x
                 if blk.downsample is not None:
                     identity = pb.conv(x, blk.downsample[0], blk.downsample[1], act="none")
-                    branch = pb.fork_last()  # beside the block's first three convs
                 c = blk.conv1[0]
                 y = pb.conv(x, c[0], c[1], act="relu")
                 y = pb.conv(y, c[3], blk.conv1[1], act="relu")
                 c = blk.conv2[0]
                 y = pb.conv(y, c[0], c[1], act="relu")
-                pb.join(branch, x.buf, identity.buf)
                 x = pb.conv(y, c[3], blk.conv2[1], act="relu", residual=identity)
         return x
 
@@ -338,10 +334,8 @@ class X3DFeatures(_plan.HipTrunk):
                         x, pre = whole
                         continue
                 fuse_short = blk.shortcut is not None and pb.short_fusable(x, blk)  # the strided shortcut conv rides in the project conv's launch
-                branch, x_in = None, x
                 if blk.shortcut is not None and not fuse_short:
                     sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")
-                    branch = pb.fork_last()  # nothing reads it before the project conv: it runs beside expand conv and stencil
                 act_b = "none" if blk.se is not None else "swish"  # no gate between BN and Swish: the stencil applies Swish
                 gate = None
                 # expand conv + stencil in one launch where the pair is covered (block width <= 48): the expanded activation never leaves LDS
@@ -360,21 +354,10 @@ class X3DFeatures(_plan.HipTrunk):
                     # the pool partial rows are produced here (gate = ("pooled", ...))
                     y, gate = pb.dwconv_se(e, blk.conv_b, blk.bn_b, blk.se.fc1, blk.se.fc2, consumer=(blk.conv_c, True))
                 else:
-                    # a block without squeeze-excite: stencil -> project conv (+ residual) -> the next block's expand conv in ONE launch where
-                    # that is covered (stride 1, no shortcut conv: every such block of an X3D stage); the stencil's output stays in LDS
-                    nxt_b = blocks[i + 1] if i + 1 < len(blocks) else None
-                    if blk.shortcut is None:
-                        chain_a = nxt_b is not None and nxt_b.shortcut is None
-                        fused_b = pb.x3d_block(e, blk.conv_b, blk.bn_b, blk.conv_c, blk.bn_c, x,
-                                               nxt_b.conv_a if chain_a else None, nxt_b.bn_a if chain_a else None)
-                        if fused_b is not None:
-                            x, pre = fused_b
-                            continue
                     y = pb.dwconv(e, blk.conv_b, blk.bn_b, act=act_b)
                 # project conv; where the geometry allows, chained in ONE launch with the next block's expand conv
                 nxt = blocks[i + 1] if i + 1 < len(blocks) else None
                 pair = None
-                pb.join(branch, x_in.buf, sc.buf)
                 if isinstance(gate, tuple):  # squeeze-excite gate in the project conv's prologue
                     if fuse_short:  # (not combined with the fused shortcut: different kernels)
                         sc = pb.conv(x, blk.shortcut.conv, blk.shortcut.bn, act="none")

@@ -153,19 +153,6 @@ struct XeGeom {
 XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype);
 int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
                      void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s);
-// x3d_block.hip: one launch per X3D residual-block body -- depthwise 3x3x3 stencil (+BN, Swish) -> project conv (+BN, residual, ReLU) -> the next
-// block's expand conv (+BN, ReLU); the stencil's output only ever in LDS; ok = 0: not covered
-struct XbGeom {
-    int ok, RPT;                        // output rows per 16-lane position tile of the stencil (2 on planes <= 8 wide)
-    int TF, BH, BW, RTH, RTW, nTch;     // tile = TF frames x BH x BW outputs; regions per frame; T chunks per clip
-    int R, RTn, NQ;                     // rows per tile, 32-row tiles, 64-channel quads of the inner width
-    int KSC, KSA, CTC, CTA;             // (even) k-steps of the project / expand conv, 32-channel output tiles of each
-    int DPL, XPL;                       // 16-byte slots per row of the stencil-output image / the block-output image (odd)
-    int NS;                             // frame images in the ring (2-4: what fits next to the operand images)
-    int dw_off, tab_off, cst_off, wop_off, lds_bytes;  // LDS layout: [ring | block-output image] [stencil-output image] [row table] [scale / bias tables] [stencil weight operands]
-    int tiles, tpb, grid, abl;          // work split; timing ablations (PASN_BLOCK_ABL, -DPASN_TUNING builds only)
-};
-XbGeom xb_geom(const pasn_conv_desc& d_dw, const pasn_conv_desc& d_c, const pasn_conv_desc* d_a, int dtype);
 // x3d_edp.hip: a whole X3D block of the 7 x 7 stage (expand -> stencil -> project [-> next expand]) in one launch, both wide tensors in LDS; ok = 0: not covered
 struct EdpGeom {
     int ok, KSA, KSC, CTA, CTC, CTN, NQ;                       // k-steps / 32-channel tiles of the expand, project and next expand convs; quads of the inner width

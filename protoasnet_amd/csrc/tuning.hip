@@ -53,9 +53,9 @@ static const TuneEntry kRegistry[] = {
     {"PASN_DWWG_BLOCKS",      "geom",  "cap on the blocks (= partial rows) of the depthwise weight-gradient march (default 512)"},
     {"PASN_TRAIN_BLOCKS",     "geom",  "blocks an elementwise training pass is cut into (default 1024; the partial-sum workspaces scale with it)"},
     {"PASN_TRAIN_ROWS_CONTIG", "geom", "1: the elementwise training passes map Cp / 8 lanes to a row (contiguous spans, fewer idle lanes) instead of the next power of two"},
+    {"PASN_NO_TRAIN_PAIR",    "route", "1: the loss recipe's two trunk passes of a training step as two passes instead of one paired pass with two statistics groups (host side, trainer.py)"},
     {"PASN_TRAIN_STREAMS",    "route", "1: weight-gradient launches of the training step on the main stream instead of a second one (host side, train.py)"},
     {"PASN_TRAIN_SIDE_DEPTH", "geom",  "side-stream weight-gradient launches outstanding before the main stream waits (default 2)"},
-    {"PASN_BRANCH",           "route", "1: shortcut / downsample convs on the plan's side stream beside their block's main branch (host side, plan.py; measured slower)"},
     {"PASN_NO_EDP",           "route", "1: no whole-block launch for the 7 x 7 stage (x3d_edp.hip)"},
     {"PASN_NO_PE",            "route", "1: no streamed project + expand pair launch for the 432-channel stage (x3d_pe.hip)"},
     {"PASN_NO_PWCONV",        "route", "no register-resident persistent pointwise conv (pwconv.hip)"},
@@ -73,7 +73,6 @@ static const TuneEntry kRegistry[] = {
     {"PASN_NO_WGRAD_TILE",    "route", "windowed weight gradient without the tiled kernel"},
     {"PASN_NO_XPAIR",         "route", "project conv never chained with the next expand conv (pwconv_xpair.hip)"},
     {"PASN_NO_XTILE",         "route", "no X-stationary pointwise conv (pwconv_xtile.hip)"},
-    {"PASN_BLOCK",            "route", "fused residual-block launch (x3d_block.hip): 0 / unset off (it loses at the benchmark shapes), 1 every covered block, 5 the 432-channel blocks only"},
     {"PASN_POOL_VALU",        "route", "1: head-B pooling on the VALU kernel"},
     {"PASN_SE_FUSE_MAXC",     "route", "largest channel count whose squeeze-excite gate rides in the stencil launch (default 128)"},
     {"PASN_WGRAD_DET",        "route", "1: windowed weight gradient through fixed-order partial buffers only"},
@@ -95,8 +94,6 @@ static const TuneEntry kRegistry[] = {
     {"PASN_WS_PT",            "geom",  "weight-stationary conv: forced waves along positions"},
     {"PASN_WS_MINK",          "geom",  "weight-stationary conv: smallest padded K it takes (default 48)"},
     {"PASN_PE_MT",            "geom",  "streamed project + expand pair: 32-row tiles per unit (2 or 4, default 4)"},
-    {"PASN_BLOCK_TF",         "geom",  "fused residual block: forced frames per tile"},
-    {"PASN_BLOCK_NS",         "geom",  "fused residual block: forced frame images in the ring (2-4)"},
     // ---- dev: only with -DPASN_TUNING (timing ablations give WRONG results) ----------------------------------------------------------
     {"PASN_DWMFMA_ABL",       "dev",   "matrix-core stencil timing ablations (bit mask)"},
     {"PASN_EXPDW_ABL",        "dev",   "fused expand + stencil timing ablations (bit mask)"},
@@ -104,7 +101,6 @@ static const TuneEntry kRegistry[] = {
     {"PASN_WS_ABL",           "dev",   "weight-stationary conv timing ablations (needs -DPASN_WS_ABLATE too)"},
     {"PASN_EDP_STAMPS",       "dev",   "whole-block launch of the 7 x 7 stage: in-kernel phase stamps (tools/edp_bench.py)"},
     {"PASN_PE_STAMPS",        "dev",   "streamed project + expand pair: in-kernel phase stamps (tools/pe_bench.py)"},
-    {"PASN_BLOCK_ABL",        "dev",   "fused residual block timing ablations (bit mask)"},
     {"PASN_DW_WT",            "dev",   "strip stencil: outputs per thread (4, 7, 8)"},
     {"PASN_HALO_SP",          "dev",   "halo implicit GEMM: slice pipeline on / off"},
     {"PASN_IGEMM_NT",         "dev",   "implicit GEMM: forced channel tiles per block"},

@@ -2,7 +2,7 @@
 //   conv_a (1x1x1) + norm_a + ReLU -> conv_b (depthwise 3x3x3) + norm_b + Swish -> conv_c (1x1x1) + norm_c + residual + ReLU
 //   (-> the NEXT block's conv_a + norm_a + ReLU), with both 2.25x-wide tensors only ever in LDS.
 //
-// Round 4's first whole-block launch (x3d_block.hip: stencil -> project -> next expand) read the expanded activation through a (quad, frame) DMA
+// Round 4's first whole-block launch (x3d_block.hip, retired in round 5: stencil -> project -> next expand) read the expanded activation through a (quad, frame) DMA
 // pipeline whose steps serialise wait / issue / MFMAs / epilogue: 65 us against 55 for the separate launches.  On a 7 x 7 plane the OTHER cut is
 // affordable: a tile = (clip, two output frames) needs the block input of FOUR whole frames -- 196 rows x 192 channels = 78 KB, no spatial halo --
 // and from then on everything is on chip: per 64-channel quad of the inner width

@@ -1,4 +1,4 @@
-// Shared by x3d_block.hip and x3d_pe.hip: one pointwise conv (1x1x1 + folded norm (+ residual) + ReLU) of a row tile whose operand image lies in
+// Shared by x3d_pe.hip and x3d_edp.hip: one pointwise conv (1x1x1 + folded norm (+ residual) + ReLU) of a row tile whose operand image lies in
 // LDS, weight fragments streamed from global memory (fragment-major, L2-resident), lane-swap epilogue, 16-byte stores.
 #pragma once
 #include "common.h"

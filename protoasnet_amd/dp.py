@@ -102,6 +102,11 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[di
     """Sum (or average) ``p.grad`` of every parameter that has one across the ranks of ``group``; returns the bucket size in
     bytes (0 when not running distributed).  Every rank must hold gradients for the same parameters (they run the same graph).
 
+    In-place path (``flat_gradient_view``): the exchange covers the SPAN of the arena's gradient buffer from the first to the last
+    listed gradient -- the alignment gaps (zeros on every rank) and any gradient slot of a parameter NOT listed in ``params`` that lies
+    inside the span are summed (and divided, with ``average``) too.  ``DPTrainer`` always passes every parameter of the model, so there
+    is no such slot; a caller that passes a subset and must keep the rest local should pass gradients that are not arena views.
+
     ``native=True`` (or ``PASN_NATIVE_RCCL=1``) sends the bucket through ``pasn_allreduce`` -- RCCL called from the C-ABI library on
     torch's current stream -- instead of ``torch.distributed.all_reduce``; it needs CUDA gradients and the default (world) group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -112,7 +117,20 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[di
     if not grads:
         return 0
     flat = flat_gradient_view(grads)  # the training arena's gradient buffer as it lies (in place), else a fresh bucket
-    in_place = flat is not None
+    # Every rank must take the SAME path with the SAME element count (round 5, ADVICE): the in-place view has the arena's layout (hi - lo
+    # elements), the bucket the parameters' (total elements); if AccumulateGrad cloned a gradient on one rank, or one rank's p.grad
+    # storages are mixed, the ranks would enter all_reduce with different sizes -- a hang or silent corruption.  One 3-word MIN-reduce
+    # per call (a few microseconds next to the bucket itself): in place only when every rank can and the spans agree.
+    total = sum(g.numel() for g in grads)
+    span = flat.numel() if flat is not None else -1
+    probe = torch.tensor([int(flat is not None), span, -span, total, -total], dtype=torch.int64, device=grads[0].device)
+    if probe.is_cuda and dist.get_backend(group) == "gloo":
+        probe = probe.cpu()
+    dist.all_reduce(probe, op=dist.ReduceOp.MIN, group=group)
+    if int(probe[3]) != -int(probe[4]):
+        raise RuntimeError(f"allreduce_gradients: the ranks hold between {int(probe[3])} and {-int(probe[4])} gradient elements; every rank must "
+                           "hold gradients for the same parameters")
+    in_place = flat is not None and int(probe[0]) == 1 and int(probe[1]) == -int(probe[2])
     if not in_place:
         flat = _flatten_dense_tensors(grads)
     if native and flat.is_cuda and group is None:

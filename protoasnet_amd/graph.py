@@ -31,6 +31,8 @@ from typing import Tuple
 
 import torch
 
+from . import _lib
+
 
 class _Entry:
     __slots__ = ("graph", "out", "sig", "keep", "x_static")
@@ -85,9 +87,9 @@ class GraphedForward:
         if not x.is_cuda:
             raise RuntimeError("GraphedForward runs on the GPU only; there is no CPU fallback")
         if self.static_input:
-            key = ("static", tuple(x.shape), x.dtype, x.device)
+            key = ("static", tuple(x.shape), x.dtype, x.device, _lib.tuning_epoch())
         else:
-            key = (x.data_ptr(), tuple(x.shape), x.dtype, tuple(x.stride()), x.device)
+            key = (x.data_ptr(), tuple(x.shape), x.dtype, tuple(x.stride()), x.device, _lib.tuning_epoch())
         sig = self._signature()
         ent = self._graphs.get(key)
         if ent is not None and ent.sig != sig:  # a weight / buffer changed since the capture: never replay the stale graph

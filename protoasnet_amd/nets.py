@@ -76,7 +76,7 @@ class PointwiseChain(nn.Sequential):
     def run_rows(self, rows: torch.Tensor, shape5, c: int, dtype: torch.dtype) -> torch.Tensor:
         """rows: channels-last [N][S][Cp] storage of a (N,c,T,H,W) map -> channels-last storage [N][T][H][W][Dp]."""
         n, t, h, w = shape5
-        key, sig = ("plan", tuple(rows.shape), tuple(shape5), c, dtype, rows.device), self._sig()
+        key, sig = ("plan", tuple(rows.shape), tuple(shape5), c, dtype, rows.device, _lib.tuning_epoch()), self._sig()
         hit = self._cache.get(key)
         if hit is None or hit[0] != sig:
             pb = PlanBuilder(rows.device, dtype, dtype)
@@ -239,6 +239,20 @@ class PPNet(nn.Module):
             logits = torch.nn.functional.linear(act(min_d), fcw)
         return logits, min_d, dist
 
+    @staticmethod
+    def _weighted_l2_convolution(input, filter, weights):  # noqa: A002 -- reference argument names
+        """Weighted squared distance of every 1x1 patch to every prototype (reference ProtoPNet.py:165-187; no caller anywhere in the
+        reference, so it is not on the hot path and has no kernel: three dense contractions in torch on whatever device the operands
+        are on).  input (N,c,h,w), filter and weights (P,c,1,1) -> (N,P,h,w), clamped at zero like the reference's ``F.relu``."""
+        if filter.shape[2:] != (1, 1) or weights.shape != filter.shape:
+            raise ValueError("prototypes and weights are (P, c, 1, 1) patches")
+        wf = weights.flatten(1)  # (P, c)
+        ff = filter.flatten(1)
+        x2w = torch.einsum("nchw,pc->nphw", input * input, wf)
+        xpw = torch.einsum("nchw,pc->nphw", input, ff * wf)
+        p2w = (ff * ff * wf).sum(1).view(1, -1, 1, 1)
+        return torch.relu(x2w - 2 * xpw + p2w)
+
     def _l2_convolution(self, x: torch.Tensor) -> torch.Tensor:
         """Distance map of a logical (N,D,H,W) feature tensor (reference ProtoPNet.py:189-207)."""
         rows, s, cp = channels_last_rows(x, self._dtype())
@@ -271,7 +285,7 @@ class PPNet(nn.Module):
         x = x.contiguous()
         runners = self.__dict__.setdefault("_train_runners", {})
         key = (tuple(x.shape), x.dtype, self._dtype(), "A", hash(tuple((p.data_ptr(), p.requires_grad) for p in self.parameters())),
-               tuple(self.prototype_shape))
+               tuple(self.prototype_shape), _lib.tuning_epoch())
         runner = runners.get(key)
         if runner is None:
             for stale in [k for k in runners if k[:4] == key[:4]]:
@@ -340,7 +354,7 @@ class _XProtoHeadMixin:
         runners = self.__dict__.setdefault("_train_runners", {})
         # the launch lists hold the parameters' device addresses: a model moved / cast / pruned since gets a fresh compilation
         key = (tuple(x.shape), x.dtype, self._dtype(), mode, hash(tuple((p.data_ptr(), p.requires_grad) for p in self.parameters())),
-               tuple(self.prototype_shape))
+               tuple(self.prototype_shape), _lib.tuning_epoch())
         runner = runners.get(key)
         if runner is None:
             for stale in [k for k in runners if k[:4] == key[:4]]:
@@ -402,6 +416,26 @@ class _XProtoHeadMixin:
     def compute_occurence_map(self, x: torch.Tensor) -> torch.Tensor:
         return self._xproto(x, 1)[2]
 
+    # The reference's models call the next two on the TRUNK OUTPUT inside forward / push_forward (XProtoNet.py:55,75-85,
+    # Video_XProtoNet.py:88,106-109); here the fused head computes the map, so nothing inside this package calls them.  They exist for
+    # code written against the reference classes (a subclass, a notebook): the occurrence module alone on a logical (N,C,[T,]H,W)
+    # feature tensor, through the same pointwise-conv launches as head A's add-on layers, no autograd graph.
+    def _occurrence_logits(self, features: torch.Tensor) -> torch.Tensor:
+        if not features.is_cuda:
+            raise RuntimeError("protoasnet_amd models run on the GPU only; there is no CPU fallback")
+        with torch.no_grad():
+            return self.occurrence_module(features).float()  # (N, P, [T,] H, W)
+
+    def get_occurence_map_absolute_val(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.abs(self._occurrence_logits(x)).unsqueeze(2)  # (N, P, 1, [T,] H, W)
+
+    def get_occurence_map_softmaxed(self, x: torch.Tensor) -> torch.Tensor:
+        """XProtoNet.py:75-80 (softmax over the flattened positions); the video class of the reference has no such method, the mixin
+        gives it the same definition over (T, H, W)."""
+        om = self._occurrence_logits(x)
+        n, p = om.shape[:2]
+        return self.om_softmax(om.reshape(n, p, -1)).reshape(om.shape).unsqueeze(2)
+
     def forward_pair(self, x: torch.Tensor, x_transformed: torch.Tensor):
         """``(forward(x), compute_occurence_map(x_transformed))`` of the reference's loss recipe (Video_XProtoNet_e2e.py:84 + loss.py:302) from
         ONE pass over the 2N clips.  Eval mode: running statistics, so a 2N batch gives every clip what two N-clip passes give.  Train mode:
@@ -439,6 +473,8 @@ class XProtoNet(_XProtoHeadMixin, PPNet):
         self._initialize_weights(self.occurrence_module)
         self.last_layer = nn.Linear(self.num_prototypes, self.num_classes, bias=False)
         self.set_last_layer_incorrect_connection(incorrect_strength=0)
+        self.om_softmax = nn.Softmax(dim=-1)  # XProtoNet.py:48-49: parameter-free attributes of the reference class
+        self.cosine_similarity = nn.CosineSimilarity(dim=2)  # (the fused head computes the cosine itself, torch semantics: head_xproto.hip)
 
     def __repr__(self):
         return (
@@ -468,6 +504,8 @@ class Video_XProtoNet(_XProtoHeadMixin, PPNet):  # noqa: N801 -- reference class
         depth = self.prototype_shape[1]
         self.add_on_layers = PointwiseChain(nn.Conv3d(cin, depth, kernel_size=1), nn.ReLU(), nn.Conv3d(depth, depth, kernel_size=1))
         self.occurrence_module = _occurrence_module(nn.Conv3d, cin, depth, self.prototype_shape[0])
+        self.om_softmax = nn.Softmax(dim=-1)  # Video_XProtoNet.py:64-65
+        self.cosine_similarity = nn.CosineSimilarity(dim=2)
         self.prototype_vectors = nn.Parameter(torch.rand(self.prototype_shape), requires_grad=True)
         self.ones = nn.Parameter(torch.ones(self.prototype_shape), requires_grad=False)
         self.last_layer = nn.Linear(self.num_prototypes, self.num_classes, bias=False)

@@ -95,7 +95,7 @@ def pack_conv_weight(w: torch.Tensor, cin_p: int, dtype: torch.dtype) -> Tuple[t
 
 
 def stencil_operands(w: torch.Tensor, c: int, cp: int) -> torch.Tensor:
-    """Depthwise 3x3x3 weights (C,1,3,3,3) as the matrix-core stencil's block-diagonal A operands (``pasn_x3d_block_fwd``'s ``w_dw``):
+    """Depthwise 3x3x3 weights (C,1,3,3,3) as the matrix-core stencil's block-diagonal A operands (``pasn_x3d_edp_fwd``'s ``w_dw``):
     int16 [ceil(cp / 16)][2][64 lanes][8], entry e = kt * 5 + j (half e >> 3, slot e & 7) = bf16 bits of the lane's one possibly nonzero
     element of A[kt][pair j] -- lane (m = lane & 15, q = lane >> 4) supplies k = 8 q .. 8 q + 7 = tap 2 j + (q >> 1) of the pair, channels
     8 (q & 1) ..: only channel m can be nonzero, and only when m's half matches.  Same values (round-to-nearest-even) as the prologue of
@@ -134,13 +134,6 @@ class PlanBuilder:
         self.ops: List[Callable[[List[int], int], None]] = []
         self.keep: List[object] = []  # packed weights / descriptors kept alive with the plan
         self.meta: List[dict] = []  # per launch: kernel instance name, algorithmic bytes and flops (DESIGN.md "Measurement")
-        # launches that run on the plan's SIDE stream (a shortcut / downsample conv beside its block's main branch: nothing reads its output
-        # until the block's last conv) and, per launch index, the side launches the main stream waits for before it.  OPT-IN (PASN_BRANCH=1):
-        # measured, the fork / join edges cost more than the 27 us of shortcut launches they hide (X3D-S 11.84 k vs 11.98 k clips/s as one
-        # chain; R(2+1)D-18 +-0: profiles/README.md entry 124)
-        self.op_side: set = set()
-        self.op_wait: Dict[int, List[int]] = {}
-        self.branches = _lib.tuning_get("PASN_BRANCH") == "1"
         self.lib = _lib.lib()
         self.tname = "bf16" if dtype == torch.bfloat16 else "f32"
         # arrival counters of the fused SE-gate launches, one [N] slice per launch, packed so that Plan.run clears them with ONE fill before
@@ -158,22 +151,6 @@ class PlanBuilder:
         for b in buf_ids:
             if b is not None:
                 self.bufs[b].last = len(self.ops)
-
-    def fork_last(self) -> Optional[int]:
-        """The launch recorded last goes to the side stream; returns the token ``join`` takes (None: branches are off)."""
-        if not self.branches or not self.ops:
-            return None
-        idx = len(self.ops) - 1
-        self.op_side.add(idx)
-        return idx
-
-    def join(self, token: Optional[int], *bufs: int) -> None:
-        """The NEXT launch recorded (and everything behind it) waits for side launch ``token``; ``bufs`` -- what that launch reads and
-        writes -- stay where they are in the arena until then (the main branch runs beside it and must not be handed their memory)."""
-        if token is None:
-            return
-        self._use(*bufs)
-        self.op_wait.setdefault(len(self.ops), []).append(token)
 
     def input(self, shape) -> Act:
         if len(shape) == 4:
@@ -617,68 +594,6 @@ class PlanBuilder:
             return y, (pool_buf, pool_blocks, y)
         return y
 
-    def x3d_block(self, e: Act, conv_b: nn.Module, norm_b: Optional[nn.Module], conv_c: nn.Module, norm_c: Optional[nn.Module], residual: Act,
-                  conv_a: Optional[nn.Module] = None, norm_a: Optional[nn.Module] = None):
-        """The body of an X3D block without squeeze-excite in ONE launch (``pasn_x3d_block_fwd``): depthwise 3x3x3 conv + BN + Swish ->
-        project conv + BN + residual + ReLU -> (``conv_a``: the NEXT block's expand conv + BN + ReLU).  ``e`` = this block's expanded
-        activation.  Returns (y, e_next or None), or None when the launch does not cover the block (the caller emits the separate ones)."""
-        one, zero = (1, 1, 1), (0, 0, 0)
-        if e.planar or self.dtype != torch.bfloat16 or conv_b.groups != conv_b.in_channels or conv_b.in_channels != e.C or conv_c.groups != 1:
-            return None
-        k, s, p = _triple(conv_b.kernel_size, 1), _triple(conv_b.stride, 1), _triple(conv_b.padding, 0)
-        if k != (3, 3, 3) or s != one or p != (1, 1, 1) or conv_b.bias is not None:
-            return None
-        for cv in (conv_c, conv_a):
-            if cv is not None and (_triple(cv.kernel_size, 1) != one or _triple(cv.stride, 1) != one or _triple(cv.padding, 0) != zero or cv.groups != 1):
-                return None
-        if conv_c.in_channels != e.C or (conv_a is not None and conv_a.in_channels != conv_c.out_channels):
-            return None
-
-        def frag32(conv, cin_p):  # fragment-major weights with K zero-padded to an EVEN number of 16-wide steps
-            wp, kc, rows = pack_conv_weight(conv.weight, round_up(cin_p, 32), self.dtype)
-            return wp.view(rows // 32, 32, kc // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous(), kc, rows
-
-        mid = Act(e.N, e.T, e.H, e.W, e.C, e.Cp, -1)  # the stencil's output: never materialised
-        dd = self._desc(e, mid, k, s, p, "swish")
-        y = self._out_act(mid, conv_c.out_channels, one, one, zero)
-        wc, kcc, rowsc = frag32(conv_c, e.Cp)
-        dc = self._desc(mid, y, one, one, zero, "relu", False, kcc, rowsc)
-        dc.w_frag = 1
-        en = da = None
-        if conv_a is not None:
-            ymid = Act(y.N, y.T, y.H, y.W, y.C, y.Cp, -1)
-            en = self._out_act(ymid, conv_a.out_channels, one, one, zero)
-            wa, kca, rowsa = frag32(conv_a, y.Cp)
-            da = self._desc(ymid, en, one, one, zero, "relu", False, kca, rowsa)
-            da.w_frag = 1
-        if (residual.N, residual.T, residual.H, residual.W, residual.Cp) != (y.N, y.T, y.H, y.W, y.Cp) or \
-                not int(self.lib.pasn_x3d_block_supported(ctypes.byref(dd), ctypes.byref(dc), ctypes.byref(da) if da is not None else None, self.code)):
-            self.bufs[y.buf].nbytes = ALIGN  # never used
-            if en is not None:
-                self.bufs[en.buf].nbytes = ALIGN
-            return None
-        wd = stencil_operands(conv_b.weight.to(self.device), e.C, e.Cp)
-        sd, bd = fold_norm(norm_b, None, e.C, e.Cp, self.device)
-        sc, bc = fold_norm(norm_c, conv_c.bias, y.C, rowsc, self.device)
-        keep = [wd, sd, bd, wc, sc, bc]
-        if conv_a is not None:
-            sa, ba = fold_norm(norm_a, conv_a.bias, en.C, rowsa, self.device)
-            keep += [wa, sa, ba]
-        self.keep += keep
-        a = tuple(t.data_ptr() for t in keep) + ((0, 0, 0) if conv_a is None else ())
-        eb, rb, yb, nb = e.buf, residual.buf, y.buf, (en.buf if en is not None else None)
-        rd, rc, ra = ctypes.byref(dd), ctypes.byref(dc), (ctypes.byref(da) if da is not None else None)
-        self._use(eb, rb, yb, nb)
-        pos = y.N * y.positions
-        cn = en.C if en is not None else 0
-        self._note("block" if en is None else "block+expand", f"x3d_block_kernel<{2 if e.W <= 8 else 1},{kcc // 16},{kca // 16 if en is not None else 0},0>",
-                   (pos * (e.C + 2 * y.C + cn) + 27 * e.C + y.C * e.C + cn * y.C) * self.es, 2 * pos * (27 * e.C + y.C * e.C + cn * y.C))
-        self.meta[-1]["shape"] = f"dw{e.C} k333 -> {e.C}->{y.C}" + (f" -> {y.C}->{cn}" if cn else "") + f" k111 in{e.T}x{e.H}x{e.W}"
-        fn, code = self.lib.pasn_x3d_block_fwd, self.code
-        self.ops.append(lambda ptrs, st: _lib.check(fn(ptrs[eb], a[0], a[1], a[2], a[3], a[4], a[5], ptrs[rb], ptrs[yb], a[6], a[7], a[8],
-                                                       ptrs[nb] if nb is not None else 0, rd, rc, ra, code, st)))
-        return y, en
-
     def x3d_edp(self, x: Act, conv_a: nn.Module, norm_a, conv_b: nn.Module, norm_b, conv_c: nn.Module, norm_c, conv_n: Optional[nn.Module] = None,
                 norm_n=None, probe: bool = False):
         """A WHOLE X3D block without squeeze-excite on 7 x 7 planes in ONE launch (``pasn_x3d_edp_fwd``): expand conv + BN + ReLU -> depthwise
@@ -928,9 +843,6 @@ class PlanBuilder:
 class Plan:
     def __init__(self, pb: PlanBuilder, x_in: Act, y_out: Act, arena_bytes: int):
         self.ops, self.keep, self.meta = pb.ops, pb.keep, pb.meta
-        self.op_side, self.op_wait = frozenset(pb.op_side), {k: tuple(v) for k, v in pb.op_wait.items()}
-        self._side = None
-        self._events: Dict[int, tuple] = {}
         self.in_buf, self.out_buf, self.out = x_in.buf, y_out.buf, y_out
         self.dtype = pb.dtype
         self.arena_bytes = arena_bytes
@@ -951,31 +863,9 @@ class Plan:
         st = _lib.current_stream()
         if self.se_counters is not None:
             self.se_counters.zero_()  # one 16-byte-multiple fill on the launch stream (see PlanBuilder.__init__)
-        if not timers and not self.op_side:
+        if not timers:
             for op in self.ops:
                 op(ptrs, st)
-            return y
-        if not timers:
-            # two branches: a side launch waits for what the main stream has produced so far and leaves an event its consumer waits for
-            # (inside a hipGraph capture these become the graph's fork and join edges)
-            main = torch.cuda.current_stream(x.device)
-            if self._side is None:
-                self._side = torch.cuda.Stream(x.device)
-                self._events = {i: (torch.cuda.Event(), torch.cuda.Event()) for i in self.op_side}
-            side, sst = self._side, self._side.cuda_stream
-            for i, op in enumerate(self.ops):
-                for tok in self.op_wait.get(i, ()):
-                    main.wait_event(self._events[tok][1])
-                if i in self.op_side:
-                    before, done = self._events[i]
-                    before.record(main)
-                    side.wait_event(before)
-                    op(ptrs, sst)
-                    done.record(side)
-                else:
-                    op(ptrs, st)
-            for tok in self.op_wait.get(len(self.ops), ()):
-                main.wait_event(self._events[tok][1])
             return y
         for i, op in enumerate(self.ops):
             sink = timers.get(i)
@@ -1061,7 +951,7 @@ class HipTrunk(nn.Module):
     def plan_for(self, x: torch.Tensor) -> Plan:
         p0 = next(self.parameters())
         dtype = self.compute_dtype or p0.dtype
-        key = (tuple(x.shape), x.dtype, dtype, x.device, self.input_affine if x.shape[1] == 1 else None)
+        key = (tuple(x.shape), x.dtype, dtype, x.device, self.input_affine if x.shape[1] == 1 else None, _lib.tuning_epoch())
         sig = self._signature()
         hit = self._plans.get(key)
         if hit is not None and hit[0] == sig:

@@ -45,7 +45,7 @@ from typing import Dict, Optional
 import torch
 import torch.distributed as dist
 
-from . import dp, losses
+from . import _lib, dp, losses
 from . import push as push_mod
 
 
@@ -114,9 +114,19 @@ class DPTrainer:
         its version counter and make the next eval forward re-plan and re-pack every weight -- and for world sizes that are not powers
         of two ``(a + a + a) / 3`` need not be ``a``, so the statistics would drift by an ulp per call.  Only norm statistics are
         exchanged: ``prototype_class_identity``-like constants and ``ones`` are equal by construction."""
-        if self.world_size <= 1 or not getattr(self, "_norm_dirty", True):
+        if self.world_size <= 1:
             return
         norms = [m for m in self.model.modules() if isinstance(m, torch.nn.modules.batchnorm._NormBase) and m.running_mean is not None]
+        # The decision to skip is COLLECTIVE (round 5, ADVICE): the local flag only knows about run_epoch("train"); a train-mode forward
+        # outside it, or a per-rank load_state_dict, also moves the statistics.  One 3-word MAX-reduce: [any rank dirty, max, -min] of the
+        # ranks' summed batch counters -- a sync runs when any rank trained since the last one or the counters disagree; every rank then
+        # takes the same branch, so the collectives below stay matched.
+        nbt = sum(int(m.num_batches_tracked) for m in norms if m.num_batches_tracked is not None)
+        probe = torch.tensor([int(bool(getattr(self, "_norm_dirty", True))), nbt, -nbt], dtype=torch.int64, device=self.device)
+        probe = push_mod._for_collective(probe)
+        dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+        if int(probe[0]) == 0 and int(probe[1]) == -int(probe[2]):
+            return
         fl = [b for m in norms for b in (m.running_mean, m.running_var)]
         it = [m.num_batches_tracked for m in norms if m.num_batches_tracked is not None]
         with torch.no_grad():
@@ -247,7 +257,7 @@ class DPTrainer:
                 self.sync_norm_buffers()
         # the reference's second trunk pass (loss.py:302) rides in the first one's launch list: eval epochs on running statistics, training
         # epochs with two statistics groups (model.forward_pair; PASN_NO_TRAIN_PAIR=1: two passes)
-        warp_in_batch = self.Trans_occurrence.loss_weight != 0 and (mode != "train" or (hasattr(self.model, "forward_pair") and os.environ.get("PASN_NO_TRAIN_PAIR") != "1"))
+        warp_in_batch = self.Trans_occurrence.loss_weight != 0 and (mode != "train" or (hasattr(self.model, "forward_pair") and _lib.tuning_get("PASN_NO_TRAIN_PAIR") != "1"))
         with torch.set_grad_enabled(mode == "train"):
             for i, sample in enumerate(loader):
                 inp = sample["cine"].to(self.device, non_blocking=True)

@@ -122,6 +122,34 @@ def test_constructor_semantics_match_reference(golden):
         p.get_cnn_backbone_out_channels(torch.nn.Linear(2, 2))
 
 
+def test_reference_class_surface_leftovers():
+    """Attributes / methods the reference classes carry although nothing in the reference calls them from outside the models
+    (XProtoNet.py:48-49,75-85; Video_XProtoNet.py:64-65,106-109; ProtoPNet.py:165-187)."""
+    import torch.nn.functional as F
+
+    from protoasnet_amd import model_builder, nets
+
+    x = model_builder.build(CFG_XPROTO)
+    v = model_builder.build(CFG_VIDEO_R2P1D)
+    for m in (x, v):
+        assert isinstance(m.cosine_similarity, torch.nn.CosineSimilarity) and m.cosine_similarity.dim == 2
+        assert isinstance(m.om_softmax, torch.nn.Softmax) and m.om_softmax.dim == -1
+        assert callable(m.get_occurence_map_absolute_val) and callable(m.get_occurence_map_softmaxed)
+        assert not any(k.startswith(("cosine_similarity", "om_softmax")) for k in m.state_dict())  # parameter-free: checkpoint keys untouched
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.get_occurence_map_absolute_val(torch.zeros(1, 512 if m is x else 256, 2, 2, *((2,) if m is v else ())))
+    # _weighted_l2_convolution against the reference's own formula (conv form) on the CPU
+    g = torch.Generator().manual_seed(3)
+    inp, filt, wts = torch.randn(2, 16, 5, 4, generator=g), torch.rand(6, 16, 1, 1, generator=g), torch.rand(6, 16, 1, 1, generator=g)
+    ref = F.relu(F.conv2d(inp**2, wts) - 2 * F.conv2d(inp, filt * wts) + (filt**2 * wts).sum(dim=(1, 2, 3)).view(-1, 1, 1))
+    got = nets.PPNet._weighted_l2_convolution(inp, filt, wts)
+    assert got.shape == (2, 6, 5, 4) and float((got - ref).abs().max()) < 1e-5
+    # with unit weights it is the plain squared distance of _l2_convolution (ProtoPNet.py:189-207)
+    ones = torch.ones_like(filt)
+    d = ((inp[:, None] - filt[None, :, :, :, :].expand(2, 6, 16, 1, 1)) ** 2).sum(2)
+    assert float((nets.PPNet._weighted_l2_convolution(inp, filt, ones) - d).abs().max()) < 1e-4
+
+
 def test_prune_prototypes():
     from protoasnet_amd import model_builder
 

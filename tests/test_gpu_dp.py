@@ -83,6 +83,31 @@ def test_bench_gpus2_real_forward_two_ranks_one_card():
     assert line["metric"] == "clips/sec forward" and line["value"] > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_gpus2_train_step_reports_the_exchange_separately():
+    """bench.py --gpus 2 --mode train (two ranks on the one card, gloo): the line carries the gradient exchange measured ALONE -- bucket
+    bytes and the time of the three formulations (all-reduce, reduce-scatter + all-gather, one-shot all-gather + local sum) -- so the
+    first multi-GPU run yields SURVEY 8e's comparison; the gradients survive the probe (the step after it is finite)."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PASN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--frames", "4", "--size", "64"], env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["metric"] == "clips/sec train step"
+    ex = line["exchange"]
+    assert ex["bucket_bytes"] == line["grad_bucket_bytes"] or ex["bucket_bytes"] > 0
+    assert isinstance(ex["all_reduce"], float) and ex["all_reduce"] > 0, ex
+    for k in ("reduce_scatter_all_gather", "all_gather_local_sum_one_shot"):  # (gloo lacks reduce_scatter: reported as the error text, not a crash)
+        assert (isinstance(ex[k], float) and ex[k] > 0) or isinstance(ex[k], str), (k, ex[k])
+
+
 def test_native_rccl_call_site_single_rank():
     """pasn_comm_* / pasn_allreduce: RCCL called from the C-ABI library (librccl resolved at run time), on torch's current stream.  One
     card admits a one-rank communicator only (RCCL refuses two ranks on a device): an all-reduce over one rank must return its input,

@@ -289,93 +289,6 @@ def test_conv_pair_chained(c0, c1, c2, gate, kernel, monkeypatch):
             assert float(o[..., c:].float().abs().max()) == 0.0, "padded channels must stay zero"
 
 
-def _block_mods(cm, c, cn, seed):
-    torch.manual_seed(seed)
-    conv_b = nn.Conv3d(cm, cm, 3, 1, 1, groups=cm, bias=False)
-    conv_c = nn.Conv3d(cm, c, 1, bias=False)
-    conv_a = nn.Conv3d(c, cn, 1, bias=False) if cn else None
-    bns = [nn.BatchNorm3d(cm), nn.BatchNorm3d(c)] + ([nn.BatchNorm3d(cn)] if cn else [])
-    with torch.no_grad():
-        conv_b.weight.normal_(0, 0.25)
-        conv_c.weight.normal_(0, 0.12)
-        if cn:
-            conv_a.weight.normal_(0, 0.15)
-        for bn in bns:
-            bn.weight.uniform_(0.5, 1.5)
-            bn.bias.normal_(0, 0.3)
-            bn.running_mean.normal_(0, 0.3)
-            bn.running_var.uniform_(0.5, 1.5)
-            bn.eval()
-    return conv_b, bns[0], conv_c, bns[1], conv_a, (bns[2] if cn else None)
-
-
-@pytest.mark.parametrize("cm,c,cn,n,thw,tf", [
-    (216, 96, 216, 3, (5, 14, 14), None),   # stage 4: two regions of 7 x 14 per frame, T odd (a tile with one frame), 3.4 quads
-    (432, 192, 432, 2, (6, 7, 7), None),    # stage 5: two output rows per position tile, 6.75 quads, K 27 -> 28 steps
-    (108, 48, 108, 2, (4, 28, 28), None),   # stage 3: padded inner width (108 -> 112), 8 regions per frame, half-empty channel tiles
-    (216, 96, 0, 2, (3, 14, 14), None),     # the last block of a stage: no chained expand conv
-    (216, 96, 216, 2, (4, 11, 13), 1),      # ragged planes (regions cut by the border), one frame per tile
-    (432, 192, 432, 3, (5, 5, 6), 3),       # small ragged plane, three frames per tile
-    (112, 48, 112, 1, (7, 9, 20), 4),       # 20 wide: the second region 6 columns; four frames per tile clamped by the row budget
-])
-def test_x3d_block_one_launch(cm, c, cn, n, thw, tf, monkeypatch):
-    """pasn_x3d_block_fwd: depthwise 3x3x3 + BN + Swish -> project conv + BN + residual + ReLU -> next expand conv + BN + ReLU in ONE launch:
-    (a) against torch on the bf16-rounded operands with the rounding points of the separate launches; (b) BIT-IDENTICAL to the separate
-    launches of this library (matrix-core stencil, then the pointwise kernels) on the same inputs; (c) padded channels stay zero."""
-    dtype = torch.bfloat16
-    if tf is not None:
-        monkeypatch.setenv("PASN_BLOCK_TF", str(tf))
-    conv_b, bn_b, conv_c, bn_c, conv_a, bn_a = _block_mods(cm, c, cn, seed=cm + c + thw[1])
-    g = torch.Generator().manual_seed(n * 7 + thw[2])
-    e = F.relu(torch.randn(n, cm, *thw, generator=g))         # an expand conv's output: post-ReLU
-    res = F.relu(torch.randn(n, c, *thw, generator=g))
-    d = bn_b(F.conv3d(_rt(e, dtype), _rt(conv_b.weight.data, dtype), padding=1, groups=cm))
-    d = _rt(d * torch.sigmoid(d), dtype)
-    y = _rt(F.relu(bn_c(F.conv3d(d, _rt(conv_c.weight.data, dtype))) + _rt(res, dtype)), dtype).detach()
-    en = F.relu(bn_a(F.conv3d(y, _rt(conv_a.weight.data, dtype)))).detach() if cn else None
-
-    def run(fused):
-        with _lib_env(PASN_BLOCK="1" if fused else "0"):
-            pb = _pb(dtype)
-            ea, es = _cl_input(pb, e, dtype)
-            ra, rs = _cl_input(pb, res, dtype)
-            mods = [m.to(DEV) if m is not None else None for m in (conv_b, bn_b, conv_c, bn_c, conv_a, bn_a)]
-            if fused:
-                out = pb.x3d_block(ea, mods[0], mods[1], mods[2], mods[3], ra, mods[4], mods[5])
-                assert out is not None and pb.meta[-1]["kernel"].startswith("x3d_block_kernel"), "the fused launch must cover this geometry"
-                o1, o2 = out
-            else:
-                assert pb.x3d_block(ea, mods[0], mods[1], mods[2], mods[3], ra, mods[4], mods[5]) is None
-                dw = pb.dwconv(ea, mods[0], mods[1], act="swish")
-                o1 = pb.conv(dw, mods[2], mods[3], act="relu", residual=ra)
-                o2 = pb.conv(o1, mods[4], mods[5], act="relu") if cn else None
-            last = o2 if o2 is not None else o1
-            if o2 is not None:
-                pb.bufs[o1.buf].external = True
-            plan = pb.finish(ea, last)
-            out1 = torch.empty(n, *thw, o1.Cp, dtype=dtype, device=DEV)
-            if o2 is not None:
-                plan.ptrs[o1.buf] = out1.data_ptr()
-            plan.ptrs[ra.buf] = rs.data_ptr()
-            outl = plan.run(es)
-            torch.cuda.synchronize()
-            return (out1, outl.clone()) if o2 is not None else (outl.clone(), None)
-
-    f1, f2 = run(True)
-    atol, rtol = _tols(dtype)
-    assert_close(_from_cl(f1, c), y, atol * max(1.0, float(y.abs().max())), rtol, "fused block: block output")
-    if cn:
-        assert_close(_from_cl(f2, cn), en, atol * max(1.0, float(en.abs().max())), rtol, "fused block: next expanded activation")
-    u1, u2 = run(False)
-    assert torch.equal(f1, u1), "block output must be bit-identical to the separate launches"
-    if cn:
-        assert torch.equal(f2, u2), "expanded activation must be bit-identical to the separate launches"
-        if f2.shape[-1] > cn:
-            assert float(f2[..., cn:].float().abs().max()) == 0.0, "padded channels must stay zero"
-    f1b, f2b = run(True)
-    assert torch.equal(f1, f1b) and (not cn or torch.equal(f2, f2b)), "bitwise reproducible"
-
-
 WS_CASES = [
     # cin, cout, (N, T, H, W), residual, gate+swish, activation -- weight-stationary pointwise kernel (pwconv_ws.hip): every template k-step count,
     # both sub-tile counts, every (channel waves, position waves) split; M never a multiple of the block tile, clips shorter than two tiles so

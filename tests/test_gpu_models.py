@@ -12,7 +12,7 @@ from util import (CFG_PPNET, CFG_PPNET_BOTTLENECK, CFG_VIDEO_R2P1D, CFG_VIDEO_X3
 pytestmark = pytest.mark.gpu
 # bf16 (activations / weights, fp32 accumulation) against the fp32 oracle, whole model: max |similarity| error, max |logit| error, mean relative
 # occurrence-map error.  Observed 1.2e-4 .. 2.9e-4 / 1.3e-4 .. 4e-4 / <= 9e-3 (round 2); fp32 stays the <= 1e-3 parity path.
-BF16_SIM, BF16_LOGITS, BF16_OCC_REL = 2e-3, 2e-2, 2e-2
+BF16_SIM, BF16_LOGITS, BF16_OCC_REL = 1e-3, 2e-3, 2e-2  # round 5: the headline dtype held to north_star's own 1e-3 (observed 1.2e-4 .. 2.9e-4)
 DEV = "cuda"
 
 
@@ -80,6 +80,28 @@ def test_video_models_fp32_vs_oracle(cfg, shape):
     assert_close(pdist, ref["proto_dist"], 1e-3, 0, "prototype distances")
     assert_close(logits, ref["logits"], 1e-3, 0, "logits")
     assert_close(feats, ref["features_extracted"], 1e-3 * float(ref["features_extracted"].abs().max()), 1e-3, "features_extracted")
+
+
+@pytest.mark.parametrize("cfg,shape", [(CFG_VIDEO_X3D, (2, 3, 4, 64, 64)), (CFG_XPROTO, (2, 3, 96, 96))])
+def test_stand_alone_occurrence_map_methods(cfg, shape):
+    """get_occurence_map_absolute_val / _softmaxed on the trunk output (XProtoNet.py:75-85, Video_XProtoNet.py:106-109): the map forward()
+    returns, and the softmax of the same pre-activation, both against the oracle's occurrence module."""
+    m = _gpu(cfg)
+    x = synth.echo_clips(shape)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = oracle.nets.xprotonet_forward(sd, x, arch=cfg["base_architecture"])
+    with torch.no_grad():
+        feat = m.cnn_backbone(x.to(DEV))
+        _, _, occ = m(x.to(DEV))
+    om = m.get_occurence_map_absolute_val(feat)  # no torch.no_grad() around it: the method must not need one
+    assert tuple(om.shape) == tuple(ref["occurrence_map"].shape) and not om.requires_grad
+    assert_close(om, ref["occurrence_map"], 1e-3 * max(1.0, float(ref["occurrence_map"].max())), 1e-3, "stand-alone occurrence map vs oracle")
+    assert_close(om, occ, 1e-4 * max(1.0, float(occ.max())), 1e-4, "stand-alone occurrence map vs forward()'s")
+    sm = m.get_occurence_map_softmaxed(feat)
+    n, p = sm.shape[:2]
+    assert tuple(sm.shape) == tuple(om.shape)
+    assert_close(sm.reshape(n, p, -1).sum(-1), torch.ones(n, p), 1e-5, 0, "softmaxed map sums to one per prototype")
+    assert_close(sm, oracle.heads.occurrence_map_softmaxed(sd, ref["backbone_features"]), 1e-4, 1e-3, "softmaxed map vs oracle")
 
 
 @pytest.mark.parametrize("cfg,shape", [(CFG_VIDEO_X3D, (2, 3, 4, 64, 64)), (CFG_VIDEO_R2P1D, (1, 3, 8, 32, 32)), (CFG_XPROTO, (2, 3, 128, 128))])
@@ -505,29 +527,3 @@ def test_ppnet_callable_prototype_activation():
         other, _ = m(x)
         assert_close(other, torch.nn.functional.linear(torch.exp(-min_d / 64.0), m.last_layer.weight), 1e-6, 1e-6, "callable logits")
         assert_close(m.distance_2_similarity(min_d), torch.exp(-min_d / 64.0), 0, 0, "distance_2_similarity with a callable")
-
-
-@pytest.mark.parametrize("cfg_name", ["CFG_VIDEO_X3D", "CFG_VIDEO_R2P1D"])
-def test_side_stream_branches_give_the_same_outputs(cfg_name, monkeypatch):
-    """PASN_BRANCH=1 (opt-in): shortcut / downsample convs run on the plan's side stream beside their block's main branch, launch by launch
-    and inside a captured graph (fork / join edges).  Same launches, same operands: outputs bit-identical to the single chain, and the
-    side launch's operands are not handed to the main branch while it runs (the arena rule of PlanBuilder.join)."""
-    from protoasnet_amd.graph import GraphedForward
-
-    cfg = globals()[cfg_name]
-    shape = (2, 3, 16, 160, 160) if cfg_name == "CFG_VIDEO_X3D" else (2, 3, 16, 112, 112)
-    x = synth.echo_clips(shape).to(DEV).bfloat16()
-    outs = {}
-    for arm in ("0", "1"):
-        monkeypatch.setenv("PASN_BRANCH", arm)
-        m = _gpu(cfg).set_compute_dtype(torch.bfloat16)
-        with torch.no_grad():
-            eager = [t.clone() for t in m(x)]
-        plan = m.cnn_backbone.plan_for(x)
-        assert bool(plan.op_side) == (arm == "1")
-        graphed = [t.clone() for t in GraphedForward(m)(x)]
-        for a, b in zip(eager, graphed):
-            assert torch.equal(a, b)
-        outs[arm] = eager
-    for a, b in zip(outs["0"], outs["1"]):
-        assert torch.equal(a, b)

@@ -1,6 +1,6 @@
 # x3d_expdw kernel time under its timing ablations (PASN_EXPDW_ABL bits: 1 expand MFMAs, 2 expand epilogue arithmetic, 4 x DMA, 8 stencil MFMAs, 16 output epilogue + stores)
 #   bash tools/expdw_abl.sh 0 1 2 3 8 16 31      (0 = the product instance)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for A in "$@"; do
   if [ "$A" != "0" ]; then export PASN_EXPDW_ABL=$A PASN_EXPDW_S1=0; else unset PASN_EXPDW_ABL PASN_EXPDW_S1; fi  # (the ablation instances exist at stride 2 only)

@@ -1,5 +1,5 @@
 # chain-head kernel time under its timing ablations (PASN_HC_ABL bits: 1 MFMAs, 2 weight loads, 4 x DMA, 8 epilogues): bash tools/hc_ablate.sh 0 1 2 4 8 15
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for A in "$@"; do
   export PASN_HC_ABL=$A

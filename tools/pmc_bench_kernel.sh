@@ -2,7 +2,7 @@
 #   usage (GPU box): bash tools/pmc_bench_kernel.sh x3d_expdw tag
 # Counter passes never share a run with tracing beyond --kernel-trace.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 PAT=${1:-x3d_expdw}
 O=$R/gpurun_out/pmcb_${2:-x}
 mkdir -p $O

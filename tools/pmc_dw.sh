@@ -1,7 +1,7 @@
 # PMC profile of ONE depthwise layer through tools/kbench.py (optimisation tool).  usage (GPU box): bash tools/pmc_dw.sh "54 1 16 56 56" tag
 # env PASN_DWM2 etc. pass through.  Counter passes never share a run with tracing beyond --kernel-trace.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 CFG=${1:-"108 1 16 28 28"}
 O=$R/gpurun_out/pmcdw_${2:-x}
 mkdir -p $O

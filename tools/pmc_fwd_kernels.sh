@@ -1,11 +1,11 @@
 # Issue-side counters of every trunk kernel of the headline forward (optimisation tool): which pipes are busy.
 #   usage (GPU box): bash tools/pmc_fwd_kernels.sh tag
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/pmcf_${1:-x}
 mkdir -p $O
 run() { n=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -o p -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-clips 0 --no-secondary --no-roofline --no-graph > $O/$n.log 2>&1 || echo "pass $n failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -o p -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-clips 0 --no-secondary --no-roofline --no-graph > $O/$n.log 2>&1 || { echo "pass $n failed (see $O/$n.log)"; exit 1; }
 }
 run a SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
 run b SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES

@@ -1,6 +1,6 @@
 # Instruction-cache counters per kernel instance of one bench.py run (GPU box):  bash tools/pmc_icache.sh [bench args...]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/pmc_icache
 rm -rf $O; mkdir -p $O
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVES --output-format csv -d $O/a -o p -- python3 $R/bench.py --steps 3 --warmup 2 --cpu-clips 0 --no-roofline "$@" > $O/a.log 2>&1 || echo "pass a failed"

@@ -1,7 +1,7 @@
 # SQ counter passes over one tools/kbench.py launch:  bash tools/pmc_kbench.sh <grep-pattern> <kbench args...>
 # (separate --pmc passes, kernel-trace only -- see the rocprofv3 rules in the round instructions)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 PAT=$1; shift
 O=$R/gpurun_out/pmck
 rm -rf $O; mkdir -p $O

@@ -3,7 +3,9 @@
 
     rocprofv3 --kernel-trace --mangled-kernels --pmc FETCH_SIZE --output-format csv -d OUT/fetch -o p -- python3 bench.py ...
     rocprofv3 --kernel-trace --mangled-kernels --pmc WRITE_SIZE --output-format csv -d OUT/write -o p -- python3 bench.py ...
-    python tools/pmc_traffic.py OUT/fetch/p_counter_collection.csv OUT/write/p_counter_collection.csv > profiles/pmc_traffic.json
+    python tools/pmc_traffic.py OUT/fetch/p_counter_collection.csv OUT/write/p_counter_collection.csv [TAG] > profiles/pmc_traffic.json
+
+TAG (e.g. r05c) is stored under "_run" so that bench.py's `roofline.traffic_source` can say which stored run the figure is from.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE / WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE reports exactly HALF of the bytes of wide (16 B/lane) coalesced reads, which is the access shape of
@@ -63,6 +65,8 @@ def main():
         wr = 1024.0 * write.get(k, 0.0) / max(nw.get(k, 1), 1)
         out[k] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "traffic_bytes_per_launch": round(rd + wr), "launches_sampled": int(nf.get(k, 0))}
+    if len(sys.argv) > 3:
+        out["_run"] = {"tag": sys.argv[3]}
     json.dump(out, sys.stdout, indent=1)
 
 

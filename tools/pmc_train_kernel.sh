@@ -2,13 +2,13 @@
 #   usage (GPU box): bash tools/pmc_train_kernel.sh grad_pass tag
 # Counter passes never share a run with tracing beyond --kernel-trace.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 PAT=${1:-grad_pass}
 O=$R/gpurun_out/pmct_${2:-x}
 mkdir -p $O
 run() { # name counters...
   n=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -o p -- python3 $R/tools/train_bench.py --steps 1 --warmup 1 --loss reference > $O/$n.log 2>&1 || echo "pass $n failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -o p -- python3 $R/tools/train_bench.py --steps 1 --warmup 1 --loss reference > $O/$n.log 2>&1 || { echo "pass $n failed (see $O/$n.log)"; exit 1; }
 }
 run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run b SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY

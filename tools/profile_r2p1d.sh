@@ -1,6 +1,6 @@
 # R(2+1)D-18[:-3] trunk evidence (GPU box):  bash tools/profile_r2p1d.sh r02b  -> gpurun_out/prof_<tag>_r2p1d/{kernel_stats.csv,bench.json,per_launch_table.txt}
 TAG=${1:-rXX}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_${TAG}_r2p1d
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

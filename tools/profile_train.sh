@@ -1,7 +1,7 @@
 # Training-step evidence on the GPU box:  bash tools/profile_train.sh r01e
 #   -> gpurun_out/prof_train_<tag>/{kernel_stats.csv, per_launch.txt, bench_bf16.json, bench_f32.json}
 TAG=${1:-rXX}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_train_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

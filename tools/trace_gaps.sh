@@ -1,7 +1,7 @@
 # Free-running kernel timeline of the forward bench under two stencil routings: per-step sum of kernel durations and of the gaps between
 # consecutive kernels (rocprofv3 --kernel-trace timestamps).  usage (GPU box): bash tools/trace_gaps.sh > gpurun_out/trace_gaps.txt
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for v in 14 1000; do
   O=$R/gpurun_out/trace_w$v
   rm -rf $O; mkdir -p $O

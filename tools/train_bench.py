@@ -106,6 +106,7 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(loss), "non-finite loss"
+    exchange = _time_exchange(params, world, dev) if world > 1 else None
     if rank == 0 and os.environ.get("PASN_TB_TORCHPROF"):
         # which torch-side ops (weight repacking, gradient accumulation, optimizer) a step issues, with their Python call sites
         from torch.profiler import ProfilerActivity, profile
@@ -168,10 +169,79 @@ def main(argv=None):
             "launches": {"forward": plan.n_fwd, "backward": len(plan.ops) - plan.n_fwd}, "arena_bytes": plan.arena_bytes,
             "naive_bytes": plan.naive_bytes, "grad_bucket_bytes": plan.gsize * 4, "loss": round(float(loss.detach()), 5),
             "max_memory_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
-            "roofline": roofline, "device_ms_by_entry_point": per_entry,
+            "roofline": roofline, "device_ms_by_entry_point": per_entry, "exchange": exchange,
         }))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _time_exchange(params, world, dev, reps: int = 10):
+    """The step's one collective measured ALONE (one-shot vs ring), after the timed region, on the gradients as the last step
+    left them: bucket bytes, and device time per exchange (HIP events on the launch stream, MAX over ranks) of three formulations --
+    ``all_reduce`` (what the step uses: RCCL picks ring / tree), ``reduce_scatter + all_gather`` (the ring's two halves as explicit calls)
+    and ``all_gather + local sum`` (one-shot: every rank pulls every peer's whole bucket over its own xGMI links, world x the bytes, one
+    step).  Gradients are restored afterwards.  Only meaningful on RCCL; on gloo (CPU rehearsal) the numbers are host times."""
+    from protoasnet_amd import dp
+
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = dp.flat_gradient_view(grads)
+    in_place = flat is not None
+    if flat is None:
+        flat = torch.cat([g.flatten() for g in grads])
+    saved = flat.clone()
+    gloo = dist.get_backend() == "gloo"
+    n = flat.numel()
+    pad = (-n) % world
+    buf = torch.zeros(n + pad, dtype=flat.dtype, device=flat.device)
+    gathered = torch.empty(world * (n + pad), dtype=flat.dtype, device=flat.device)
+    shard = torch.empty((n + pad) // world, dtype=flat.dtype, device=flat.device)
+
+    def timed(fn):
+        try:
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            if gloo:
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                ms = (time.perf_counter() - t0) * 1e3 / reps
+            else:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / reps
+            t = torch.tensor([ms], dtype=torch.float64, device="cpu" if gloo else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(float(t.item()), 4)
+        except Exception as e:  # noqa: BLE001 -- a formulation the backend lacks must not cost the line
+            return f"{type(e).__name__}: {e}"[:120]
+
+    def h(t):  # gloo rehearsal: collectives on host copies
+        return t.cpu() if gloo else t
+
+    def f_allreduce():
+        dist.all_reduce(h(buf))
+
+    def f_rs_ag():
+        dist.reduce_scatter_tensor(h(shard), h(buf))
+        dist.all_gather_into_tensor(h(buf), h(shard))
+
+    def f_oneshot():
+        g = h(gathered)
+        dist.all_gather_into_tensor(g, h(buf))
+        g.view(world, -1).sum(0, out=h(buf))
+
+    buf[:n].copy_(saved)
+    out = {"bucket_bytes": n * flat.element_size(), "in_place_on_the_arena": in_place, "reps": reps, "unit": "ms per exchange (max over ranks)",
+           "all_reduce": timed(f_allreduce), "reduce_scatter_all_gather": timed(f_rs_ag), "all_gather_local_sum_one_shot": timed(f_oneshot)}
+    if isinstance(out["all_reduce"], float) and out["all_reduce"] > 0:
+        out["all_reduce_bus_GBps"] = round(2 * (world - 1) / world * out["bucket_bytes"] / out["all_reduce"] / 1e6, 1)
+    flat.copy_(saved)
+    return out
 
 
 if __name__ == "__main__":

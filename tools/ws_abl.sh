@@ -3,7 +3,7 @@
 # Runs on the tuning build (protoasnet_amd.build_extension(variant="tuning"): -DPASN_TUNING -DPASN_WS_ABLATE; the product kernel compiles the flag
 # tests out: they cost 0.5 % of the step, log entry 96) and WITHOUT the hipGraph replay: every kernel then runs exactly warm-up + steps = 13 times,
 # which is the divisor below (with the graph-enabled bench each kernel ran 17 times and the reported us/step were 31 % high: ADVICE round 3).
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export PASN_LIB_PATH=$R/protoasnet_amd/lib/libprotoasnet_amd_tuning.so
 cd /tmp && export TMPDIR=/tmp
 for A in "$@"; do
