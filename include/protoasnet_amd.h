@@ -299,6 +299,9 @@ typedef struct pasn_xproto_desc {
  */
 int pasn_x3d_expdw_supported(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype);
 int pasn_x3d_expdw_pool_blocks(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype);
+/* which kernel pasn_x3d_expdw_fwd runs for the pair: 0 = block-diagonal stencil operands (x3d_expdw.hip), 1 = per-channel Toeplitz operands on a
+ * channel-planar image (x3d_expdw_tz.hip, stride 1, round 5), -1 = pair not covered.  Same arguments, same results up to fp32 summation order. */
+int pasn_x3d_expdw_variant(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype);
 int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, const float* bias_a, const float* w, const float* scale,
                        const float* bias, void* y, float* pool_partial, const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype,
                        void* stream);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pasn_xproto_head_workspace_bytes": (c_size_t, [POINTER(XProtoDesc), c_int]),
     "pasn_xproto_head_fwd": (c_int, [c_void_p] * 17 + [POINTER(XProtoDesc), c_int, c_void_p]),
     "pasn_x3d_expdw_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int]),
+    "pasn_x3d_expdw_variant": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int]),
     "pasn_x3d_expdw_pool_blocks": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_int]),
     "pasn_x3d_expdw_fwd": (c_int, [c_void_p] * 9 + [POINTER(ConvDesc), POINTER(ConvDesc), c_int, c_void_p]),
     "pasn_xproto_chain_supported": (c_int, [POINTER(XProtoDesc), c_int]),

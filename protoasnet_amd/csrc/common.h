@@ -149,8 +149,15 @@ struct XeGeom {
     int Tc, nT, upb, chunks, bpc;   // T chunk (+count), units per block, SE partial rows per clip, blocks per clip
     int abl;                        // timing ablations (PASN_EXPDW_ABL; results are wrong when set)
     int fuse;                       // steady-state step as one scheduling region (PASN_EXPDW_FUSE=0: expand, then stencil)
+    // x3d_expdw_tz.hip (round 5): the Toeplitz formulation on a channel-planar image, stride 1; tz = 1: that kernel runs, the fields above are unused
+    int tz, tzCG, tzRTH, tzRTW;     // 16-channel groups, regions (8 x 14 outputs) per frame
+    int tzTc, tznT, tzChunks;       // T chunk (+count), SE partial rows per clip (= units per clip)
+    int tzXS, tzLds;                // 16-byte slots per staged x position, dynamic LDS
 };
 XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype);
+void xe_geom_tz(XeGeom& g, const pasn_conv_desc& de, const pasn_conv_desc& d);
+int launch_x3d_expdw_tz(const void* x, const void* wa, const float* ba, const float* w, const float* scale, const float* bias, void* y, float* pool,
+                        const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s);
 int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
                      void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s);
 // x3d_edp.hip: a whole X3D block of the 7 x 7 stage (expand -> stencil -> project [-> next expand]) in one launch, both wide tensors in LDS; ok = 0: not covered

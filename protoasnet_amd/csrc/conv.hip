@@ -984,6 +984,13 @@ extern "C" int pasn_x3d_expdw_pool_blocks(const pasn_conv_desc* de, const pasn_c
     const XeGeom g = xe_geom(f, *d, dtype);
     return g.ok ? g.chunks : 0;
 }
+extern "C" int pasn_x3d_expdw_variant(const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype) {
+    if (!conv_desc_ok(de) || !conv_desc_ok(d)) return -1;
+    pasn_conv_desc f = *de;
+    f.w_frag = 1;
+    const XeGeom g = xe_geom(f, *d, dtype);
+    return g.ok ? (g.tz ? 1 : 0) : -1;
+}
 extern "C" int pasn_x3d_expdw_fwd(const void* x, const void* wa, const float* scale_a, const float* bias_a, const float* w, const float* scale,
                                   const float* bias, void* y, float* pool_partial, const pasn_conv_desc* de, const pasn_conv_desc* d, int dtype,
                                   void* stream) {

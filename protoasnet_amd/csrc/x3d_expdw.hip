@@ -548,7 +548,7 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     // With the ReLU-only expand epilogue (entry 81) the Swish (non-SE) blocks of those planes win too, narrowly (10 845 -> 10 875 clips/s).
     const char* s1m = tune("PASN_EXPDW_S1");  // 0: off; 1: the SE blocks only
     const bool s1 = ss == 1 && d.Wo >= 56 && !(s1m && s1m[0] == '0') && (d.act == PASN_ACT_NONE || (d.act == PASN_ACT_SWISH && !(s1m && s1m[0] == '1')));
-    if (ss != 2 && !s1) return g;
+    if (ss != 2 && ss != 1) return g;
     const bool dw = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sw == ss && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
                     d.To == d.Ti && d.Ho == (d.Hi - 1) / ss + 1 && d.Wo == (d.Wi - 1) / ss + 1 && d.Cin_p == d.Cout_p && d.Cin == d.Cout &&
                     d.Cout_p % 8 == 0;
@@ -560,6 +560,19 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
     const int nks = de.w_kc / 16;
     if (nks > 2) return g;  // (the LDS check below admits block widths up to 24 channels: three 16-byte pieces per staged x position)
     if ((long)d.Ti * d.Hi * d.Wi * de.Cin_p * 2 >= (1L << 31) || (long)d.To * d.Ho * d.Wo * d.Cout_p * 2 >= (1L << 31)) return g;
+    // round 5: at stride 1 the Toeplitz formulation (x3d_expdw_tz.hip) takes the pair wherever the planes are wide enough to fill its
+    // 8 x 14 regions (same coverage rule as the stride-1 use of this kernel; PASN_EXPDW_TZ=0: off)
+    if (ss == 1 && s1) {
+        xe_geom_tz(g, de, d);
+        if (g.tz) {
+            g.SS = 1;
+            g.chunks = g.tzChunks;
+            g.lds = g.tzLds;
+            g.ok = 1;
+            return g;
+        }
+    }
+    if (ss != 2 && !s1) return g;
     const int NT = ss == 2 ? XeR<2>::NT : XeR<1>::NT, POS = ss == 2 ? XeR<2>::POS : XeR<1>::POS, FRB = ss == 2 ? XeR<2>::FRB : XeR<1>::FRB;
     g.SS = ss;
     g.KS = 2;
@@ -604,6 +617,10 @@ XeGeom xe_geom(const pasn_conv_desc& de, const pasn_conv_desc& d, int dtype) {
 
 int launch_x3d_expdw(const void* x, const void* wa, const float* sa, const float* ba, const float* w, const float* scale, const float* bias,
                      void* y, float* pool, const pasn_conv_desc& de, const pasn_conv_desc& d, const XeGeom& g, hipStream_t s) {
+    if (g.tz) {
+        PASN_REQUIRE(sa == nullptr, "x3d_expdw (Toeplitz form): norm_a's scale folded into the expand weights (scale_a == NULL)");
+        return launch_x3d_expdw_tz(x, wa, ba, w, scale, bias, y, pool, de, d, g, s);
+    }
     const dim3 grid((unsigned)(g.bpc * d.N)), block(256);
 #define PASN_XEF(KS_, ACT_, SS_, ABL_, FOLD_)                                                                                    \
     do {                                                                                                                         \

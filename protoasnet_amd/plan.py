@@ -709,7 +709,9 @@ class PlanBuilder:
         self._use(xb, yb, pb_)
         in_pos, out_pos = x.N * x.positions, y.N * y.positions
         actc = _lib.ACT[act_b]
-        self._note("expand+dwconv", f"x3d_expdw_kernel<{2 if kca // 16 <= 2 else 3},{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1},{s[1]}>",
+        tz = int(self.lib.pasn_x3d_expdw_variant(ctypes.byref(de), ctypes.byref(d), self.code)) == 1
+        self._note("expand+dwconv", f"x3d_expdw_tz_kernel<1,{actc},{'true' if pool else 'false'}>" if tz else
+                   f"x3d_expdw_kernel<{2 if kca // 16 <= 2 else 3},{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1},{s[1]}>",
                    (in_pos * x.C + out_pos * y.C + cm * x.C) * self.es + (y.N * pool_blocks * y.C * 4 if pool else 0),
                    2 * in_pos * cm * x.C + 2 * out_pos * y.C * 27)
         self.meta[-1]["shape"] = f"{x.C}->{cm} k111 + dw k333 s1{s[1]}{s[2]} in{x.T}x{x.H}x{x.W} out{y.T}x{y.H}x{y.W}"

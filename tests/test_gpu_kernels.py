@@ -455,7 +455,8 @@ def test_conv_with_fused_strided_shortcut(inner, cout, cin2, thw, gate, monkeypa
 @pytest.mark.parametrize("se", [False, True])
 @pytest.mark.parametrize("cin,cm,n,thw,stride", [(24, 54, 2, (4, 16, 30), 2), (24, 108, 3, (5, 13, 17), 2), (24, 54, 2, (18, 12, 56), 2),
                                                  (16, 40, 2, (3, 7, 9), 2), (24, 54, 1, (2, 2, 3), 2), (8, 72, 2, (3, 11, 16), 2),
-                                                 (24, 54, 2, (4, 14, 56), 1), (24, 54, 2, (18, 7, 59), 1), (16, 40, 3, (3, 13, 70), 1)])
+                                                 (24, 54, 2, (4, 14, 56), 1), (24, 54, 2, (18, 7, 59), 1), (16, 40, 3, (3, 13, 70), 1),
+                                                 (24, 54, 2, (5, 56, 56), 1), (24, 54, 1, (1, 9, 57), 1), (8, 24, 2, (7, 17, 71), 1)])
 def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, stride, se):
     """Front half of an X3D block: 1x1x1 expand conv + BN + ReLU -> depthwise 3x3x3 conv, stride (1,2,2) (a stage's first block) or stride 1
     (the blocks of planes >= 56 wide), + BN (+ Swish, or the squeeze-excite pool partial rows) in ONE launch with the expanded activation in LDS (pasn_x3d_expdw_fwd) -- against torch on the
@@ -483,12 +484,13 @@ def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, stride, 
     ref = pre if se else pre * torch.sigmoid(pre)
     conv_a, conv_b, bn_a, bn_b = conv_a.to(DEV), conv_b.to(DEV), bn_a.to(DEV), bn_b.to(DEV)
 
-    def run(fused: bool):
+    def run(fused: bool, want_kernel: str = "x3d_expdw"):
         pb = _pb(dtype)
         xa, xs = _cl_input(pb, x, dtype)
         if fused:
             out = pb.expand_dw(xa, conv_a, bn_a, conv_b, bn_b, act_b, pool=se)
             assert out is not None and pb.meta[-1]["kind"] == "expand+dwconv", "the fused launch must cover this pair"
+            assert pb.meta[-1]["kernel"].startswith(want_kernel + "<"), pb.meta[-1]["kernel"]
         else:
             e = pb.conv(xa, conv_a, bn_a, act="relu")
             out = pb.dwconv(e, conv_b, bn_b, act=act_b, pool=se)
@@ -504,10 +506,22 @@ def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, stride, 
         torch.cuda.synchronize()
         return o, pool_t, len(plan.ops)
 
-    out, pool_f, n_f = run(True)
+    # stride 1: the Toeplitz kernel on a channel-planar image (x3d_expdw_tz.hip, round 5) is the default; the block-diagonal kernel is the
+    # PASN_EXPDW_TZ=0 route -- both are held to the same bounds, and to each other
+    out, pool_f, n_f = run(True, "x3d_expdw_tz_kernel" if stride == 1 else "x3d_expdw_kernel")
     two, pool_t, n_t = run(False)
     assert n_f == 1 and n_t == 2
     scale = max(1.0, float(ref.abs().max()))
+    if stride == 1:
+        with _lib_env(PASN_EXPDW_TZ="0"):
+            old, pool_o, _ = run(True, "x3d_expdw_kernel")
+        assert_close(_from_cl(out, cm), _from_cl(old, cm), 1.6e-2 * scale, 1e-2, "Toeplitz vs block-diagonal fused launch")  # one bf16 ulp
+        if se:
+            assert_close(pool_f.sum(1)[:, :cm], pool_o.sum(1)[:, :cm], 1e-3 * float(pool_o.sum(1).abs().max()) + 1e-2, 1e-3, "pool sums of the two fused kernels")
+        for tc in (1, 3):  # chunked march (odd chunks: a step with one output frame) == the one-chunk march, bit for bit
+            with _lib_env(PASN_EXPDW_TC=str(tc)):
+                ch, pool_c, _ = run(True, "x3d_expdw_tz_kernel")
+            assert torch.equal(ch, out), f"T chunk {tc}"
     assert_close(_from_cl(out, cm), ref, 3e-2 * scale, 2e-2, f"fused expand + stencil {cin}->{cm} {thw}")
     assert_close(_from_cl(out, cm), _from_cl(two, cm), 1.6e-2 * scale, 1e-2, "fused vs the two launches")  # one bf16 ulp of the output
     if out.shape[-1] > cm:

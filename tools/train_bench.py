@@ -181,6 +181,8 @@ def _time_exchange(params, world, dev, reps: int = 10):
     ``all_reduce`` (what the step uses: RCCL picks ring / tree), ``reduce_scatter + all_gather`` (the ring's two halves as explicit calls)
     and ``all_gather + local sum`` (one-shot: every rank pulls every peer's whole bucket over its own xGMI links, world x the bytes, one
     step).  Gradients are restored afterwards.  Only meaningful on RCCL; on gloo (CPU rehearsal) the numbers are host times."""
+    import torch.distributed as dist
+
     from protoasnet_amd import dp
 
     grads = [p.grad for p in params if p.grad is not None]
