@@ -101,6 +101,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_HALO_ABL",         "dev",   "halo implicit GEMM timing ablations"},
     {"PASN_WS_ABL",           "dev",   "weight-stationary conv timing ablations (needs -DPASN_WS_ABLATE too)"},
     {"PASN_EDP_STAMPS",       "dev",   "whole-block launch of the 7 x 7 stage: in-kernel phase stamps (tools/edp_bench.py)"},
+    {"PASN_TZ_STAMPS",        "dev",   "Toeplitz expand + stencil launch: in-kernel phase stamps (tools/tz_bench.py)"},
     {"PASN_PE_STAMPS",        "dev",   "streamed project + expand pair: in-kernel phase stamps (tools/pe_bench.py)"},
     {"PASN_DW_WT",            "dev",   "strip stencil: outputs per thread (4, 7, 8)"},
     {"PASN_HALO_SP",          "dev",   "halo implicit GEMM: slice pipeline on / off"},

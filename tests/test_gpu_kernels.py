@@ -516,8 +516,9 @@ def test_expand_conv_and_strided_stencil_in_one_launch(cin, cm, n, thw, stride, 
         with _lib_env(PASN_EXPDW_TZ="0"):
             old, pool_o, _ = run(True, "x3d_expdw_kernel")
         assert_close(_from_cl(out, cm), _from_cl(old, cm), 1.6e-2 * scale, 1e-2, "Toeplitz vs block-diagonal fused launch")  # one bf16 ulp
-        if se:
-            assert_close(pool_f.sum(1)[:, :cm], pool_o.sum(1)[:, :cm], 1e-3 * float(pool_o.sum(1).abs().max()) + 1e-2, 1e-3, "pool sums of the two fused kernels")
+        if se:  # (norm_b's scale meets the stencil weights before THEIR rounding in the Toeplitz kernel, after the MFMAs in the other: a per-channel
+            # relative difference of up to one bf16 ulp per tap, which the sum over positions does not average away; both are held to the fp64 sums below)
+            assert_close(pool_f.sum(1)[:, :cm], pool_o.sum(1)[:, :cm], 2e-2 * float(pre.abs().max()) * pre[0, 0].numel() ** 0.5 + 1e-3, 1e-2, "pool sums of the two fused kernels")
         for tc in (1, 3):  # chunked march (odd chunks: a step with one output frame) == the one-chunk march, bit for bit
             with _lib_env(PASN_EXPDW_TC=str(tc)):
                 ch, pool_c, _ = run(True, "x3d_expdw_tz_kernel")
