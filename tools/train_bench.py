@@ -131,7 +131,9 @@ def main(argv=None):
             return run
         plan.ops[:] = [wrap(i, op) for i, op in enumerate(orig)]
         was_serial, plan.serial = plan.serial, True  # per-launch times: every launch on the bracketed stream
-        step(); torch.cuda.synchronize()
+    if world > 1 or rank == 0:
+        step(); torch.cuda.synchronize()  # EVERY rank runs the bracketed step: it contains the gradient exchange (a collective)
+    if rank == 0:
         plan.ops[:] = orig
         plan.serial = was_serial
         agg = {}
