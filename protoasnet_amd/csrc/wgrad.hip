@@ -529,7 +529,16 @@ namespace pasn {
 template <int KT>
 struct WgLds {
     static constexpr int PITCH = KT * 2 + 16;  // bytes per channel row
+    static constexpr int SLOTS = KT / 8;       // 16-byte slots (8 rows of a channel) per channel row
+    static_assert((SLOTS & (SLOTS - 1)) == 0, "the slot rotation below wraps with a mask");
 };
+// Slot rotation (round 5).  A staging thread writes the 8 rows of channels 8 cg .. 8 cg + 7 as eight 16-byte LDS writes, and the 8 lanes a
+// ds_write_b128 serves together hold 8 CONSECUTIVE channel groups of one row octet: 8 * PITCH bytes apart = a multiple of 128 bytes whatever the
+// pitch -- one bank group, 8-way conflicts on every staging write (SQ counters, tools/pmc_lds_audit.sh: 24 LDS cycles per LDS instruction, 78 %
+// of them conflicts, in every pointwise weight-gradient kernel).  Rotating a channel row's slots by its channel group, slot' = (slot + cg) mod
+// SLOTS, spreads the 8 lanes over 8 slots; a fragment read (32 channel rows of one slot) adds the row's group the same way: 17 slots of pitch x
+// channel row + rotation stays conflict-free except for one pair of lanes per group.
+__device__ __forceinline__ int wg_slot(int slot, int cg, int slots) { return (slot + cg) & (slots - 1); }
 
 __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&out)[8]) {
     // in[r] = 8 channels of row r (2 per dword); out[c] = 8 rows of channel c (2 per dword)
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
                 for (int i = 0; i < 8; ++i)
                     if (!((okbits >> (v * 8 + i)) & 1u)) pre[v][i] = make_uint4(0, 0, 0, 0);
                 transpose8x8_bf16(pre[v], out);
-                unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * PITCH + r8 * 16;
+                unsigned char* dst = (is_a ? At : Bt) + (size_t)(cg * 8) * PITCH + wg_slot(r8, cg, WgLds<KT>::SLOTS) * 16;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dst + c * PITCH) = out[c];
             }
@@ -649,8 +658,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const __bf16* __rest
         for (int kk = 0; kk < KT / 16; ++kk) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (size_t)(t_co[j] * 32 + m) * PITCH + (kk * 2 + h) * 16);
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (size_t)(t_ci[j] * 32 + m) * PITCH + (kk * 2 + h) * 16);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (size_t)(t_co[j] * 32 + m) * PITCH + wg_slot(kk * 2 + h, t_co[j] * 4 + (m >> 3), WgLds<KT>::SLOTS) * 16);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (size_t)(t_ci[j] * 32 + m) * PITCH + wg_slot(kk * 2 + h, t_ci[j] * 4 + (m >> 3), WgLds<KT>::SLOTS) * 16);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
             }
         }
@@ -740,7 +749,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __rest
         const int ch = (is_a ? co0 : ci0) + cg * 8;
         pok[k] = p < 16 * NG && ch < cpp[k];  // a group past the last tile, or no patch: zeros / nothing
         src[k] = (is_a ? dy : x) + (pok[k] ? ch : 0);
-        dst[k] = p < 16 * NG ? (is_a ? At : Bt) + (size_t)(cg * 8) * WT_PITCH + r8[k] * 16 : nullptr;
+        dst[k] = p < 16 * NG ? (is_a ? At : Bt) + (size_t)(cg * 8) * WT_PITCH + wg_slot(r8[k], cg, WT_KT / 8) * 16 : nullptr;
     }
     f32x16 acc[COT][CIT];
 #pragma unroll
@@ -787,9 +796,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_tile_kernel(const __bf16* __rest
         for (int kk = 0; kk < WT_KT / 16; ++kk) {
             bf16x8 a[COT], b[CIT];
 #pragma unroll
-            for (int i = 0; i < COT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(At + (size_t)((tco + i) * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
+            for (int i = 0; i < COT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(At + (size_t)((tco + i) * 32 + m) * WT_PITCH + wg_slot(kk * 2 + h, (tco + i) * 4 + (m >> 3), WT_KT / 8) * 16);
 #pragma unroll
-            for (int j = 0; j < CIT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bt + (size_t)((tci + j) * 32 + m) * WT_PITCH + (kk * 2 + h) * 16);
+            for (int j = 0; j < CIT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bt + (size_t)((tci + j) * 32 + m) * WT_PITCH + wg_slot(kk * 2 + h, (tci + j) * 4 + (m >> 3), WT_KT / 8) * 16);
 #pragma unroll
             for (int i = 0; i < COT; ++i)
 #pragma unroll

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_gather_kernel(const __bf16* __
     const int ch = (is_a ? co0 : ci0) + cg * 8;
     const bool ch_ok = ch < cp;
     const __bf16* src = (is_a ? dy : x) + (ch_ok ? ch : 0);
-    const int dst = (is_a ? 0 : 64 * PITCH) + (cg * 8) * PITCH + r8 * 16;
+    const int dst = (is_a ? 0 : 64 * PITCH) + (cg * 8) * PITCH + ((r8 + cg) & (WH_KT / 8 - 1)) * 16;  // slot rotation: see wgrad.hip (wg_slot)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_gather_kernel(const __bf16* __
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < WH_KT / 16; ++kk) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (size_t)(tco * 32 + m) * PITCH + (kk * 2 + h) * 16);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (size_t)(tci * 32 + m) * PITCH + (kk * 2 + h) * 16);
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (size_t)(tco * 32 + m) * PITCH + ((kk * 2 + h + tco * 4 + (m >> 3)) & (WH_KT / 8 - 1)) * 16);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (size_t)(tci * 32 + m) * PITCH + ((kk * 2 + h + tci * 4 + (m >> 3)) & (WH_KT / 8 - 1)) * 16);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
