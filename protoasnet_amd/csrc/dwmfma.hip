@@ -53,7 +53,12 @@ constexpr int dwf_pitch(int ss) { return ss == 2 ? 32 : 16; }  // staged positio
 // them on different banks (10 at stride 1, 9 at stride 2: 20 slots apart would put lanes m and m + 4 on the same banks)
 constexpr int dwf_slots(int ss) { return ss == 2 ? 9 : 10; }
 constexpr int dwf_rows(int rpt, int ss) { return (dwf_tiles(rpt, ss) * rpt - 1) * ss + 3; }  // staged rows per region
-constexpr int dwf_ni(int rpt, int ss) { return (dwf_rows(rpt, ss) * dwf_pitch(ss) * dwf_slots(ss) + 63) / 64; }  // 1-KiB DMA instructions per frame
+// 16-byte slots per staged region ROW: the positions' slots + 6 of padding at stride 1 (round 5).  On planes <= 8 wide a position tile holds TWO
+// output rows; with rows exactly 160 slots apart the second row's lanes of an operand read fall on the first row's banks: 2-way conflicts on every
+// read (tools/pmc_lds_audit.sh: 7.7 LDS cycles per instruction, 48 % conflicts in the two-row instance).  166 (= 6 mod 16) makes the 16 addresses
+// of a read cover the 64 banks exactly -- provided the lanes without a position read a cell another lane reads.  One-row tiles are unaffected.
+constexpr int dwf_rowp(int ss) { return dwf_pitch(ss) * dwf_slots(ss) + (ss == 1 ? 6 : 0); }
+constexpr int dwf_ni(int rpt, int ss) { return (dwf_rows(rpt, ss) * dwf_rowp(ss) + 63) / 64; }  // 1-KiB DMA instructions per frame
 
 __device__ __forceinline__ unsigned bf16_bits_rne(float f) {
     const __bf16 b = (__bf16)f;
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
     const int abl = ABLB ? g.abl : 0;   // timing ablations: a separate instance, the product kernel carries none of the checks
     constexpr int RW = dwf_pitch(SS);  // staged positions per region row ((BW - 1) SS + 3 <= RW used)
     constexpr int SLOTS = dwf_slots(SS);
+    constexpr int ROWP = dwf_rowp(SS);  // slots per staged region row
     constexpr int NE = (dwf_ni(RPT, SS) + 3) / 4;  // DMA instructions per wave and frame
     // frame image size is a compile-time constant of the instance (the ring slots, the DMA destinations and the operand reads are then
     // immediates: as run-time scalars they cost ~90 spilled SGPRs, reloaded lane by lane at every frame)
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int tap9 = min(2 * j + (q >> 1), 8);
-        tapoff[j] = ((tap9 / 3) * RW + (tap9 % 3)) * (SLOTS * 16);
+        tapoff[j] = ((tap9 / 3) * ROWP + (tap9 % 3) * SLOTS) * 16;
     }
     const int regions = g.RTH * g.RTW;
     const int units = g.nT * regions;
@@ -198,10 +204,10 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int slot = (wave + 4 * e) * 64 + lane;
-            const int rp = slot / SLOTS, c = slot - rp * SLOTS;
-            const int rr = rp / RW, cc = rp - rr * RW;
+            const int rr = slot / ROWP, rem = slot - rr * ROWP;  // staged row, slot inside it (the row's padding slots fetch nothing)
+            const int cc = rem / SLOTS, c = rem - cc * SLOTS;
             const int hi = h0 * SS - 1 + rr, wi = w0 * SS - 1 + cc;
-            const bool ok = !(abl & 16) && wave + 4 * e < NI && rp < g.RP && cc < (g.BW - 1) * SS + 3 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            const bool ok = !(abl & 16) && wave + 4 * e < NI && rr * RW < g.RP && cc < (g.BW - 1) * SS + 3 && c < npieces && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
             goff[e] = ok ? (unsigned)(((hi * Wi + wi) * Cp + c * 8) * 2) : 0x80000000u;
         }
         const int kdma = max(0, (NI - wave + 3) >> 2);  // DMA instructions of this wave per frame (i = wave + 4e < NI)
@@ -222,8 +228,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3d_mfma_kernel(const __bf16* __r
         const int mrow_lim = lane_ok ? mrow : (1 << 20);  // row of this lane inside its tile, or "never valid"
         const int rows_valid = min(g.BH, d.Ho - h0);                                       // output rows of this region
         const int ntl = (rows_valid + RPT - 1) / RPT;                                      // tiles that hold any of them (wave-uniform)
-        const int lbase0 = ((min(mrow, RPT - 1) * SS * RW + min(mcol, g.BW - 1) * SS) * SLOTS + 2 * wave + (q & 1)) * 16;
-        constexpr int lstep = RPT * SS * RW * SLOTS * 16;                                   // bytes between tiles in the staged image: an immediate
+        const bool mpos = m < RPT * g.BW;  // a lane without a position reads the cell of the tile's last position (a broadcast, not an address of its own)
+        const int lbase0 = ((mpos ? mrow : RPT - 1) * SS * ROWP + (mpos ? mcol : g.BW - 1) * SS * SLOTS + 2 * wave + (q & 1)) * 16;
+        constexpr int lstep = RPT * SS * ROWP * 16;                                         // bytes between tiles in the staged image: an immediate
         const int ystep = RPT * d.Wo * Cp;
         __bf16* yclip = y + (long)n * d.To * d.Ho * d.Wo * Cp;
         const long ofs = (long)d.Ho * d.Wo * Cp;

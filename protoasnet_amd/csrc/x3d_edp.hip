@@ -47,7 +47,12 @@ __device__ __forceinline__ void edp_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int EDP_HW = 7, EDP_S = 49;           // the plane
 constexpr int EDP_RWI = 10, EDP_SLOTS = 10;     // frame image: 9 rows x 10 positions x 10 slots of 16 bytes (8 used: one quad)
-constexpr int EDP_FB = 9 * EDP_RWI * EDP_SLOTS * 16;  // 14400 bytes per frame image
+// Slots per image ROW: 100 + 2 of padding (round 5).  A stencil operand read serves 16 lanes = TWO output rows of 7 positions; with rows exactly
+// 100 slots apart the second row's lanes fall on the first row's banks -- 2-way conflicts on EVERY operand read of a phase that sits at its LDS
+// bound (tools/pmc_lds_audit.sh: 6.6 LDS cycles per instruction, 36 % of them conflicts).  102 (= 6 mod 16) makes the 16 addresses cover the
+// 64 banks exactly, provided the two lanes without a position read a cell another lane reads (broadcast) instead of a clamped one of their own.
+constexpr int EDP_ROWP = EDP_RWI * EDP_SLOTS + 2;
+constexpr int EDP_FB = 9 * EDP_ROWP * 16;  // 14688 bytes per frame image
 constexpr int EDP_CPL = 9;                       // slots per row of the stencil-output chunk
 
 template <int KSA, int KSC, bool NEXT>
@@ -104,10 +109,11 @@ __global__ __launch_bounds__(512) void x3d_edp_kernel(EdpArgs a, EdpGeom g) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int tap9 = min(2 * j + (q4 >> 1), 8);
-        tapoff[j] = ((tap9 / 3) * EDP_RWI + (tap9 % 3)) * (EDP_SLOTS * 16);
+        tapoff[j] = ((tap9 / 3) * EDP_ROWP + (tap9 % 3) * EDP_SLOTS) * 16;
     }
-    const int lbase0 = ((min(mrow, 1) * EDP_RWI + min(mcol, EDP_HW - 1)) * EDP_SLOTS + 2 * ctw + (q4 & 1)) * 16;
-    constexpr int lstep = 2 * EDP_RWI * EDP_SLOTS * 16;
+    const bool mpos = m < 2 * EDP_HW;  // lanes 14, 15 hold no position: they read lane 13's cell
+    const int lbase0 = ((mpos ? mrow : 1) * EDP_ROWP + (mpos ? mcol : EDP_HW - 1) * EDP_SLOTS + 2 * ctw + (q4 & 1)) * 16;
+    constexpr int lstep = 2 * EDP_ROWP * 16;
     const int CT16 = (Cmp + 15) >> 4;
     // project roles: row tile rt, output tiles co = cg, cg + 2, cg + 4
     const int prt = wave & 3, pcg = wave >> 2;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(512) void x3d_edp_kernel(EdpArgs a, EdpGeom g) {
                     const int ti = t0 - 1 + f;
                     const bool wr = colive && r < RI;
                     const bool inclip = ti >= 0 && ti < T;
-                    char* const cell = wr ? fimg + f * EDP_FB + (((ph + 1) * EDP_RWI + pw + 1) * EDP_SLOTS + 4 * ea + h) * 16 : dch + R * EDP_CPL * 16;
+                    char* const cell = wr ? fimg + f * EDP_FB + ((ph + 1) * EDP_ROWP + (pw + 1) * EDP_SLOTS + 4 * ea + h) * 16 : dch + R * EDP_CPL * 16;
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         float v[8];
