@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/ldsaudit_${1:-x}
 mkdir -p $O
-if [ "$2" = "train" ]; then CMD="python3 $R/tools/train_bench.py --steps 1 --warmup 1 --loss reference"; else CMD="python3 $R/bench.py --steps 2 --warmup 1 --cpu-clips 0 --no-secondary --no-roofline --no-graph"; fi
+if [ "$2" = "train" ]; then CMD="python3 $R/tools/train_bench.py --steps 1 --warmup 1 --loss reference"; elif [ "$2" = "r2p1d" ]; then CMD="python3 $R/bench.py --arch resnet2p1d_18 --batch 8 --frames 32 --size 112 --prototypes 40 --classes 4 --steps 2 --warmup 1 --cpu-clips 0 --no-secondary --no-roofline --no-graph"; else CMD="python3 $R/bench.py --steps 2 --warmup 1 --cpu-clips 0 --no-secondary --no-roofline --no-graph"; fi
 run() { n=$1; shift
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -o p -- $CMD > $O/$n.log 2>&1 || { echo "pass $n failed (see $O/$n.log)"; exit 1; }
 }
