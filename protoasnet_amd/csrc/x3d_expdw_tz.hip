@@ -355,8 +355,10 @@ __global__ __launch_bounds__(512, 4) void x3d_expdw_tz_kernel(const __bf16* __re
             const tz_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tz_lds_s16x4_t)(outi + tr_off + ps * 8 * TZ_ORS + 4 * TZ_OCS));
             const tz_u32x2 ua = __builtin_bit_cast(tz_u32x2, a), ub = __builtin_bit_cast(tz_u32x2, b);
             const int to = t + ps;
-            const unsigned off = to < t1 ? ooff : TZ_OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(tz_u32x4{ua.x, ua.y, ub.x, ub.y}, yrsrc, (int)off, (int)((unsigned)to * (unsigned)(oframe * 2)), 0);
+            // (the frame's offset rides in the VECTOR offset, soffset = 0: behind a 16-byte buffer store with an SGPR soffset the compiler puts no
+            // wait state before a VALU write to the store's data registers, and gfx950 needs one -- dw_tz.hip met it; tools/store_hazard_scan.py)
+            const unsigned off = to < t1 ? ooff + (unsigned)to * (unsigned)(oframe * 2) : TZ_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(tz_u32x4{ua.x, ua.y, ub.x, ub.y}, yrsrc, (int)off, 0, 0);
         }
         TZ_STAMP(5 + 6 * k);
         // (each tile's x row for the NEXT pair is requested as soon as the tile's registers are free)

@@ -335,3 +335,26 @@ def test_grey_first_layer_identity_on_the_oracle():
     got = F.conv3d(u * (1 / ECHO_STD) + (-ECHO_MEAN / ECHO_STD), w.sum(1, keepdim=True), stride=(1, 2, 2), padding=(0, 1, 1))
     assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
     assert tuple(gray_to_gray3(u[0]).shape) == (3, 4, 20, 20) and gray_to_gray3(u[0]).stride(0) == 0  # a view, like the reference's expand
+
+
+def test_wide_buffer_stores_carry_no_register_soffset():
+    """A 12- or 16-byte buffer store whose soffset is an SGPR gets no wait state from the compiler before a VALU write to its data registers
+    (LLVM models the hazard for an immediate soffset only); gfx950 needs one -- round 5's dw_tz.hip stored a register pair the next instruction
+    had already overwritten, in a few percent of the runs (profiles/README.md; tools/store_hazard_scan.py finds the pattern in assembly).
+    The sources keep the frame offset in the VECTOR offset instead: every such store names soffset 0."""
+    import glob
+    import re
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "protoasnet_amd", "csrc")
+    calls = 0
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        text = open(path).read()
+        for m in re.finditer(r"__builtin_amdgcn_raw_buffer_store_b(?:96|128)\(", text):
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                i += 1
+            args = text[m.end():i - 1]
+            calls += 1
+            assert re.search(r",\s*0\s*,\s*0\s*$", args), f"{os.path.basename(path)}: wide buffer store with a register soffset: {args[-80:]}"
+    assert calls >= 8

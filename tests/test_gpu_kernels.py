@@ -1055,6 +1055,7 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     fp32 accumulation in both)."""
     tc, upb = geom.split(",")
     monkeypatch.setenv("PASN_DWMFMA", "1")  # every stride-1 layer (default: only the planes at most 8 wide)
+    monkeypatch.setenv("PASN_DW_TZ", "0")   # (planes 9 .. 14 wide take the Toeplitz kernel by default)
     if tc != "0":
         monkeypatch.setenv("PASN_DWMFMA_TC", tc)
         monkeypatch.setenv("PASN_DWMFMA_UPB", upb)
@@ -1072,6 +1073,52 @@ def test_dwconv3d_mfma_variants(thw, geom, c, monkeypatch):
     assert kernel1.startswith("dwconv3d_march_kernel<"), kernel1
     d = (out.float() - out1.float()).abs()
     assert float(d.max()) <= 2.0 ** -6 * max(1.0, float(out1.float().abs().max())), float(d.max())
+
+
+@pytest.mark.parametrize("act", ["swish", "none"])
+@pytest.mark.parametrize("c", [24, 216])
+@pytest.mark.parametrize("thw", [(16, 14, 14), (9, 16, 12), (9, 13, 11), (1, 14, 14), (4, 9, 9), (3, 5, 14), (5, 28, 28), (9, 30, 33), (4, 9, 61), (2, 57, 29)])
+def test_dwconv3d_toeplitz_variants(thw, c, act, monkeypatch):
+    """dw_tz.hip: the stride-1 stencil in Toeplitz form on a channel-planar image (LDS-DMA of the channels-last rows + ds_read_b64_tr_b16).
+    Planes at most 14 wide (the default route: a block's two tiles are row bands of the whole plane): the 14 x 14 stage's plane, planes with a
+    cut second band or none, odd T (a step with one output frame), T = 1, a partial 16-channel group; wider planes (PASN_DW_TZ=all: regions of
+    8 x 28): the 28 x 28 plane, planes cut by the region in both directions, one to three regions per row.  With and without SE partial sums,
+    against torch, against the block-diagonal matrix-core stencil (weights rounded before / after the norm's scale: one bf16 ulp of the
+    output) and bit for bit across T chunks."""
+    bands = thw[2] <= 14 and thw[1] <= 14
+    if not bands:
+        monkeypatch.setenv("PASN_DW_TZ", "all")
+    monkeypatch.setenv("PASN_DWMFMA", "1")
+    x, conv, bn, pre = _march_case(1, c, thw=thw)
+    ref = pre * torch.sigmoid(pre) if act == "swish" else pre
+    out, part, kernel = _run_march(x, conv, bn, act)
+    inst = f"{3 if act == 'swish' else 0},{{}},{'true' if bands else 'false'}"
+    assert kernel == f"dwconv3d_tz_kernel<{inst.format('true')}>", kernel
+    atol, rtol = _tols(torch.bfloat16)
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, c), ref, atol * scale, rtol, f"toeplitz stencil {thw} c{c} {act}")
+    want = pre.sum(dim=(2, 3, 4))
+    assert_close(part.sum(dim=1)[:, :c].cpu(), want, 2e-2 * float(pre.abs().max()) * (pre[0, 0].numel() ** 0.5), 0, "SE partial sums")
+    assert float(out[..., c:].abs().max() if out.shape[-1] > c else 0.0) == 0.0, "padded channels must stay zero"
+    # without pool sums (norm's scale folded into the operands)
+    pb = _pb(torch.bfloat16)
+    xa, xs = _cl_input(pb, x, torch.bfloat16)
+    y = pb.dwconv(xa, conv.to(DEV), bn.to(DEV), act)
+    assert pb.meta[-1]["kernel"] == f"dwconv3d_tz_kernel<{inst.format('false')}>"
+    out0 = pb.finish(xa, y).run(xs).clone()
+    torch.cuda.synchronize()
+    assert_close(_from_cl(out0, c), ref, atol * scale, rtol, f"toeplitz stencil, no pool {thw} c{c} {act}")
+    for tc in (1, 3):
+        monkeypatch.setenv("PASN_DWMFMA_TC", str(tc))
+        outc, partc, kernelc = _run_march(x, conv, bn, act)
+        assert kernelc == kernel and torch.equal(outc, out), f"T chunk {tc}"
+        assert_close(partc.sum(dim=1)[:, :c].cpu(), part.sum(dim=1)[:, :c].cpu(), 1e-3 * float(pre.abs().max()) * (pre[0, 0].numel() ** 0.5), 0, "pool, T chunks")
+    monkeypatch.delenv("PASN_DWMFMA_TC")
+    monkeypatch.setenv("PASN_DW_TZ", "0")
+    out1, part1, kernel1 = _run_march(x, conv, bn, act)
+    assert kernel1.startswith("dwconv3d_mfma_kernel<"), kernel1
+    dd = (out.float() - out1.float()).abs()
+    assert float(dd.max()) <= 2.0 ** -6 * scale, float(dd.max())
 
 
 @pytest.mark.parametrize("wt", [2, 3])
