@@ -10,7 +10,7 @@
 // 4 positions x 16 channels, no vector arithmetic; zeros outside the image come from the DMA's range check.
 //
 // Block = 8 waves = 16 channels x (8 x 28 outputs) of one clip, marching along T two output frames per step over a ring of 4 frame images, two
-// barriers per step: [stencil of pairs k, k + 1 -> output image] | [transpose pair k + 2 over pair k, request the rows of pair k + 3, store].
+// barriers per step: [stencil of pairs k, k + 1 -> output image] | [store, transpose pair k + 2 over pair k, request the rows of pair k + 3].
 // Stencil, operands, output path: x3d_expdw_tz.hip's (5 MFMAs per 224 outputs of a channel, ONE accumulator of 4 registers, 40 registers of
 // Toeplitz operands per wave, ds_read_b64_tr_b16 on the way out, four waves per SIMD).  norm's scale is folded into the operands where no pool
 // sums are taken (a weight rounded after scaling: results agree with dwmfma.hip to one bf16 ulp of the output, not bit for bit).
@@ -51,8 +51,9 @@ __device__ __forceinline__ unsigned tz_bf16_bits(float f) {
 __device__ __forceinline__ void tz_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef PASN_TUNING
 // shader-clock stamps of one block's wave 0 (tuning builds, PASN_TZ_STAMPS = 1 + block; tools/dwtz_bench.py prints them): [0] start, [1] operands
-// built, [2] prologue done, then per step: stencil done, rows landed, barrier passed, stores issued, transposed, barrier passed
-__device__ long long dt_stamps[2 + 6 * 10];
+// built, [2] prologue done, then five per step: stencil done, rows landed, barrier passed + stores issued, pair transposed + next requested,
+// barrier passed
+__device__ long long dt_stamps[62];
 #define TZ_STAMP(i) do { if (g.abl && (int)blockIdx.x == g.abl - 1 && threadIdx.x == 0 && (i) < 62) dt_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TZ_STAMP(i) do { } while (0)
@@ -155,26 +156,46 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
     // into the planar frame image.  Rows and frames outside the tensor: zeros whatever the raw row holds.
     const int tr_in = (4 * q + (m >> 2)) * 32 + (m & 3) * 8;
     const unsigned raw_addr = tz_lds_addr(raw), outi_addr = tz_lds_addr(outi), tmp_addr = tz_lds_addr(ring + 2 * TZ_FS);
-    auto transpose_row = [&](int p, int i, unsigned base_addr) {
-        int fs, rr;
-        const int st = instr(p, i, fs, rr);
-        if (st < 0) return;  // wave-uniform (EXEC is all ones at every transposing read: the branches around them are wave-uniform)
-        const unsigned rmask = st ? 0xffffffffu : 0u;
-        char* img = ring + (((2 * p) & (TZ_NF - 1)) + fs) * TZ_FS + m * TZ_CHS + q * 8;
-        tz_u32x2 uv[2];
+    // One pair of frames in two halves.  stage_read: every transposing read of this wave's rows (one statement, one wait), then -- the rows are
+    // in registers -- the requests that refill them with pair pd (pd < 0: none).  stage_write: the rows into the frame images.
+    struct Staged {
+        tz_u32x2 uv[NR][2];
+        int fs[NR], rr[NR], st[NR];
+    };
+    auto stage_read = [&](Staged& sg, int p, unsigned base_addr, int pd) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) sg.st[i] = instr(p, i, sg.fs[i], sg.rr[i]);  // wave-uniform (EXEC is all ones at every transposing read)
         if (BANDS) {
-            // plane rows rr - 1, rr (staged rows rr, rr + 1 of 16): band 0 holds staged rows 0 .. 9, band 1 rows 8 .. 17 as its rows 0 .. 9
-            tz_read_tr2<0, 512>(base_addr + (fs * 16 + rr) * 512 + tr_in, uv[0], uv[1]);
+            // plane rows rr - 1, rr (staged rows rr, rr + 1 of 16) of both frames
+            tz_read_tr4<0, 512, 16 * 512, 17 * 512>(base_addr + sg.rr[0] * 512 + tr_in, sg.uv[0][0], sg.uv[0][1], sg.uv[1][0], sg.uv[1][1]);
+        } else {
+            // rows wave, wave + 8 (, wave + 16), both column tiles of each
+            tz_read_tr4<0, TZ_BW * 32, 8 * TZ_RAWROW, 8 * TZ_RAWROW + TZ_BW * 32>(base_addr + wave * TZ_RAWROW + tr_in, sg.uv[0][0], sg.uv[0][1], sg.uv[1][0],
+                                                                              sg.uv[1][1]);
+            if (sg.st[NR - 1] >= 0)
+                tz_read_tr2<16 * TZ_RAWROW, 16 * TZ_RAWROW + TZ_BW * 32>(base_addr + wave * TZ_RAWROW + tr_in, sg.uv[NR - 1][0], sg.uv[NR - 1][1]);
+        }
+        if (pd >= 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) dma_row(pd, i, raw);
+        }
+    };
+    auto stage_write = [&](const Staged& sg, int p) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (sg.st[i] < 0) continue;
+            const unsigned rmask = sg.st[i] ? 0xffffffffu : 0u;  // rows and frames outside the tensor: zeros whatever the raw row holds
+            char* img = ring + (((2 * p) & (TZ_NF - 1)) + sg.fs[i]) * TZ_FS + m * TZ_CHS + q * 8;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const tz_u32x2 v = tz_u32x2{uv[j].x & rmask, uv[j].y & rmask};
-                if (rr + j < TZ_RH) *reinterpret_cast<tz_u32x2*>(img + (rr + j) * 32) = v;
-                if (rr + j >= TZ_RT) *reinterpret_cast<tz_u32x2*>(img + TZ_TS + (rr + j - TZ_RT) * 32) = v;
+                const tz_u32x2 v = tz_u32x2{sg.uv[i][j].x & rmask, sg.uv[i][j].y & rmask};
+                if (BANDS) {  // band 0 holds staged rows 0 .. 9 of the 16, band 1 rows 8 .. 17 as its rows 0 .. 9
+                    if (sg.rr[i] + j < TZ_RH) *reinterpret_cast<tz_u32x2*>(img + (sg.rr[i] + j) * 32) = v;
+                    if (sg.rr[i] + j >= TZ_RT) *reinterpret_cast<tz_u32x2*>(img + TZ_TS + (sg.rr[i] + j - TZ_RT) * 32) = v;
+                } else {
+                    *reinterpret_cast<tz_u32x2*>(img + j * TZ_TS + sg.rr[i] * 32) = v;
+                }
             }
-        } else {
-            tz_read_tr2<0, TZ_BW * 32>(base_addr + (fs * TZ_RH + rr) * TZ_RAWROW + tr_in, uv[0], uv[1]);
-#pragma unroll
-            for (int ct = 0; ct < TZ_CT; ++ct) *reinterpret_cast<tz_u32x2*>(img + ct * TZ_TS + rr * 32) = tz_u32x2{uv[ct].x & rmask, uv[ct].y & rmask};
         }
     };
     // Both pairs of the prologue are requested at once: pair 1 into the raw rows, pair 0 into the (still empty) frame images 2, 3 of the ring
@@ -301,14 +322,17 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
     };
     if (BANDS) zero_band_tail(0);
     tz_barrier();  // (the rows are read a barrier behind their wait, as in the loop)
-#pragma unroll
-    for (int i = 0; i < NR; ++i) transpose_row(0, i, tmp_addr);
+    {
+        Staged sg;
+        stage_read(sg, 0, tmp_addr, -1);
+        stage_write(sg, 0);
+    }
     tz_barrier();  // everyone has read its rows of pair 0: frame images 2, 3 may be written
     if (BANDS) zero_band_tail(2);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        transpose_row(1, i, raw_addr);  // (the row has been read when the statement ends: its cells may be refilled)
-        if (steps >= 2) dma_row(2, i, raw);
+    {
+        Staged sg;
+        stage_read(sg, 1, raw_addr, steps >= 2 ? 2 : -1);
+        stage_write(sg, 1);
     }
     tz_barrier();
     TZ_STAMP(2);
@@ -364,16 +388,16 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
                         tz_u32x2{__builtin_bit_cast(unsigned, o0), __builtin_bit_cast(unsigned, o1)};
                 }
         }
-        TZ_STAMP(3 + 6 * k);
+        TZ_STAMP(3 + 5 * k);
         // The rows of pair k + 2 were requested one step ago.  The wait stands BEFORE the barrier and the rows are read behind it
         // (cdna_hip_programming.md: read a staged buffer one phase after the wait that retires it).
         if (k + 2 <= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TZ_STAMP(4 + 6 * k);
+        TZ_STAMP(4 + 5 * k);
         tz_barrier();  // the output image is complete; nobody reads pair k's frame images any more
         // ---- phase 2: the store -- two transposing reads deliver channels 8 og .. + 3 and + 4 .. + 7 of this lane's column, one 16-byte
-        // channels-last store per output frame -- then pair k + 2 transposed over pair k, each row's cells refilled with pair k + 3 as soon as
-        // the row is read (the stores go first: the wait for the rows at the next step's barrier is then a plain vmcnt(0), whatever order
-        // loads and stores retire in) ----
+        // channels-last store per output frame -- then pair k + 2 transposed over pair k and the rows of pair k + 3 requested.  (Measured
+        // both ways, 14 x 14 x 216, Swish / pool: stores first 29.5 / 26.9 us; requests first, then stores, then the writes of the frame
+        // images 31.2 / 28.3 with vmcnt(0), 31.9 / 28.9 with a counted vmcnt(2).) ----
         tz_u32x2 ua[2], ub[2];
         tz_read_tr4<0, 4 * TZ_OCS, 8 * TZ_ORS, 8 * TZ_ORS + 4 * TZ_OCS>(outi_addr + tr_off, ua[0], ub[0], ua[1], ub[1]);
 #pragma unroll
@@ -384,18 +408,15 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
             const unsigned off = to < t1 ? ooff + (unsigned)to * (unsigned)(oframe * 2) : TZ_OOB;
             __builtin_amdgcn_raw_buffer_store_b128(tz_u32x4{ua[ps].x, ua[ps].y, ub[ps].x, ub[ps].y}, yrsrc, (int)off, 0, 0);
         }
-        TZ_STAMP(5 + 6 * k);
+        TZ_STAMP(5 + 5 * k);
         if (k + 2 <= steps) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                transpose_row(k + 2, i, raw_addr);
-                if (k + 3 <= steps) dma_row(k + 3, i, raw);
-            }
+            Staged sg;
+            stage_read(sg, k + 2, raw_addr, k + 3 <= steps ? k + 3 : -1);
+            stage_write(sg, k + 2);
         }
-        TZ_STAMP(6 + 6 * k);
-        TZ_STAMP(7 + 6 * k);
+        TZ_STAMP(6 + 5 * k);
         tz_barrier();  // pair k + 2's frame images are complete; everyone is done with the output image
-        TZ_STAMP(8 + 6 * k);
+        TZ_STAMP(7 + 5 * k);
     }
 
     if (POOL && pool && wave_live) {
@@ -423,6 +444,7 @@ DtGeom dw_tz_geom(const pasn_conv_desc& d, int dtype) {
     // faster than dwconv3d_mfma_kernel -- profiles/README.md, round 5).
     const char* mode = tune("PASN_DW_TZ");
     if (mode && mode[0] == '0') return g;
+    if (tune("PASN_DWMFMA") && tune("PASN_DWMFMA")[0] == '0') return g;  // "no matrix-core stencil": the VALU stencil's tests and A/B runs
     const bool all = mode && mode[0] == 'a';
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
                        d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cin == d.Cout && d.Cout_p % 8 == 0;

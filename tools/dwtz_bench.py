@@ -72,10 +72,10 @@ def main():
                 v = list(buf)
                 print(f"  block {int(os.environ['PASN_TZ_STAMPS']) - 1} / wave 0 (shader cycles): operands {v[1] - v[0]}  prologue {v[2] - v[1]}")
                 for k in range(8):
-                    b = 3 + 6 * k
+                    b = 3 + 5 * k
                     prev = v[2] if k == 0 else v[b - 1]
-                    print(f"  step {k}: stencil {v[b] - prev:6d}  rows landed {v[b + 1] - v[b]:6d}  barrier {v[b + 2] - v[b + 1]:6d}  stores {v[b + 3] - v[b + 2]:6d}  transposed {v[b + 4] - v[b + 3]:6d}  barrier {v[b + 5] - v[b + 4]:6d}   step total {v[b + 5] - prev:6d}")
-                print(f"  block total {v[3 + 6 * 7 + 5] - v[0]} cycles")
+                    print(f"  step {k}: stencil {v[b] - prev:6d}  rows landed {v[b + 1] - v[b]:6d}  barrier + stores {v[b + 2] - v[b + 1]:6d}  pair transposed, next requested {v[b + 3] - v[b + 2]:6d}  barrier {v[b + 4] - v[b + 3]:6d}   step total {v[b + 4] - prev:6d}")
+                print(f"  block total {v[3 + 5 * 7 + 4] - v[0]} cycles")
 
 
 if __name__ == "__main__":
