@@ -141,12 +141,11 @@ struct DwMfmaGeom {
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
                    const DwMfmaGeom& g, hipStream_t s, int stats = 0, const float* shift = nullptr);  // stats: pool = [N][chunks][2][Cp]: (sum, sum of squares) of (raw output - shift[c])
-// dw_tz.hip (round 5): the stride-1 depthwise 3x3x3 stencil in Toeplitz form on a channel-planar LDS image (channels-last input transposed by
+// dw_tz.hip (round 5): the stride-1 depthwise 3x3x3 stencil of planes at most 14 x 14 in Toeplitz form on a channel-planar LDS image (channels-last input transposed by
 // ds_read_b64_tr_b16); ok = 0: not covered
 struct DtGeom {
-    int ok, bands;             // bands: planes at most 14 wide -- a block's two tiles are row bands of the whole plane (else column tiles of a region)
-    int CG, RTH, RTW;          // 16-channel groups, regions (8 x 28 outputs) per frame
-    int Tc, nT, chunks, lds;   // T chunk (+count), SE partial rows per clip (= blocks per clip and channel group), dynamic LDS
+    int ok, CG;                // 16-channel groups
+    int Tc, nT, lds;           // T chunk (+count = SE partial rows per clip = blocks per clip and channel group), dynamic LDS
     int abl;                   // tuning builds: 1 + the block whose wave 0 leaves shader-clock stamps (PASN_TZ_STAMPS)
 };
 DtGeom dw_tz_geom(const pasn_conv_desc& d, int dtype);

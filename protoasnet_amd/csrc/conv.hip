@@ -931,7 +931,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags
 
 extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
-    if (const DtGeom tz = dw_tz_geom(*d, dtype); tz.ok) return 60000 + tz.bands;  // dwconv3d_tz_kernel (stride 1; row bands / regions)
+    if (dw_tz_geom(*d, dtype).ok) return 60001;  // dwconv3d_tz_kernel (stride 1, planes 9 .. 14 wide)
     if (const DwMfmaGeom mf = dw_mfma_geom(*d, dtype); mf.ok) return 50001;  // dwconv3d_mfma_kernel (stride 1)
     const DwMarchGeom m = dw_march_geom(*d, dtype);
     if (m.WT) return 3000 + m.WT * 10 + d->sw;  // dwconv3d_march_kernel<SW, WT>
@@ -941,7 +941,7 @@ extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
 
 extern "C" int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
-    if (const DtGeom tz = dw_tz_geom(*d, dtype); tz.ok) return tz.chunks;
+    if (const DtGeom tz = dw_tz_geom(*d, dtype); tz.ok) return tz.nT;
     const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
     if (mf.ok) return mf.chunks;
     const DwMarchGeom m = dw_march_geom(*d, dtype);

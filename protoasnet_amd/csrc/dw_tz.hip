@@ -1,19 +1,24 @@
-// Depthwise 3x3x3 conv, stride 1, pad 1, + BN (+ Swish, + squeeze-excite pool partial rows) as PER-CHANNEL TOEPLITZ matrix products on a
-// channel-planar LDS image (round 5): x3d_expdw_tz.hip's stencil for layers whose input arrives CHANNELS-LAST from HBM -- the stride-1 blocks of
-// the 28 x 28 stage, where the expand conv is a launch of its own (pytorchvideo's BottleneckTransform conv_b as the x3d trunks instantiate it).
+// Depthwise 3x3x3 conv, stride 1, pad 1, + BN (+ Swish, + squeeze-excite pool partial rows) on planes at most 14 x 14 as PER-CHANNEL TOEPLITZ
+// matrix products on a channel-planar LDS image (round 5): x3d_expdw_tz.hip's stencil for layers whose input arrives CHANNELS-LAST from HBM --
+// the stride-1 blocks of the 14 x 14 stage, where the expand conv is a launch of its own (pytorchvideo's BottleneckTransform conv_b as the x3d
+// trunks instantiate it).
 //
 // dwmfma.hip runs the same layers with block-diagonal operands at two waves per SIMD (15 MFMAs + 5 operand reads per 16-channel tile and frame,
 // three T-marching accumulator sets, 226-253 registers).  The Toeplitz form needs 8 consecutive COLUMNS of one channel per lane; round 4 priced the
-// transposition of a channels-last tensor at two passes per element and left it.  gfx950's ds_read_b64_tr_b16 does it in one: the x rows of a
-// region arrive by LDS-DMA as they lie ([position][16 channels], 32 bytes per position), and a 16-lane group's transposing read of 4 positions x
+// transposition of a channels-last tensor at two passes per element and left it.  gfx950's ds_read_b64_tr_b16 does it in one: the rows of the
+// plane arrive by LDS-DMA as they lie ([position][16 channels], 32 bytes per position), and a 16-lane group's transposing read of 4 positions x
 // 16 channels hands lane i the 4 consecutive columns of channel i -- one ds_write_b64 into the planar frame image.  One read + one write per
 // 4 positions x 16 channels, no vector arithmetic; zeros outside the image come from the DMA's range check.
 //
-// Block = 8 waves = 16 channels x (8 x 28 outputs) of one clip, marching along T two output frames per step over a ring of 4 frame images, two
-// barriers per step: [stencil of pairs k, k + 1 -> output image] | [store, transpose pair k + 2 over pair k, request the rows of pair k + 3].
+// Block = 8 waves = 16 channels x one clip (a T chunk of it), the whole plane: the block's two 16 x 14-output tiles are ROW BANDS (tile ct =
+// output rows 8 ct .. 8 ct + 7, every column).  It marches along T two output frames per step over a ring of 4 frame images, two barriers per
+// step: [stencil of pairs k, k + 1 -> output image] | [store, transpose pair k + 2 over pair k, request the rows of pair k + 3].
 // Stencil, operands, output path: x3d_expdw_tz.hip's (5 MFMAs per 224 outputs of a channel, ONE accumulator of 4 registers, 40 registers of
 // Toeplitz operands per wave, ds_read_b64_tr_b16 on the way out, four waves per SIMD).  norm's scale is folded into the operands where no pool
 // sums are taken (a weight rounded after scaling: results agree with dwmfma.hip to one bf16 ulp of the output, not bit for bit).
+// Wider planes in regions of 8 x 28 outputs (two column tiles) were built and measured: 28 x 28 x 108 53 / 50 us against dwmfma.hip's 52 / 47,
+// 56 x 56 x 54 117 / 114 against 103 / 86 -- a block's start-up (two memory round trips before its first MFMA) is a third of its time and
+// 896 blocks on 512 slots run two rounds; that form is gone (profiles/README.md, round 5).
 #include "common.h"
 
 namespace pasn {
@@ -26,22 +31,23 @@ typedef __attribute__((ext_vector_type(2))) float tz_f32x2;
 typedef __attribute__((address_space(3))) tz_s16x4* tz_lds_s16x4_t;
 typedef __attribute__((address_space(3))) void* tz_lds_ptr_t;
 
-constexpr int TZ_RT = 8;                       // output rows of a region
-constexpr int TZ_BW = 14;                      // output columns of a column tile
-constexpr int TZ_CT = 2;                       // column tiles of a region (28 output columns)
-constexpr int TZ_RH = TZ_RT + 2;               // staged rows
-constexpr int TZ_TS = TZ_RH * 32;              // bytes per (channel, column tile) of a frame image: 10 rows x 16 columns
+constexpr int TZ_RT = 8;                       // output rows of a band
+constexpr int TZ_BW = 14;                      // output columns of a band (the plane's width, at most)
+constexpr int TZ_CT = 2;                       // bands of a plane
+constexpr int TZ_RH = TZ_RT + 2;               // staged rows of a band
+constexpr int TZ_TS = TZ_RH * 32;              // bytes per (channel, band) of a frame image: 10 rows x 16 columns
 constexpr int TZ_CHS = TZ_CT * TZ_TS + 16;     // bytes per channel of a frame image (16-byte aligned planes: x3d_expdw_tz.hip)
 constexpr int TZ_FS = 16 * TZ_CHS;             // bytes per frame image, a multiple of 256
 static_assert(TZ_FS % 256 == 0 && TZ_CHS % 16 == 0, "frame images: 16-byte aligned channel planes, 256-byte aligned frames");
 constexpr int TZ_NF = 4;                       // frame images in the ring: pairs k, k + 1
-constexpr int TZ_ORS = 32;                     // bytes per row of the output image (the launch sits at 78 KB of LDS: the 40-byte rows of x3d_expdw_tz.hip, whose
-                                               // only point is a conflict-free ds_write_b64 four times per step, do not fit beside the raw rows)
-constexpr int TZ_OTS = 16 * TZ_ORS;            // bytes per (channel, column tile) of the output image
+constexpr int TZ_ORS = 40;                     // bytes per row of the output image (32 used: conflict-free ds_write_b64, x3d_expdw_tz.hip)
+constexpr int TZ_OTS = 16 * TZ_ORS;            // bytes per (channel, band) of the output image
 constexpr int TZ_OCS = TZ_CT * TZ_OTS + 16;    // bytes per channel of the output image
-constexpr int TZ_RAWROW = 32 * 32;             // bytes per staged raw row: 32 positions x 16 channels = ONE LDS-DMA instruction (30 positions used)
-constexpr int TZ_RAW = 2 * TZ_RH * TZ_RAWROW;  // raw rows of one pair of frames
-constexpr int TZ_RW = 3;                       // raw rows per wave and pair, at most (20 rows on 8 waves)
+constexpr int TZ_PR = 16;                      // staged rows of the plane: -1 .. 14
+constexpr int TZ_RAWROW = 16 * 32;             // bytes per raw row: 16 positions (columns -1 .. 14) x 16 channels; one LDS-DMA instruction = two rows
+constexpr int TZ_RAW = 2 * TZ_PR * TZ_RAWROW;  // raw rows of one pair of frames
+constexpr int TZ_NR = 2;                       // LDS-DMA instructions per wave and pair: rows 2 wave, 2 wave + 1 of either frame
+static_assert(TZ_NF * TZ_FS + 16 * TZ_OCS + TZ_RAW + 1024 <= 80 * 1024, "two blocks per CU");
 constexpr unsigned TZ_OOB = 0x80000000u;
 
 __device__ __forceinline__ unsigned tz_bf16_bits(float f) {
@@ -81,128 +87,78 @@ __device__ __forceinline__ unsigned tz_lds_addr(const void* p) { return (unsigne
 // The 9 (dt, dh) tap rows of a channel in 5 MFMAs: K half h of MFMA j carries tap row 2 j + h (row 9 = none)
 __device__ __forceinline__ constexpr int tz_row(int j, int h) { return 2 * j + h; }
 
-// ACT: the epilogue (PASN_ACT_NONE / PASN_ACT_SWISH); POOL: squeeze-excite partial sums; BANDS: planes at most 14 x 14 -- the two
-// 16 x 14 tiles of a block are ROW BANDS of the whole plane (tile ct = output rows 8 ct .. 8 ct + 7, every column) instead of two column tiles of
-// an 8 x 28 region: a 14-wide plane fills its tiles (a region 28 wide on such a plane would leave the second tile empty)
-template <int ACT, bool POOL, bool BANDS>
+// ACT: the epilogue (PASN_ACT_NONE / PASN_ACT_SWISH); POOL: squeeze-excite partial sums
+template <int ACT, bool POOL>
 __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                                                              const float* __restrict__ bias, __bf16* __restrict__ y, float* __restrict__ pool,
                                                              pasn_conv_desc d, DtGeom g) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const ring = smem;                                  // [TZ_NF][TZ_FS]
     char* const outi = smem + TZ_NF * TZ_FS;                  // [16 channels][TZ_OCS]
-    char* const raw = outi + 16 * TZ_OCS;                     // the x rows of ONE pair of frames as they lie in memory: [2 frames][TZ_RH rows][32 positions]
-                                                              // x 32 bytes; BANDS: [2 frames][16 rows][16 positions] x 32 bytes
+    char* const raw = outi + 16 * TZ_OCS;                     // the rows of ONE pair of frames as they lie in memory: [2 frames][TZ_PR][TZ_RAWROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int cgi = lb % g.CG, r1 = lb / g.CG;
-    const int regions = g.RTH * g.RTW, units = g.nT * regions;
-    const int u = r1 % units, n = r1 / units;
-    const int tch = u / regions, reg = u - tch * regions;
-    const int rth = reg / g.RTW, rtw = reg - rth * g.RTW;
-    const int t0 = tch * g.Tc, t1 = min(t0 + g.Tc, d.To);
-    const int h0 = rth * TZ_RT, w0 = rtw * (TZ_CT * TZ_BW);   // (BANDS: one region per frame, h0 = w0 = 0)
+    const int u = r1 % g.nT, n = r1 / g.nT;                   // T chunk, clip
+    const int t0 = u * g.Tc, t1 = min(t0 + g.Tc, d.To);
     const int Cp = d.Cout_p, Ti = d.Ti, Hi = d.Hi, Wi = d.Wi;
     TZ_STAMP(0);
     const int steps = (t1 - t0 + 1) >> 1;                     // output frames t0 + 2 k, t0 + 2 k + 1; input pairs 0 .. steps: frames (t0 - 1 + 2 p, t0 + 2 p)
 
-    // ---- staging roles: NR LDS-DMA instructions per wave and pair of frames, 1 KB each, lane -> 16 bytes (8 channels); positions outside the
-    // image, pad positions and channels beyond the tensor carry an out-of-range offset: the hardware writes zeros.
-    //   regions: instruction rr2 = wave + 8 i < 20 = the staged row rr2 % 10 of frame rr2 / 10, lane -> (staged column lane >> 1, half lane & 1)
-    //   BANDS:   instruction wave + 8 i < 16 = rows 2 wave, 2 wave + 1 (of the plane's 16 staged rows: -1 .. 14) of frame i,
-    //            lane -> (row lane >> 5, staged column (lane & 31) >> 1, half lane & 1)
-    // The wave that requested a row transposes it: no barrier between a row's arrival and its use.
-    constexpr int NR = BANDS ? 2 : TZ_RW;
+    // ---- staging roles: two LDS-DMA instructions per wave and pair of frames, 1 KB each: instruction i = rows 2 wave, 2 wave + 1 of the plane's
+    // 16 staged rows (-1 .. 14) of frame i, lane -> (row lane >> 5, staged column (lane & 31) >> 1, channel half lane & 1), 16 bytes each;
+    // positions outside the image and channels beyond the tensor carry an out-of-range offset: the hardware writes zeros.  The wave that
+    // requested a row transposes it.
     const long fx = (long)Hi * Wi * Cp;
-    const unsigned fx_bytes = (unsigned)(fx * 2), rx_bytes = (unsigned)(Wi * Cp * 2);
+    const unsigned fx_bytes = (unsigned)(fx * 2);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x + (long)n * Ti * fx), 0, (unsigned)Ti * fx_bytes, 0x00020000);
     unsigned xoff;
     {
         const int ch = cgi * 16 + (lane & 1) * 8;
-        if (BANDS) {
-            const int hi = 2 * wave + (lane >> 5) - 1, wi = ((lane & 31) >> 1) - 1;
-            xoff = ((unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi && ch < Cp) ? (unsigned)(((hi * Wi + wi) * Cp + ch) * 2) : TZ_OOB;
-        } else {
-            const int col = lane >> 1, wi = w0 - 1 + col;
-            xoff = (col < TZ_CT * TZ_BW + 2 && (unsigned)wi < (unsigned)Wi && ch < Cp) ? (unsigned)((wi * Cp + ch) * 2) : TZ_OOB;
-        }
+        const int hi = 2 * wave + (lane >> 5) - 1, wi = ((lane & 31) >> 1) - 1;
+        xoff = ((unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi && ch < Cp) ? (unsigned)(((hi * Wi + wi) * Cp + ch) * 2) : TZ_OOB;
     }
-    // instruction i of pair p: wave-uniform (frame slot, staged row, whether anything is fetched; -1: no such instruction)
-    auto instr = [&](int p, int i, int& fs, int& rr) -> int {
-        const int id = wave + 8 * i;
-        if (BANDS) {
-            fs = i;
-            rr = 2 * wave;
-        } else {
-            if (id >= 2 * TZ_RH) return -1;
-            fs = id >= TZ_RH ? 1 : 0;
-            rr = id - fs * TZ_RH;
-        }
+    auto frame_ok = [&](int p, int fs) -> bool {  // wave-uniform: frame fs of pair p exists
         const int f = t0 - 1 + 2 * p + fs;
-        return (f >= 0 && f < Ti && (BANDS || (unsigned)(h0 - 1 + rr) < (unsigned)Hi)) ? 1 : 0;
+        return f >= 0 && f < Ti;
     };
-    auto dma_row = [&](int p, int i, char* base) {
-        int fs, rr;
-        if (instr(p, i, fs, rr) == 1) {
-            const unsigned f = (unsigned)(t0 - 1 + 2 * p + fs);
-            const unsigned so = BANDS ? f * fx_bytes : f * fx_bytes + (unsigned)(h0 - 1 + rr) * rx_bytes;
-            char* dst = BANDS ? base + (fs * 16 + rr) * 512 : base + (fs * TZ_RH + rr) * TZ_RAWROW;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (tz_lds_ptr_t)dst, 16, (int)xoff, (int)so, 0, 0);
-        }
+    auto dma_rows = [&](int p, char* base) {
+#pragma unroll
+        for (int fs = 0; fs < TZ_NR; ++fs)
+            if (frame_ok(p, fs))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (tz_lds_ptr_t)(base + (fs * TZ_PR + 2 * wave) * TZ_RAWROW), 16, (int)xoff,
+                                                         (int)((unsigned)(t0 - 1 + 2 * p + fs) * fx_bytes), 0, 0);
     };
     // transposing read of a raw row's 16 positions x 16 channels: lane 4 q' + p of a 16-lane group supplies the address of position 4 group + q',
     // channels 4 p ..; lane i receives channel i's values at the group's 4 positions = 4 consecutive columns of channel i -> one ds_write_b64
-    // into the planar frame image.  Rows and frames outside the tensor: zeros whatever the raw row holds.
+    // into the planar frame image.
     const int tr_in = (4 * q + (m >> 2)) * 32 + (m & 3) * 8;
     const unsigned raw_addr = tz_lds_addr(raw), outi_addr = tz_lds_addr(outi), tmp_addr = tz_lds_addr(ring + 2 * TZ_FS);
-    // One pair of frames in two halves.  stage_read: every transposing read of this wave's rows (one statement, one wait), then -- the rows are
-    // in registers -- the requests that refill them with pair pd (pd < 0: none).  stage_write: the rows into the frame images.
-    struct Staged {
-        tz_u32x2 uv[NR][2];
-        int fs[NR], rr[NR], st[NR];
-    };
-    auto stage_read = [&](Staged& sg, int p, unsigned base_addr, int pd) {
+    // One pair of frames: the four transposing reads of this wave's rows (one statement, one wait: read by read, each with its own wait, the
+    // pass was a chain of LDS round trips), the requests that refill the rows with pair pd (pd < 0: none) -- they are in registers -- and the
+    // rows into the frame images: band 0 holds staged rows 0 .. 9 of the 16, band 1 rows 8 .. 17 as its rows 0 .. 9.  Frames outside the
+    // clip: zeros whatever the raw rows hold.  (EXEC is all ones at every transposing read: the branches around them are wave-uniform.)
+    auto stage_pair = [&](int p, unsigned base_addr, int pd) {
+        tz_u32x2 uv[TZ_NR][2];
+        tz_read_tr4<0, TZ_RAWROW, TZ_PR * TZ_RAWROW, (TZ_PR + 1) * TZ_RAWROW>(base_addr + 2 * wave * TZ_RAWROW + tr_in, uv[0][0], uv[0][1], uv[1][0], uv[1][1]);
+        if (pd >= 0) dma_rows(pd, raw);
 #pragma unroll
-        for (int i = 0; i < NR; ++i) sg.st[i] = instr(p, i, sg.fs[i], sg.rr[i]);  // wave-uniform (EXEC is all ones at every transposing read)
-        if (BANDS) {
-            // plane rows rr - 1, rr (staged rows rr, rr + 1 of 16) of both frames
-            tz_read_tr4<0, 512, 16 * 512, 17 * 512>(base_addr + sg.rr[0] * 512 + tr_in, sg.uv[0][0], sg.uv[0][1], sg.uv[1][0], sg.uv[1][1]);
-        } else {
-            // rows wave, wave + 8 (, wave + 16), both column tiles of each
-            tz_read_tr4<0, TZ_BW * 32, 8 * TZ_RAWROW, 8 * TZ_RAWROW + TZ_BW * 32>(base_addr + wave * TZ_RAWROW + tr_in, sg.uv[0][0], sg.uv[0][1], sg.uv[1][0],
-                                                                              sg.uv[1][1]);
-            if (sg.st[NR - 1] >= 0)
-                tz_read_tr2<16 * TZ_RAWROW, 16 * TZ_RAWROW + TZ_BW * 32>(base_addr + wave * TZ_RAWROW + tr_in, sg.uv[NR - 1][0], sg.uv[NR - 1][1]);
-        }
-        if (pd >= 0) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) dma_row(pd, i, raw);
-        }
-    };
-    auto stage_write = [&](const Staged& sg, int p) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            if (sg.st[i] < 0) continue;
-            const unsigned rmask = sg.st[i] ? 0xffffffffu : 0u;  // rows and frames outside the tensor: zeros whatever the raw row holds
-            char* img = ring + (((2 * p) & (TZ_NF - 1)) + sg.fs[i]) * TZ_FS + m * TZ_CHS + q * 8;
+        for (int fs = 0; fs < TZ_NR; ++fs) {
+            const unsigned rmask = frame_ok(p, fs) ? 0xffffffffu : 0u;
+            char* img = ring + (((2 * p) & (TZ_NF - 1)) + fs) * TZ_FS + m * TZ_CHS + q * 8;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const tz_u32x2 v = tz_u32x2{sg.uv[i][j].x & rmask, sg.uv[i][j].y & rmask};
-                if (BANDS) {  // band 0 holds staged rows 0 .. 9 of the 16, band 1 rows 8 .. 17 as its rows 0 .. 9
-                    if (sg.rr[i] + j < TZ_RH) *reinterpret_cast<tz_u32x2*>(img + (sg.rr[i] + j) * 32) = v;
-                    if (sg.rr[i] + j >= TZ_RT) *reinterpret_cast<tz_u32x2*>(img + TZ_TS + (sg.rr[i] + j - TZ_RT) * 32) = v;
-                } else {
-                    *reinterpret_cast<tz_u32x2*>(img + j * TZ_TS + sg.rr[i] * 32) = v;
-                }
+                const int r = 2 * wave + j;  // staged row of the plane
+                const tz_u32x2 v = tz_u32x2{uv[fs][j].x & rmask, uv[fs][j].y & rmask};
+                if (r < TZ_RH) *reinterpret_cast<tz_u32x2*>(img + r * 32) = v;
+                if (r >= TZ_RT) *reinterpret_cast<tz_u32x2*>(img + TZ_TS + (r - TZ_RT) * 32) = v;
             }
         }
     };
     // Both pairs of the prologue are requested at once: pair 1 into the raw rows, pair 0 into the (still empty) frame images 2, 3 of the ring
-#pragma unroll
-    for (int i = 0; i < NR; ++i) dma_row(0, i, ring + 2 * TZ_FS);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) dma_row(1, i, raw);
+    dma_rows(0, ring + 2 * TZ_FS);
+    dma_rows(1, raw);
 
     // ---- stencil roles: this wave's two channels; Toeplitz operands in registers for the launch ----
     // FOLDB (the instances without pool sums): norm_b's scale meets the stencil weights BEFORE their rounding to bf16 and its bias is the
@@ -268,12 +224,10 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
         bpk[j] = ((row / 3 + f2) << 20) | ((2 * wave) * TZ_CHS + ((m & 7) + row % 3) * 32 + (q & 1) * 16);
     }
     // Pool sums are taken from the ROUNDED outputs (v_dot2c_f32_bf16 of the packed pairs the store needs anyway with 1 / 0 pairs: 2 instructions
-    // per tile where fp32 masks cost 5 and 8 registers): the rounding errors are unbiased and the squeeze-excite mean runs over 50 k positions
-    // per clip -- 1e-5 of the mean's scale.  (Swish + pool, which no X3D block has, pools the pre-activation in fp32.)  On a region that lies
-    // inside the plane the weights are ones except for output columns 14, 15 of a tile (lanes q = 3, second pair): ONE register; a region cut by
-    // the plane's border computes its column / row weights where it uses them.
-    const bool ragged = BANDS || w0 + TZ_CT * TZ_BW > d.Wo || h0 + TZ_RT > d.Ho;  // wave-uniform
-    unsigned* const ptab = reinterpret_cast<unsigned*>(raw + TZ_RAW);  // [column tile][pair][64 lanes]: the weights of a cut region
+    // per tile where fp32 masks cost 5 and 8 registers): the rounding errors are unbiased and the squeeze-excite mean runs over 3 k positions
+    // per clip and channel.  (Swish + pool, which no X3D block has, pools the pre-activation in fp32.)  The 1 / 0 weights of a lane's four
+    // outputs (columns 14, 15 of a band, rows below the plane, the missing second frame of an odd chunk's last step) come from a 1 KB table.
+    unsigned* const ptab = reinterpret_cast<unsigned*>(raw + TZ_RAW);  // [band][pair][64 lanes]
     if (POOL && wave == 0) {
 #pragma unroll
         for (int ct = 0; ct < TZ_CT; ++ct)
@@ -283,16 +237,14 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int col = 4 * q + 2 * h + i;
-                    const int wo = BANDS ? col : w0 + ct * TZ_BW + col, ho = BANDS ? ct * TZ_RT + (m & 7) : h0 + (m & 7);
-                    if (col < TZ_BW && wo < d.Wo && ho < d.Ho) v |= 0x3f80u << (16 * i);
+                    if (col < d.Wo && ct * TZ_RT + (m & 7) < d.Ho) v |= 0x3f80u << (16 * i);
                 }
                 ptab[(ct * 2 + h) * 64 + lane] = v;
             }
     }
-    const unsigned mk23 = q < 3 ? 0x3f803f80u : 0u;
     float psum[2] = {0.0f, 0.0f};
 
-    // ---- output roles: 16-lane group = (output row of the 16, column tile, 8 channels), lane = output column; two passes of 32 groups ----
+    // ---- output roles: 16-lane group = (output row of a band, band, 8 channels), lane = output column; the two frames of a step in turn ----
     const long oframe = (long)d.Ho * d.Wo * Cp;
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y + (long)n * d.To * oframe, 0, (unsigned)(d.To * oframe * 2), 0x00020000);
     const int G = tid >> 4, l16 = tid & 15;
@@ -301,8 +253,8 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
     {
         const int og = G & 1, ct = (G >> 1) & 1, n8 = G >> 2;
         tr_off = (8 * og + (l16 >> 2)) * TZ_OCS + ct * TZ_OTS + n8 * TZ_ORS + (l16 & 3) * 8;
-        const int ho = BANDS ? ct * TZ_RT + n8 : h0 + n8, wo = BANDS ? l16 : w0 + ct * TZ_BW + l16;
-        const bool ok = l16 < TZ_BW && wo < d.Wo && ho < d.Ho && cgi * 16 + 8 * og < Cp;
+        const int ho = ct * TZ_RT + n8, wo = l16;
+        const bool ok = wo < d.Wo && ho < d.Ho && cgi * 16 + 8 * og < Cp;
         ooff = ok ? (unsigned)(((ho * d.Wo + wo) * Cp + cgi * 16 + 8 * og) * 2) : TZ_OOB;
     }
 
@@ -314,26 +266,18 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
     TZ_STAMP(1);
     // ---- prologue: pair 0 transposed out of the ring's far half, then pair 1 over it; the rows of pair 2 requested ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    auto zero_band_tail = [&](int sl0) {  // BANDS: band 1's staged rows 8, 9 lie below every plane and are never staged: zeros once (finite
-                                          // values under the pool sums' zero weights)
+    auto zero_band_tail = [&](int sl0) {  // band 1's staged rows 8, 9 lie below every plane and are never staged: zeros once (finite values
+                                          // under the pool sums' zero weights)
 #pragma unroll
         for (int sl = sl0; sl < sl0 + 2; ++sl)
             if (tid < 16 * 8) *reinterpret_cast<tz_u32x2*>(ring + sl * TZ_FS + (tid >> 3) * TZ_CHS + TZ_TS + TZ_RT * 32 + (tid & 7) * 8) = tz_u32x2{0u, 0u};
     };
-    if (BANDS) zero_band_tail(0);
+    zero_band_tail(0);
     tz_barrier();  // (the rows are read a barrier behind their wait, as in the loop)
-    {
-        Staged sg;
-        stage_read(sg, 0, tmp_addr, -1);
-        stage_write(sg, 0);
-    }
+    stage_pair(0, tmp_addr, -1);
     tz_barrier();  // everyone has read its rows of pair 0: frame images 2, 3 may be written
-    if (BANDS) zero_band_tail(2);
-    {
-        Staged sg;
-        stage_read(sg, 1, raw_addr, steps >= 2 ? 2 : -1);
-        stage_write(sg, 1);
-    }
+    zero_band_tail(2);
+    stage_pair(1, raw_addr, steps >= 2 ? 2 : -1);
     tz_barrier();
     TZ_STAMP(2);
 
@@ -376,11 +320,7 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
                     const tz_bf16x2 o0 = __builtin_convertvector(tz_f32x2{v[0], v[1]}, tz_bf16x2);
                     const tz_bf16x2 o1 = __builtin_convertvector(tz_f32x2{v[2], v[3]}, tz_bf16x2);
                     if (POOL && ACT != PASN_ACT_SWISH) {
-                        unsigned w01 = 0x3f803f80u, w23 = mk23;
-                        if (ragged || tailf) {  // wave-uniform
-                            w01 = ptab[(ct * 2) * 64 + lane] & fm;
-                            w23 = ptab[(ct * 2 + 1) * 64 + lane] & fm;
-                        }
+                        const unsigned w01 = ptab[(ct * 2) * 64 + lane] & fm, w23 = ptab[(ct * 2 + 1) * 64 + lane] & fm;
                         psum[c2] = __builtin_amdgcn_fdot2_f32_bf16(o0, __builtin_bit_cast(tz_bf16x2, w01), psum[c2], false);
                         psum[c2] = __builtin_amdgcn_fdot2_f32_bf16(o1, __builtin_bit_cast(tz_bf16x2, w23), psum[c2], false);
                     }
@@ -409,11 +349,7 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
             __builtin_amdgcn_raw_buffer_store_b128(tz_u32x4{ua[ps].x, ua[ps].y, ub[ps].x, ub[ps].y}, yrsrc, (int)off, 0, 0);
         }
         TZ_STAMP(5 + 5 * k);
-        if (k + 2 <= steps) {
-            Staged sg;
-            stage_read(sg, k + 2, raw_addr, k + 3 <= steps ? k + 3 : -1);
-            stage_write(sg, k + 2);
-        }
+        if (k + 2 <= steps) stage_pair(k + 2, raw_addr, k + 3 <= steps ? k + 3 : -1);
         TZ_STAMP(6 + 5 * k);
         tz_barrier();  // pair k + 2's frame images are complete; everyone is done with the output image
         TZ_STAMP(7 + 5 * k);
@@ -428,7 +364,7 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
             psum[c2] = s;
         }
         if (lane == 0) {
-            float* pr = pool + ((long)n * g.chunks + u) * Cp + cA;
+            float* pr = pool + ((long)n * g.nT + u) * Cp + cA;
             pr[0] = psum[0];
             pr[1] = psum[1];
         }
@@ -439,27 +375,20 @@ __global__ __launch_bounds__(512, 4) void dwconv3d_tz_kernel(const __bf16* __res
 DtGeom dw_tz_geom(const pasn_conv_desc& d, int dtype) {
     DtGeom g{};
     if (dtype != PASN_BF16) return g;
-    // Default: the stride-1 stencils of planes 9 .. 14 wide and at most 14 high (the 14 x 14 stage: one block = 16 channels of a whole clip).
-    // PASN_DW_TZ=0: off; PASN_DW_TZ=all: also planes at least 15 wide, in regions of 8 x 28 outputs (measured at 28 x 28 and 56 x 56: not
-    // faster than dwconv3d_mfma_kernel -- profiles/README.md, round 5).
-    const char* mode = tune("PASN_DW_TZ");
-    if (mode && mode[0] == '0') return g;
+    // The stride-1 stencils of planes 9 .. 14 wide and at most 14 high (the 14 x 14 stage: one block = 16 channels of a whole clip; narrower
+    // planes leave the 14-column tiles half empty and stay with dwmfma.hip).  PASN_DW_TZ=0: off.
+    if (tune("PASN_DW_TZ") && tune("PASN_DW_TZ")[0] == '0') return g;
     if (tune("PASN_DWMFMA") && tune("PASN_DWMFMA")[0] == '0') return g;  // "no matrix-core stencil": the VALU stencil's tests and A/B runs
-    const bool all = mode && mode[0] == 'a';
     const bool shape = d.kt == 3 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 1 && d.pw == 1 &&
                        d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.Cin_p == d.Cout_p && d.Cin == d.Cout && d.Cout_p % 8 == 0;
     if (!shape || (d.act != PASN_ACT_NONE && d.act != PASN_ACT_SWISH)) return g;
-    g.bands = d.Wo <= TZ_BW && d.Ho <= TZ_BW;  // (16 staged rows: plane rows -1 .. 14)
-    if (g.bands ? d.Wo < 9 : !all) return g;
-    if ((long)d.Ti * d.Hi * d.Wi * d.Cin_p * 2 >= (1L << 31)) return DtGeom{};  // one clip per buffer descriptor
+    if (d.Wo > TZ_BW || d.Wo < 9 || d.Ho > TZ_BW) return g;   // (16 staged rows: plane rows -1 .. 14)
+    if ((long)d.Ti * d.Hi * d.Wi * d.Cin_p * 2 >= (1L << 31)) return g;  // one clip per buffer descriptor
     g.CG = ceil_div(d.Cout_p, 16);
-    g.RTH = g.bands ? 1 : ceil_div(d.Ho, TZ_RT);
-    g.RTW = g.bands ? 1 : ceil_div(d.Wo, TZ_CT * TZ_BW);
     const int force_tc = tune("PASN_DWMFMA_TC") ? atoi(tune("PASN_DWMFMA_TC")) : 0;
     g.Tc = force_tc > 0 ? std::min(force_tc, (int)d.To) : d.To;
-    g.nT = ceil_div(d.To, g.Tc);
-    g.chunks = g.nT * g.RTH * g.RTW;
-    if (g.chunks > 64 && !force_tc) return DtGeom{};          // SE partial rows per clip the consumers sum
+    g.nT = ceil_div(d.To, g.Tc);                              // = SE partial rows per clip
+    if (g.nT > 64 && !force_tc) return DtGeom{};
     g.lds = TZ_NF * TZ_FS + 16 * TZ_OCS + TZ_RAW + 1024;      // + the pool-weight table
     g.abl = tune_dev("PASN_TZ_STAMPS") ? std::max(1, atoi(tune_dev("PASN_TZ_STAMPS"))) : 0;  // 1 + the block that leaves stamps
     g.ok = 1;
@@ -468,25 +397,19 @@ DtGeom dw_tz_geom(const pasn_conv_desc& d, int dtype) {
 
 int launch_dw_tz(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d, const DtGeom& g,
                  hipStream_t s) {
-    const dim3 grid((unsigned)((long)d.N * g.CG * g.nT * g.RTH * g.RTW)), block(512);
-#define PASN_DT(ACT_, POOL_, BANDS_)                                                                                                  \
+    const dim3 grid((unsigned)((long)d.N * g.CG * g.nT)), block(512);
+#define PASN_DT(ACT_, POOL_)                                                                                                          \
     do {                                                                                                                            \
-        PASN_MAX_LDS(80 * 1024, dwconv3d_tz_kernel<ACT_, POOL_, BANDS_>);                                                           \
-        hipLaunchKernelGGL((dwconv3d_tz_kernel<ACT_, POOL_, BANDS_>), grid, block, (size_t)g.lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g); \
-    } while (0)
-#define PASN_DT2(ACT_, POOL_)                      \
-    do {                                           \
-        if (g.bands) PASN_DT(ACT_, POOL_, true);   \
-        else PASN_DT(ACT_, POOL_, false);          \
+        PASN_MAX_LDS(80 * 1024, dwconv3d_tz_kernel<ACT_, POOL_>);                                                                   \
+        hipLaunchKernelGGL((dwconv3d_tz_kernel<ACT_, POOL_>), grid, block, (size_t)g.lds, s, (const __bf16*)x, w, scale, bias, (__bf16*)y, pool, d, g); \
     } while (0)
     if (d.act == PASN_ACT_SWISH) {
-        if (pool) PASN_DT2(PASN_ACT_SWISH, true);
-        else PASN_DT2(PASN_ACT_SWISH, false);
+        if (pool) PASN_DT(PASN_ACT_SWISH, true);
+        else PASN_DT(PASN_ACT_SWISH, false);
     } else {
-        if (pool) PASN_DT2(PASN_ACT_NONE, true);
-        else PASN_DT2(PASN_ACT_NONE, false);
+        if (pool) PASN_DT(PASN_ACT_NONE, true);
+        else PASN_DT(PASN_ACT_NONE, false);
     }
-#undef PASN_DT2
 #undef PASN_DT
     return check_launch("dwconv3d_tz_kernel");
 }

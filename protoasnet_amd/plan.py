@@ -576,7 +576,7 @@ class PlanBuilder:
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
         if dv >= 60000:
-            kname = f"dwconv3d_tz_kernel<{_lib.ACT[act]},{'true' if pool else 'false'},{'true' if dv % 10 else 'false'}>"
+            kname = f"dwconv3d_tz_kernel<{_lib.ACT[act]},{'true' if pool else 'false'}>"
         elif dv >= 50000:  # the instance as the profiler prints it: <rows per position tile, ablation build, compiled-in activation>
             actc = _lib.ACT[act]
             kname = f"dwconv3d_mfma_kernel<{2 if y.W <= 8 else 1},false,{actc if actc in (_lib.ACT['none'], _lib.ACT['swish']) else -1}>"
