@@ -1117,6 +1117,40 @@ def test_dwconv3d_toeplitz_variants(thw, c, act, monkeypatch):
     assert float(dd.max()) <= 2.0 ** -6 * scale, float(dd.max())
 
 
+@pytest.mark.parametrize("kernel", ["dw_tz", "expdw_tz"])
+def test_toeplitz_kernels_repeat_bit_for_bit(kernel):
+    """Both Toeplitz kernels at shapes that fill the card (several blocks per CU, full-length marches), launched 24 times on the same input:
+    every run bit-identical to the first.  Round 5's store-data hazard (a 16-byte buffer store whose data register the next instruction
+    overwrote: profiles/README.md entry 144) passed every single-run parity case and showed as one wrong output row in a few percent of the
+    runs -- a repeat test is what sees that class of fault."""
+    dtype = torch.bfloat16
+    torch.manual_seed(5)
+    pb = _pb(dtype)
+    if kernel == "dw_tz":
+        n, c, thw = 8, 216, (16, 14, 14)
+        x = torch.randn(n, c, *thw)
+        conv, bn = nn.Conv3d(c, c, 3, 1, 1, groups=c, bias=False).to(DEV), nn.BatchNorm3d(c).to(DEV).eval()
+        xa, xs = _cl_input(pb, x, dtype)
+        y = pb.dwconv(xa, conv, bn, "swish")
+        assert pb.meta[-1]["kernel"].startswith("dwconv3d_tz_kernel<"), pb.meta[-1]["kernel"]
+    else:
+        n, cin, cm, thw = 4, 24, 54, (16, 56, 56)
+        x = torch.randn(n, cin, *thw)
+        mods = [nn.Conv3d(cin, cm, 1, bias=False), nn.BatchNorm3d(cm), nn.Conv3d(cm, cm, 3, 1, 1, groups=cm, bias=False), nn.BatchNorm3d(cm)]
+        mods = [m.to(DEV).eval() for m in mods]
+        xa, xs = _cl_input(pb, x, dtype)
+        y = pb.expand_dw(xa, mods[0], mods[1], mods[2], mods[3], "swish", pool=False)
+        assert y is not None and pb.meta[-1]["kernel"].startswith("x3d_expdw_tz_kernel<"), pb.meta[-1]["kernel"]
+    plan = pb.finish(xa, y)
+    first = plan.run(xs).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(first.float()).all()
+    for rep in range(24):
+        again = plan.run(xs)
+        torch.cuda.synchronize()
+        assert torch.equal(again, first), f"run {rep + 1} differs from the first in {int((again != first).sum())} elements"
+
+
 @pytest.mark.parametrize("wt", [2, 3])
 @pytest.mark.parametrize("tc", [4, 8, 16])
 @pytest.mark.parametrize("stride", [1, 2])
