@@ -389,6 +389,10 @@ DtGeom dw_tz_geom(const pasn_conv_desc& d, int dtype) {
     g.Tc = force_tc > 0 ? std::min(force_tc, (int)d.To) : d.To;
     g.nT = ceil_div(d.To, g.Tc);                              // = SE partial rows per clip
     if (g.nT > 64 && !force_tc) return DtGeom{};
+    // One round of blocks (two per CU, 256 CUs) or none: a block's first MFMA stands behind two memory round trips, and a second round pays
+    // them again -- 64 clips of the 14 x 14 stage (the paired training pass: 896 blocks) take 58-64 us here against dwmfma.hip's 54-58, 32
+    // clips (448 blocks) 29.6 / 26.2 against 33.5 / 29.6 (profiles/README.md entries 143, 149).  PASN_DW_TZ=1: whatever the block count.
+    if ((long)d.N * g.CG * g.nT > 512 && !(tune("PASN_DW_TZ") && tune("PASN_DW_TZ")[0] == '1')) return DtGeom{};
     g.lds = TZ_NF * TZ_FS + 16 * TZ_OCS + TZ_RAW + 1024;      // + the pool-weight table
     g.abl = tune_dev("PASN_TZ_STAMPS") ? std::max(1, atoi(tune_dev("PASN_TZ_STAMPS"))) : 0;  // 1 + the block that leaves stamps
     g.ok = 1;
