@@ -358,3 +358,23 @@ def test_wide_buffer_stores_carry_no_register_soffset():
             calls += 1
             assert re.search(r",\s*0\s*,\s*0\s*$", args), f"{os.path.basename(path)}: wide buffer store with a register soffset: {args[-80:]}"
     assert calls >= 8
+
+
+def test_store_hazard_scanner_finds_the_pattern(tmp_path):
+    """tools/store_hazard_scan.py on three snippets: the failing sequence of round 5 (16-byte buffer store with an SGPR soffset, its first data
+    register overwritten by the next instruction), the same store behind an immediate soffset, and a store followed by an unrelated write."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("store_hazard_scan", os.path.join(root, "tools", "store_hazard_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = tmp_path / "bad.s"
+    bad.write_text("\tbuffer_store_dwordx4 v[46:49], v50, s[12:15], s8 offen\n\tv_cndmask_b32_e32 v46, v72, v54, vcc\n")
+    imm = tmp_path / "imm.s"
+    imm.write_text("\tbuffer_store_dwordx4 v[46:49], v50, s[12:15], 0 offen\n\tv_cndmask_b32_e32 v46, v72, v54, vcc\n")
+    other = tmp_path / "other.s"
+    other.write_text("\tbuffer_store_dwordx4 v[46:49], v50, s[12:15], s8 offen\n\ts_add_i32 s8, s8, 1\n\tv_add_u32_e32 v50, s38, v54\n\tv_mov_b32_e32 v46, 0\n")
+    assert mod.scan(str(bad)) == 1
+    assert mod.scan(str(imm)) == 0
+    assert mod.scan(str(other), window=2) == 0 and mod.scan(str(other), window=4) == 1
