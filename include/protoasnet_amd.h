@@ -63,7 +63,7 @@ typedef struct pasn_conv_desc {
     int32_t w_kc;             /* conv3d: per-tap K extent of the packed weight (elements)  */
     int32_t w_rows;           /* conv3d: rows of the packed weight / scale / bias arrays   */
     int32_t w_frag;           /* conv3d: 0 = w is [w_rows][taps][w_kc]; 1 = MFMA-fragment-major
-                                 [w_rows/32][w_kc/KSTEP][2][32][CH] (KSTEP/CH = 16/8 bf16, 8/4 fp32):
+                                 [w_rows/32][taps*w_kc/KSTEP][2][32][CH] (KSTEP/CH = 16/8 bf16, 8/4 fp32; K = (tap, channel)):
                                  only where pasn_conv3d_variant() reports 2500..5999 or >= 7000 */
 } pasn_conv_desc;
 
@@ -200,7 +200,10 @@ int pasn_conv3d_short_fwd(const void* x, const void* w, const float* scale, cons
  * (1x1x1 stride-1 convs with Cin_p >= 64: whole-K position tiles in LDS); 2000 / 2001 = gemm_conv_kernel<dtype, pointwise /
  * windowed> (LDS-tiled implicit GEMM); otherwise NT*10 + MT = conv3d_mfma_kernel<dtype, NT, MT> (output-channel /
  * position tiles per wave); 7000 + KS*10 + MT = pwconv_ws_kernel<KS, MT, ..> (bf16 1x1x1 stride-1 convs with Cin_p >= 48:
- * weight-stationary persistent blocks, LDS-DMA stage ring; fragment-major weights like 2500+); 0 on a bad descriptor.
+ * weight-stationary persistent blocks, LDS-DMA stage ring; fragment-major weights like 2500+); 9000 + KSF = tconv_ws_kernel<KSF, ..>
+ * (bf16 (3,1,1) stride-1 convs with Cin_p = 16 KSF in {48, 64, 144} and up to 64 output channels -- torchvision's Conv2Plus1D temporal half as
+ * resnet_features.py's r2plus1d_18 trunk instantiates it: weight-stationary, T-marching LDS ring; fragment-major weights over K = 3 Cin_p);
+ * 0 on a bad descriptor.
  * flags: bit 0 = `gate` will be non-NULL, bit 1 = `residual` will be non-NULL (the choice between the pointwise kernels and
  * their tile sizes depend on both).  For profilers, benchmarks and the weight packing (w_frag). */
 int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags);

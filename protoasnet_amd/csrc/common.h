@@ -141,6 +141,13 @@ struct DwMfmaGeom {
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
                    const DwMfmaGeom& g, hipStream_t s, int stats = 0, const float* shift = nullptr);  // stats: pool = [N][chunks][2][Cp]: (sum, sum of squares) of (raw output - shift[c])
+// tconv_ws.hip (round 5): temporal (3,1,1) stride-1 conv, weight-stationary and T-marching (fragment-major weights, K = (dt, channel)); ok = 0: not covered
+struct TcGeom {
+    int ok, KSF, CT, ptiles, bm, lds;  // k-steps per frame (Cin_p / 16), channel tiles of 32, tiles per frame and their positions (<= 64), dynamic LDS
+};
+TcGeom tconv_geom(const pasn_conv_desc& d, int dtype, bool has_gate);
+int launch_tconv_ws(const void* x, const void* w, const float* scale, const float* bias, const void* res, void* y, const pasn_conv_desc& d,
+                    const TcGeom& g, hipStream_t s);
 // dw_tz.hip (round 5): the stride-1 depthwise 3x3x3 stencil of planes at most 14 x 14 in Toeplitz form on a channel-planar LDS image (channels-last input transposed by
 // ds_read_b64_tr_b16); ok = 0: not covered
 struct DtGeom {

@@ -794,6 +794,8 @@ extern "C" int pasn_conv3d_fwd(const void* x, const void* w, const float* scale,
     PASN_REQUIRE(d->w_rows % 128 == 0 && d->w_rows >= d->Cout_p, "w_rows must be a multiple of 128 covering Cout_p");
     hipStream_t s = (hipStream_t)stream;
     PASN_REQUIRE(dtype == PASN_F32 || dtype == PASN_BF16, "unknown dtype");
+    if (const TcGeom tg = tconv_geom(*d, dtype, gate != nullptr); tg.ok)  // temporal (3,1,1) conv, weight-stationary + T-marching (bf16, fragment-major weights)
+        return launch_tconv_ws(x, w, scale, bias, residual, y, *d, tg, s);
     if (const WsGeom wg = pw_ws_geom(*d, dtype, gate != nullptr, residual != nullptr); wg.ok)  // weight-stationary persistent blocks (bf16, fragment-major weights)
         return launch_pw_ws(x, w, scale, bias, residual, gate, y, *d, wg, s);
     if (pw_tiny_applicable(*d, dtype, gate != nullptr))  // fp32, few positions (the image heads): one wave per 32 x 32 output tile
@@ -914,6 +916,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags
     {  // asked before the host has packed the weights: the weight-stationary kernel reads them fragment-major like the X-tile kernel
         pasn_conv_desc df = *d;
         df.w_frag = 1;
+        if (const TcGeom tg = tconv_geom(df, dtype, has_gate != 0); tg.ok) return 9000 + tg.KSF;  // tconv_ws_kernel<KSF, residual?> (fragment-major weights)
         if (const int v = pw_ws_variant(df, dtype, has_gate != 0, has_res != 0)) return v;
     }
     if (pw_tiny_applicable(*d, dtype, has_gate != 0)) return 2002;  // pwconv_tiny_f32_kernel

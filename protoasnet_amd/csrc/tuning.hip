@@ -44,6 +44,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_NO_FIRST_IM2COL",  "route", "first-layer weight gradient without the im2col path"},
     {"PASN_NO_GEMM",          "route", "no LDS-tiled GEMM for pointwise convs (gemm_pw.hip)"},
     {"PASN_NO_GEMM_BN64",     "route", "no 64-column instance of the LDS-tiled GEMM"},
+    {"PASN_TCONV",            "route", "0: temporal (3,1,1) convs on the implicit-GEMM kernels instead of the weight-stationary T-marching kernel (tconv_ws.hip)"},
     {"PASN_NO_HALO",          "route", "no halo-tile implicit GEMM (igemm_halo.hip)"},
     {"PASN_NO_IGEMM",         "route", "no direct-to-LDS implicit GEMM (igemm.hip)"},
     {"PASN_NO_PACK",          "route", "1: training weights packed by torch ops instead of the one-launch pack kernel (host side, train.py)"},

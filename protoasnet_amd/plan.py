@@ -328,13 +328,15 @@ class PlanBuilder:
         if 2500 <= variant < 6000 or variant >= 7000:
             # pwconv_xtile_kernel reads its weights as MFMA fragments: store them fragment-major, so a wave's fragment
             # load is one contiguous 1 KB run instead of a 32-row gather (the gather saturated the CU's address unit)
+            # (variant >= 9000, tconv_ws_kernel: the K axis is (tap, channel) -- the packed rows are [taps][kc] already)
             kstep, ch = (16, 8) if self.dtype == torch.bfloat16 else (8, 4)
-            wf = wp.view(rows // 32, 32, kc // kstep, 2, ch).permute(0, 2, 3, 1, 4).contiguous()
+            wf = wp.view(rows // 32, 32, (k[0] * k[1] * k[2] * kc) // kstep, 2, ch).permute(0, 2, 3, 1, 4).contiguous()
             self.keep.append(wf)
             a = (wf.data_ptr(), a[1], a[2])
             d.w_frag = 1
         taps, out_pos = k[0] * k[1] * k[2], y.N * y.positions
-        self._note("conv", f"pwconv_ws_kernel<{(variant - 7000) // 10},{variant % 10},{'true' if (in_gate is not None or in_swish) else 'false'},{'true' if residual is not None else 'false'}>" if variant >= 7000 else
+        self._note("conv", f"tconv_ws_kernel<{variant - 9000},{'true' if residual is not None else 'false'}>" if variant >= 9000 else
+                   f"pwconv_ws_kernel<{(variant - 7000) // 10},{variant % 10},{'true' if (in_gate is not None or in_swish) else 'false'},{'true' if residual is not None else 'false'}>" if variant >= 7000 else
                    _igemm_name(variant - 6000) if variant >= 6000 else f"pwconv_xtile_kernel<{self.tname},{(variant - 2500) // 2},{'true' if (in_gate is not None or variant % 2 == 1) else 'false'}>" if 2500 <= variant < 6000 else
                    f"pwconv_tiny_kernel<{self.tname}>" if variant == 2002 else
                    f"gemm_conv_kernel<{self.tname},{'true' if variant == 2000 else 'false'}>" if variant >= 2000 else

@@ -805,6 +805,73 @@ def test_chained_pair_with_se_gate_in_its_prologue(n, thw, monkeypatch):
         assert_close(_from_cl(got, cc), _from_cl(other, cc), 1.6e-2 * scale, 1e-2, f"prologue pair vs gate launch + chained pair: {tag}")
 
 
+TCONV_CASES = [
+    # cin, cout, (N, T, H, W), act, residual -- temporal (3,1,1) stride-1 convs whose weights fit a wave's registers (tconv_ws.hip)
+    (144, 64, (2, 5, 9, 11), "relu", False),   # the 56 x 56 stage's layer: ragged last tile (99 positions), odd T
+    (144, 64, (1, 32, 8, 8), "relu", True),    # a full march of 32 frames, one whole tile per frame, residual
+    (144, 64, (3, 1, 7, 7), "none", True),     # T = 1: only the centre tap sees data
+    (144, 64, (2, 2, 5, 29), "relu", True),    # T = 2, three tiles per frame
+    (144, 45, (2, 4, 6, 6), "relu", False),    # 45 output channels: a channel tile with a tail
+    (144, 24, (1, 6, 9, 9), "none", True),     # one channel tile (a block of two waves)
+    (64, 64, (2, 7, 10, 13), "relu", True),    # 64 input channels (four k-steps per frame)
+    (45, 64, (2, 5, 6, 7), "relu", False),     # R(2+1)D stem's temporal conv: 45 channels in 48 (three k-steps per frame, a zero-padded tail)
+]
+
+
+@pytest.mark.parametrize("case", TCONV_CASES)
+def test_temporal_conv_weight_stationary(case, monkeypatch):
+    """tconv_ws.hip (bf16): the (3,1,1) stride-1 conv as a weight-stationary pointwise conv over three frames of a T-marching LDS ring --
+    against torch on the bf16-rounded operands, and against the halo-tile implicit GEMM it replaces (same products, fp32 accumulation in
+    another order); repeated launches bit-identical."""
+    cin, cout, nthw, act, use_res = case
+    torch.manual_seed(sum(nthw) + cin + cout)
+    dtype = torch.bfloat16
+    x = torch.randn(*nthw[:1], cin, *nthw[1:])
+    conv = nn.Conv3d(cin, cout, (3, 1, 1), 1, (1, 0, 0), bias=False)
+    bn = nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    conv_r = nn.Conv3d(cin, cout, (3, 1, 1), 1, (1, 0, 0), bias=False)
+    conv_r.weight.data = _rt(conv.weight.data, dtype)
+    ref = bn(conv_r(_rt(x, dtype)))
+    res = torch.randn_like(ref) if use_res else None
+    if res is not None:
+        ref = ref + _rt(res, dtype)
+    ref = (F.relu(ref) if act == "relu" else ref).detach()
+    conv, bn = conv.to(DEV), bn.to(DEV)
+
+    def run(tconv):
+        monkeypatch.setenv("PASN_TCONV", "1" if tconv else "0")
+        pb = _pb(dtype)
+        xa, xs = _cl_input(pb, x, dtype)
+        ra = rs = None
+        if res is not None:
+            ra, rs = _cl_input(pb, res, dtype)
+        y = pb.conv(xa, conv, bn, act, residual=ra)
+        plan = pb.finish(xa, y)
+        if ra is not None:
+            plan.ptrs[ra.buf] = rs.data_ptr()
+        out = plan.run(xs).clone()
+        again = plan.run(xs).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(out, again)
+        return out, plan.meta[0]["kernel"]
+
+    out, name = run(True)
+    assert name == f"tconv_ws_kernel<{(cin + 15) // 16},{'true' if use_res else 'false'}>", name
+    old, old_name = run(False)
+    assert not old_name.startswith("tconv_ws"), old_name
+    scale = max(1.0, float(ref.abs().max()))
+    assert_close(_from_cl(out, cout), ref, 3e-2 * scale, 2e-2, f"temporal conv {case}")
+    assert_close(_from_cl(out, cout), _from_cl(old, cout), 1.6e-2 * scale, 1e-2, "weight-stationary vs implicit GEMM")  # one bf16 ulp of the output
+    if out.shape[-1] > cout:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "padded channels must stay zero"
+
+
 HALO_CASES = [
     # cin, cout, k, p, (N, T, H, W), act, residual -- stride-1 "same" convs of R(2+1)D-18 / ResNet-18 (igemm_halo.hip)
     (64, 144, (1, 3, 3), (0, 1, 1), (2, 3, 9, 11), "relu", False),    # spatial taps, 160-channel tile, tiles straddle rows / frames / clips
@@ -846,6 +913,8 @@ def test_igemm_halo_kernel(case, monkeypatch):
         ref = ref + _rt(res, dtype)
     ref = (F.relu(ref) if act == "relu" else ref).detach()
     conv, bn = conv.to(DEV), bn.to(DEV)
+
+    monkeypatch.setenv("PASN_TCONV", "0")  # (the 144 -> 64 temporal layers take tconv_ws_kernel by default: test_temporal_conv_weight_stationary)
 
     def run(no_halo):
         monkeypatch.setenv("PASN_NO_HALO", "1" if no_halo else "0")
