@@ -217,7 +217,9 @@ int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags);
  */
 int pasn_dwconv3d_pool_blocks(const pasn_conv_desc* d, int dtype);
 /* Kernel instance for this geometry: 3000 + WT*10 + SW = dwconv3d_march_kernel<SW, WT> (bf16, 3x3x3, stride (1,s,s));
- * WT*100 + KW*10 + SW = dwconv3d_strip_kernel<dtype, WT, KW, SW>; 0 = generic kernel. */
+ * WT*100 + KW*10 + SW = dwconv3d_strip_kernel<dtype, WT, KW, SW>; 50001 = dwconv3d_mfma_kernel (stride-1 3x3x3 on the matrix cores);
+ * 60001 = dwconv3d_tz_kernel (stride-1 3x3x3, planes 9 .. 14 wide: Toeplitz form); 70000 + kt = dwconv_t_kernel<dtype, kt> ((kt,1,1),
+ * kt = 3 / 5, stride 1, taken when pool_partial is NULL: the X3D stem's conv_t as a launch of its own); 0 = generic kernel. */
 int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype);
 /* The same stencil with the squeeze-excite gate of the block fused into the launch (X3D conv_b + SE: global average pool ->
  * fc1 + ReLU -> fc2 + sigmoid): every block writes its pool partial row, the clip's last-arriving block reduces them and computes

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ("api.hip", "tuning.hip", "comm.hip", "conv.hip", "pwconv.hip", "gemm_pw.hip", "igemm.hip", "igemm_halo.hip", "first_conv_mfma.hip", "pwconv_xtile.hip", "pwconv_tiny.hip", "pwconv_ws.hip", "pwconv_xpair.hip", "tconv_ws.hip", "stem.hip", "stem_mfma.hip", "dwmarch.hip", "dwmfma.hip", "x3d_expdw.hip", "x3d_expdw_tz.hip", "dw_tz.hip", "x3d_pe.hip", "x3d_edp.hip", "head_l2.hip", "head_xproto.hip", "head_chain.hip", "push.hip", "train.hip", "pack.hip", "wgrad.hip", "wgrad_halo.hip", "head_train.hip", "warp.hip")
+SOURCES = ("api.hip", "tuning.hip", "comm.hip", "conv.hip", "pwconv.hip", "gemm_pw.hip", "igemm.hip", "igemm_halo.hip", "first_conv_mfma.hip", "pwconv_xtile.hip", "pwconv_tiny.hip", "pwconv_ws.hip", "pwconv_xpair.hip", "tconv_ws.hip", "stem.hip", "stem_mfma.hip", "dwmarch.hip", "dwmfma.hip", "x3d_expdw.hip", "x3d_expdw_tz.hip", "dw_tz.hip", "dwtemporal.hip", "x3d_pe.hip", "x3d_edp.hip", "head_l2.hip", "head_xproto.hip", "head_chain.hip", "push.hip", "train.hip", "pack.hip", "wgrad.hip", "wgrad_halo.hip", "head_train.hip", "warp.hip")
 ARCH = "gfx950"
 
 

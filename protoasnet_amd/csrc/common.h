@@ -141,6 +141,9 @@ struct DwMfmaGeom {
 DwMfmaGeom dw_mfma_geom(const pasn_conv_desc& d, int dtype);
 int launch_dw_mfma(const void* x, const float* w, const float* scale, const float* bias, void* y, float* pool, const pasn_conv_desc& d,
                    const DwMfmaGeom& g, hipStream_t s, int stats = 0, const float* shift = nullptr);  // stats: pool = [N][chunks][2][Cp]: (sum, sum of squares) of (raw output - shift[c])
+// dwtemporal.hip (round 5): depthwise (kt,1,1) conv, kt = 3 / 5, stride 1: thread = (position, 8 channels) marching along T with a register ring
+bool dw_temporal_applicable(const pasn_conv_desc& d, int dtype);
+int launch_dw_temporal(const void* x, const float* w, const float* scale, const float* bias, void* y, const pasn_conv_desc& d, int dtype, hipStream_t s);
 // tconv_ws.hip (round 5): temporal (3,1,1) stride-1 conv, weight-stationary and T-marching (fragment-major weights, K = (dt, channel)); ok = 0: not covered
 struct TcGeom {
     int ok, KSF, CT, ptiles, bm, lds;  // k-steps per frame (Cin_p / 16), channel tiles of 32, tiles per frame and their positions (<= 64), dynamic LDS

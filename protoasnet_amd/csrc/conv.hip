@@ -934,6 +934,7 @@ extern "C" int pasn_conv3d_variant(const pasn_conv_desc* d, int dtype, int flags
 
 extern "C" int pasn_dwconv3d_variant(const pasn_conv_desc* d, int dtype) {
     if (!d || d->Cout_p <= 0 || d->Cout_p % 8 != 0) return 0;
+    if (dw_temporal_applicable(*d, dtype)) return 70000 + d->kt;  // dwconv_t_kernel<dtype, KT> (without pool partial rows; with them the generic kernels)
     if (dw_tz_geom(*d, dtype).ok) return 60001;  // dwconv3d_tz_kernel (stride 1, planes 9 .. 14 wide)
     if (const DwMfmaGeom mf = dw_mfma_geom(*d, dtype); mf.ok) return 50001;  // dwconv3d_mfma_kernel (stride 1)
     const DwMarchGeom m = dw_march_geom(*d, dtype);
@@ -964,6 +965,7 @@ extern "C" int pasn_dwconv3d_fwd(const void* x, const float* w, const float* sca
     PASN_REQUIRE(conv_desc_ok(d), "bad geometry (channel strides must be multiples of 8)");
     PASN_REQUIRE(d->Cin == d->Cout && d->Cin_p == d->Cout_p, "depthwise conv keeps the channel count");
     hipStream_t s = (hipStream_t)stream;
+    if (!pool_partial && dw_temporal_applicable(*d, dtype)) return launch_dw_temporal(x, w, scale, bias, y, *d, dtype, s);  // (kt,1,1): T-marching register ring
     if (const DtGeom tz = dw_tz_geom(*d, dtype); tz.ok) return launch_dw_tz(x, w, scale, bias, y, pool_partial, *d, tz, s);
     const DwMfmaGeom mf = dw_mfma_geom(*d, dtype);
     if (mf.ok) return launch_dw_mfma(x, w, scale, bias, y, pool_partial, *d, mf, s);

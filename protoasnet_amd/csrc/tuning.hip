@@ -29,6 +29,7 @@ static const TuneEntry kRegistry[] = {
     {"PASN_DW_DGRAD_REDUCE",  "route", "0: depthwise dgrad without the fused backward sums of the producer unit"},
     {"PASN_DWWG_FUSED",       "route", "1: depthwise weight gradient with the three kt taps in one launch"},
     {"PASN_EXPDW",            "route", "0: no fused expand-conv + stencil launch (x3d_expdw.hip)"},
+    {"PASN_DW_TEMPORAL",      "route", "0: depthwise (kt,1,1) convs on the generic strip kernel instead of the T-marching kernel (dwtemporal.hip)"},
     {"PASN_DW_TZ",            "route", "0: the stride-1 stencils of planes 9 .. 14 wide on dwconv3d_mfma_kernel instead of the Toeplitz kernel (dw_tz.hip); 1: the Toeplitz kernel also where its blocks do not fit one round (more than 512)"},
     {"PASN_EXPDW_TZ",         "route", "0: stride-1 fused expand + stencil launches on the block-diagonal kernel (x3d_expdw.hip) instead of the Toeplitz kernel (x3d_expdw_tz.hip)"},
     {"PASN_EXPDW_S1",         "route", "stride-1 use of the fused expand + stencil launch: 0 off, 1 the SE blocks of wide planes only"},

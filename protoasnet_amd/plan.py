@@ -577,7 +577,11 @@ class PlanBuilder:
         self._use(xb, yb, pb)
         out_pos = y.N * y.positions
         dv = int(self.lib.pasn_dwconv3d_variant(dref, self.code))
-        if dv >= 60000:
+        if dv >= 70000 and not pool:
+            kname = f"dwconv_t_kernel<{self.tname},{dv - 70000}>"
+        elif dv >= 70000:  # with pool partial rows the (kt,1,1) layer stays on the generic kernel
+            kname = f"dwconv3d_kernel<{self.tname}>"
+        elif dv >= 60000:
             kname = f"dwconv3d_tz_kernel<{_lib.ACT[act]},{'true' if pool else 'false'}>"
         elif dv >= 50000:  # the instance as the profiler prints it: <rows per position tile, ablation build, compiled-in activation>
             actc = _lib.ACT[act]

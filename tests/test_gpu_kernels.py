@@ -1077,6 +1077,12 @@ DW_CASES = [
     (108, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 7, 6), "swish", False),  # X3D conv_b stride 1, Swish epilogue
     (432, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 13, 13), "none", True),  # widest stage, several pool blocks
     (520, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 5, 5), "none", True),    # > 512 channels: strip kernel + generic SE gate
+    # the temporal kernel (dwtemporal.hip: a thread marches along T with the window in registers): T shorter than the window, a channel tail, kt = 3
+    (24, (5, 1, 1), (1, 1, 1), (2, 0, 0), (1, 4, 7), "relu", False),
+    (24, (5, 1, 1), (1, 1, 1), (2, 0, 0), (2, 3, 3), "none", False),
+    (20, (5, 1, 1), (1, 1, 1), (2, 0, 0), (9, 6, 5), "swish", False),
+    (45, (3, 1, 1), (1, 1, 1), (1, 0, 0), (7, 5, 6), "relu", False),
+    (24, (5, 1, 1), (1, 1, 1), (2, 0, 0), (6, 4, 4), "none", True),     # with pool partial rows: the generic kernel keeps the layer
 ]
 
 
@@ -1286,6 +1292,8 @@ def test_dwconv3d_and_se(case, dtype):
     atol, rtol = _tols(dtype)
     if not pool:
         y = pb.dwconv(xa, conv, bn, act)
+        if k[1] == 1 and k[2] == 1:
+            assert pb.meta[-1]["kernel"].startswith("dwconv_t_kernel<"), pb.meta[-1]["kernel"]
         out = _run_single(pb, xa, y, xs)
         assert_close(_from_cl(out, c), ref, atol * max(1.0, float(ref.abs().max())), rtol, f"dwconv {case}")
         return
